@@ -1,0 +1,184 @@
+"""ctypes front-end of the CPU oracle (``oracle/xsdba_oracle.c``).
+
+TEST INFRASTRUCTURE ONLY: imported by ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` — never by ``xsdba_amd`` (the product fails loudly when its
+HIP library is missing instead of falling back to this).
+
+All functions take cell-major numpy arrays ``x[C, T]`` (any strides), 0-based ``gidx[T]`` (int32
+group of the window centre), and return new arrays; see the C file for the reference citations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+INTERP = {"nearest": 0, "linear": 1}
+EXTRAP = {"constant": 0, "nan": 1}
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "_build" / "libxsdba_oracle.so"
+    src = [_HERE / "xsdba_oracle.c", _HERE / "oracle_impl.inc"]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in src):
+        subprocess.run(["make", "-C", str(_HERE)], check=True, capture_output=True)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.xsdba_oracle_num_threads.restype = C.c_int
+    return _LIB
+
+
+def _dt(a):
+    if a.dtype == np.float32:
+        return 0
+    if a.dtype == np.float64:
+        return 1
+    raise TypeError(f"unsupported dtype {a.dtype}")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _strides(a):
+    """element strides (stride_t, stride_c) of a [C, T] array"""
+    return a.strides[1] // a.itemsize, a.strides[0] // a.itemsize
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+def num_threads() -> int:
+    return lib().xsdba_oracle_num_threads()
+
+
+def set_num_threads(n: int) -> None:
+    lib().xsdba_oracle_set_num_threads(C.c_int(n))
+
+
+def quantile_groups(x, gidx, G, W, q):
+    x = np.asarray(x)
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    q = np.ascontiguousarray(q, x.dtype)
+    Cn, T = x.shape
+    out = np.empty((Cn, G, q.size), x.dtype)
+    st, sc = _strides(x)
+    _check(lib().xsdba_oracle_quantile_groups(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(gidx),
+                                              C.c_int(G), C.c_int(W), _p(q), C.c_int(q.size), _p(out)), "quantile_groups")
+    return out
+
+
+def eqm_train(ref, hist, gidx, G, W, q, kind):
+    ref = np.asarray(ref)
+    hist = np.ascontiguousarray(hist, ref.dtype) if hist.strides != ref.strides else hist
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    q = np.ascontiguousarray(q, ref.dtype)
+    Cn, T = ref.shape
+    af = np.empty((Cn, G, q.size), ref.dtype)
+    hq = np.empty_like(af)
+    if hist.strides != ref.strides:
+        ref = np.ascontiguousarray(ref)
+    st, sc = _strides(ref)
+    _check(lib().xsdba_oracle_eqm_train(_p(ref), _p(hist), _dt(ref), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(gidx),
+                                        C.c_int(G), C.c_int(W), _p(q), C.c_int(q.size), C.c_char(kind.encode()),
+                                        _p(af), _p(hq)), "eqm_train")
+    return af, hq
+
+
+def dqm_train(ref, hist, gidx, G, W, q, kind):
+    ref = np.ascontiguousarray(ref)
+    hist = np.ascontiguousarray(hist, ref.dtype)
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    q = np.ascontiguousarray(q, ref.dtype)
+    Cn, T = ref.shape
+    af = np.empty((Cn, G, q.size), ref.dtype)
+    hq = np.empty_like(af)
+    sc_ = np.empty((Cn, G), ref.dtype)
+    st, sc = _strides(ref)
+    _check(lib().xsdba_oracle_dqm_train(_p(ref), _p(hist), _dt(ref), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(gidx),
+                                        C.c_int(G), C.c_int(W), _p(q), C.c_int(q.size), C.c_char(kind.encode()),
+                                        _p(af), _p(hq), _p(sc_)), "dqm_train")
+    return af, hq, sc_
+
+
+def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="+", return_nodes=False):
+    """``kind=None`` returns the interpolated factors themselves (utils.interp_on_quantiles)."""
+    sim = np.asarray(sim)
+    af = np.ascontiguousarray(af, sim.dtype)
+    hist_q = np.ascontiguousarray(hist_q, sim.dtype)
+    Cn, T = sim.shape
+    G, Q = af.shape[1:]
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T), np.int32)
+    scen = np.empty((Cn, T), sim.dtype)
+    node = np.empty((Cn, T), np.int32) if return_nodes else None
+    st, sc = _strides(sim)
+    k = C.c_char(kind.encode()) if kind else C.c_char(b"\0")
+    _check(lib().xsdba_oracle_qm_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(af), _p(hist_q),
+                                        C.c_int(G), C.c_int(Q), _p(gidx), C.c_int(INTERP[interp]),
+                                        C.c_int(EXTRAP[extrap]), k, _p(scen), _i64(1), _i64(T), _p(node)), "qm_adjust")
+    return (scen, node) if return_nodes else scen
+
+
+def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+"):
+    sim = np.asarray(sim)
+    af = np.ascontiguousarray(af, sim.dtype)
+    hist_q = np.ascontiguousarray(hist_q, sim.dtype)
+    scaling = np.ascontiguousarray(scaling, sim.dtype)
+    Cn, T = sim.shape
+    G, Q = af.shape[1:]
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    tn = np.ascontiguousarray(time_num, np.float64)
+    scen = np.empty((Cn, T), sim.dtype)
+    trend = np.empty((Cn, T), sim.dtype)
+    st, sc = _strides(sim)
+    _check(lib().xsdba_oracle_dqm_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(af), _p(hist_q),
+                                         _p(scaling), C.c_int(G), C.c_int(Q), _p(gidx), C.c_int(W), _p(tn),
+                                         C.c_int(degree), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),
+                                         C.c_char(kind.encode()), _p(scen), _p(trend), _i64(1), _i64(T)), "dqm_adjust")
+    return scen, trend
+
+
+def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest", extrap="constant", kind="+"):
+    sim = np.asarray(sim)
+    af = np.ascontiguousarray(af, sim.dtype)
+    quantiles = np.ascontiguousarray(quantiles, sim.dtype)
+    Cn, T = sim.shape
+    G, Q = af.shape[1:]
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    scen = np.empty((Cn, T), sim.dtype)
+    sim_q = np.empty((Cn, T), np.float64)
+    st, sc = _strides(sim)
+    _check(lib().xsdba_oracle_qdm_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(af),
+                                         _p(quantiles), C.c_int(G), C.c_int(Q), _p(gidx), C.c_int(W),
+                                         C.c_int(int(bool(rank_window))), C.c_int(INTERP[interp]),
+                                         C.c_int(EXTRAP[extrap]), C.c_char(kind.encode()), _p(scen), _p(sim_q),
+                                         _i64(1), _i64(T)), "qdm_adjust")
+    return scen, sim_q
+
+
+def rank_groups(x, gidx, G, W, rank_window=False):
+    x = np.asarray(x)
+    Cn, T = x.shape
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    out = np.empty((Cn, T), np.float64)
+    st, sc = _strides(x)
+    _check(lib().xsdba_oracle_rank_groups(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(gidx), C.c_int(G),
+                                          C.c_int(W), C.c_int(int(bool(rank_window))), _p(out), _i64(1), _i64(T)),
+           "rank_groups")
+    return out

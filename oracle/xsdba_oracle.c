@@ -1,0 +1,241 @@
+/*
+ * xsdba_oracle.c — CPU restatement ("oracle") of xsdba's empirical-quantile-mapping hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker / the reported CPU baseline.
+ * The product path (xsdba_amd + libxsdba_hip.so) never links, imports or falls back to it.
+ *
+ * Parity status: PINNED.  The restatement is checked (tests/test_oracle_golden.py) against golden
+ * vectors generated in the build container by executing the reference's own kernel source
+ * (/root/reference/src/xsdba/nbutils.py via stub numba/xarray modules; utils.py functions
+ * AST-extracted; real scipy interp1d/griddata) composed as _adjustment.py does — see
+ * tests/golden/make_golden.py — and against the reference tests' known answers
+ * (tests/test_utils.py:68-113,149-194; tests/test_nbutils.py:23-34; tests/test_adjustment.py:947-989).
+ * Not restated (returns -3): grouped interp="linear"/"cubic", which the reference routes through
+ * scipy.griddata's Qhull triangulation (utils.py:391-396).
+ *
+ * Conventions shared with include/xsdba_hip.h: series are addressed as x[c*stride_c + t*stride_t]
+ * (element strides); tables are [cell][group][quantile] contiguous; group_of_time[t] in [0,G) is the
+ * 0-based group of the window CENTRE (coordinate g+1), -1 = no group; dtype 0 = float32, 1 = float64;
+ * interp 0 = nearest, 1 = linear; extrap 0 = constant, 1 = nan; kind '+' or '*'.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int G, W;
+    int64_t T;
+    const int32_t *group_of_time;
+    int64_t *row_ptr;  /* [G+1] windowed rows: time index of every in-range window slot, with multiplicity */
+    int32_t *row_idx;
+    int64_t *mem_ptr;  /* [G+1] the times whose own group is g (window centres), in time order */
+    int32_t *mem_idx;
+    int64_t max_row;
+} group_plan;
+
+/* base.py:232-272: rolling(center=True, W).construct -> slot j of centre t' is x[t' + j - W//2];
+ * groupby on the group of t'. */
+static int plan_build(group_plan *pl, const int32_t *gidx, int64_t T, int G, int W)
+{
+    memset(pl, 0, sizeof(*pl));
+    pl->G = G; pl->W = W; pl->T = T; pl->group_of_time = gidx;
+    pl->row_ptr = (int64_t *)calloc((size_t)G + 1, sizeof(int64_t));
+    pl->mem_ptr = (int64_t *)calloc((size_t)G + 1, sizeof(int64_t));
+    if (!pl->row_ptr || !pl->mem_ptr) return -2;
+    int h = W / 2;
+    for (int64_t t = 0; t < T; t++) {
+        int g = gidx[t];
+        if (g < 0) continue;
+        if (g >= G) return -1;
+        int64_t lo = t - h, hi = t - h + W - 1;
+        if (lo < 0) lo = 0;
+        if (hi > T - 1) hi = T - 1;
+        pl->row_ptr[g + 1] += hi - lo + 1;
+        pl->mem_ptr[g + 1] += 1;
+    }
+    for (int g = 0; g < G; g++) {
+        if (pl->row_ptr[g + 1] > pl->max_row) pl->max_row = pl->row_ptr[g + 1];
+        pl->row_ptr[g + 1] += pl->row_ptr[g];
+        pl->mem_ptr[g + 1] += pl->mem_ptr[g];
+    }
+    pl->row_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(pl->row_ptr[G] + 1));
+    pl->mem_idx = (int32_t *)malloc(sizeof(int32_t) * (size_t)(pl->mem_ptr[G] + 1));
+    int64_t *rp = (int64_t *)malloc(sizeof(int64_t) * (size_t)G * 2), *mp = rp + G;
+    if (!pl->row_idx || !pl->mem_idx || !rp) return -2;
+    for (int g = 0; g < G; g++) { rp[g] = pl->row_ptr[g]; mp[g] = pl->mem_ptr[g]; }
+    for (int64_t t = 0; t < T; t++) {
+        int g = gidx[t];
+        if (g < 0) continue;
+        pl->mem_idx[mp[g]++] = (int32_t)t;
+        for (int j = 0; j < W; j++) {
+            int64_t tt = t + j - h;
+            if (tt >= 0 && tt < T) pl->row_idx[rp[g]++] = (int32_t)tt;
+        }
+    }
+    free(rp);
+    return 0;
+}
+
+static void plan_free(group_plan *pl)
+{
+    free(pl->row_ptr); free(pl->row_idx); free(pl->mem_ptr); free(pl->mem_idx);
+}
+
+#define REAL float
+#define SFX f32
+#include "oracle_impl.inc"
+#undef REAL
+#undef SFX
+#define REAL double
+#define SFX f64
+#include "oracle_impl.inc"
+#undef REAL
+#undef SFX
+
+#define API __attribute__((visibility("default")))
+
+API int xsdba_oracle_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+API void xsdba_oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
+API int xsdba_oracle_quantile_groups(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                     const int32_t *gidx, int G, int W, const void *q, int Q, void *out)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (!rc)
+        rc = dtype == 0 ? quantile_groups_f32((const float *)x, T, C, st, sc, &pl, (const float *)q, Q, (float *)out)
+                        : quantile_groups_f64((const double *)x, T, C, st, sc, &pl, (const double *)q, Q, (double *)out);
+    plan_free(&pl);
+    return rc;
+}
+
+API int xsdba_oracle_eqm_train(const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
+                               int64_t sc, const int32_t *gidx, int G, int W, const void *q, int Q, char kind,
+                               void *af, void *hist_q)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (!rc)
+        rc = dtype == 0 ? train_f32((const float *)ref, (const float *)hist, T, C, st, sc, &pl, (const float *)q, Q,
+                                    kind, (float *)af, (float *)hist_q, NULL)
+                        : train_f64((const double *)ref, (const double *)hist, T, C, st, sc, &pl, (const double *)q,
+                                    Q, kind, (double *)af, (double *)hist_q, NULL);
+    plan_free(&pl);
+    return rc;
+}
+
+API int xsdba_oracle_dqm_train(const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
+                               int64_t sc, const int32_t *gidx, int G, int W, const void *q, int Q, char kind,
+                               void *af, void *hist_q, void *scaling)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (!rc)
+        rc = dtype == 0 ? train_f32((const float *)ref, (const float *)hist, T, C, st, sc, &pl, (const float *)q, Q,
+                                    kind, (float *)af, (float *)hist_q, (float *)scaling)
+                        : train_f64((const double *)ref, (const double *)hist, T, C, st, sc, &pl, (const double *)q,
+                                    Q, kind, (double *)af, (double *)hist_q, (double *)scaling);
+    plan_free(&pl);
+    return rc;
+}
+
+/* kind == 0: plain utils.interp_on_quantiles (returns the interpolated yq instead of sim (+|*) yq) */
+API int xsdba_oracle_qm_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                               const void *af, const void *hist_q, int G, int Q, const int32_t *gidx, int interp,
+                               int extrap, char kind, void *scen, int64_t ost, int64_t osc, int32_t *node_index)
+{
+    return dtype == 0 ? qm_adjust_f32((const float *)sim, T, C, st, sc, (const float *)af, (const float *)hist_q, G,
+                                      Q, gidx, interp, extrap, kind, (float *)scen, ost, osc, node_index)
+                      : qm_adjust_f64((const double *)sim, T, C, st, sc, (const double *)af, (const double *)hist_q,
+                                      G, Q, gidx, interp, extrap, kind, (double *)scen, ost, osc, node_index);
+}
+
+API int xsdba_oracle_dqm_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                const void *af, const void *hist_q, const void *scaling, int G, int Q,
+                                const int32_t *gidx, int W, const double *time_num, int degree, int interp,
+                                int extrap, char kind, void *scen, void *trend, int64_t ost, int64_t osc)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (!rc)
+        rc = dtype == 0 ? dqm_adjust_f32((const float *)sim, T, C, st, sc, (const float *)af, (const float *)hist_q,
+                                         (const float *)scaling, G, Q, &pl, time_num, degree, interp, extrap, kind,
+                                         (float *)scen, (float *)trend, ost, osc)
+                        : dqm_adjust_f64((const double *)sim, T, C, st, sc, (const double *)af,
+                                         (const double *)hist_q, (const double *)scaling, G, Q, &pl, time_num, degree,
+                                         interp, extrap, kind, (double *)scen, (double *)trend, ost, osc);
+    plan_free(&pl);
+    return rc;
+}
+
+API int xsdba_oracle_qdm_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                const void *af, const void *quantiles, int G, int Q, const int32_t *gidx, int W,
+                                int rank_window, int interp, int extrap, char kind, void *scen, double *sim_q,
+                                int64_t ost, int64_t osc)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (!rc)
+        rc = dtype == 0 ? qdm_adjust_f32((const float *)sim, T, C, st, sc, (const float *)af,
+                                         (const float *)quantiles, G, Q, &pl, rank_window, interp, extrap, kind,
+                                         (float *)scen, sim_q, ost, osc)
+                        : qdm_adjust_f64((const double *)sim, T, C, st, sc, (const double *)af,
+                                         (const double *)quantiles, G, Q, &pl, rank_window, interp, extrap, kind,
+                                         (double *)scen, sim_q, ost, osc);
+    plan_free(&pl);
+    return rc;
+}
+
+/* utils.rank(pct=True) through Grouper.apply for every cell: out[c*osc + t*ost] float64 */
+API int xsdba_oracle_rank_groups(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                 const int32_t *gidx, int G, int W, int rank_window, double *out, int64_t ost,
+                                 int64_t osc)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (rc) { plan_free(&pl); return rc; }
+    size_t nb = (size_t)(pl.max_row > T ? pl.max_row : T);
+#pragma omp parallel
+    {
+        void *xc = malloc((dtype ? 8 : 4) * ((size_t)T + nb));
+        double *sq = (double *)malloc(sizeof(double) * (size_t)T);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t c = 0; c < C; c++) {
+            if (dtype == 0) {
+                float *xf = (float *)xc;
+                for (int64_t t = 0; t < T; t++) xf[t] = ((const float *)x)[c * sc + t * st];
+                group_pct_rank_f32(xf, T, &pl, rank_window, sq, xf + T);
+            } else {
+                double *xd = (double *)xc;
+                for (int64_t t = 0; t < T; t++) xd[t] = ((const double *)x)[c * sc + t * st];
+                group_pct_rank_f64(xd, T, &pl, rank_window, sq, xd + T);
+            }
+            for (int64_t t = 0; t < T; t++) out[c * osc + t * ost] = sq[t];
+        }
+        free(xc); free(sq);
+    }
+    plan_free(&pl);
+    return 0;
+}
