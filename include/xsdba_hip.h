@@ -1,0 +1,154 @@
+/*
+ * xsdba_hip.h — C ABI of libxsdba_hip.so: the MI355X (gfx950) implementation of xsdba's
+ * empirical-quantile-mapping hot path (EQM / DQM / QDM train + adjust over grouped time windows).
+ *
+ * This is the drop-in boundary.  The reference (Ouranosinc/xsdba, pure Python + numba) has no FFI of
+ * its own; each entry point below replaces one Python-level compute function that the reference's
+ * TrainAdjust classes call, and is what a ctypes binding inside xsdba would bind (INTEGRATION.md shows
+ * that stub).  Citations are file:line under /root/reference/src/xsdba/.
+ *
+ * Conventions
+ *   - plain C symbols, `int` status: 0 ok; <0 argument / capability error (XSDBA_E_*); >0 a hipError_t.
+ *     The message of the last failure on the calling thread: xsdba_hip_last_error().  Nothing throws.
+ *   - every data pointer may be a HOST pointer or a DEVICE pointer (hipMalloc / xsdba_hip_malloc /
+ *     any other allocator on the context's device); the library detects which (hipPointerGetAttributes).
+ *     Host buffers are staged through device scratch owned by the context and results are copied back
+ *     before the call returns.  With device pointers the call only enqueues work on the context's
+ *     stream (call xsdba_hip_synchronize to wait); nothing is allocated after the first call of a
+ *     given shape.
+ *   - series blocks are addressed as x[c*stride_c + t*stride_t] (ELEMENT strides): stride_t == 1 is the
+ *     cell-major [cell][time] layout, stride_c == 1 the time-major [time][cell] layout of an
+ *     xarray (time, lat, lon) cube.  Host series must be dense (cover exactly n_cell*n_time elements).
+ *   - trained tables are [cell][group][quantile] contiguous, `scaling` is [cell][group].
+ *   - dtype: XSDBA_F32 or XSDBA_F64 for every floating array of the call (sim_q / time_num / newg are
+ *     always float64 as in the reference).
+ *   - group_of_time[t] in [0, n_groups): 0-based group of time step t (the reference's group coordinate
+ *     is group_of_time[t] + 1: month 1..12, dayofyear 1..366, base.py:207-230); -1 = belongs to no group.
+ *     `window` is Grouper.window (base.py:128-175): the row of group g holds x[t' + j - window/2] for every
+ *     t' with group_of_time[t'] == g and j in [0, window), slots outside the series being NaN padding
+ *     (xarray rolling(center=True).construct, base.py:261-262).
+ *   - kind: '+' additive or '*' multiplicative (utils.py:130-177).
+ *   - one context per (process, device); calls on one context are serialised by the caller, contexts on
+ *     different devices are independent (one process per GPU under torch.distributed / mpirun).
+ */
+#ifndef XSDBA_HIP_H
+#define XSDBA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XSDBA_HIP_ABI_VERSION 1
+
+enum { XSDBA_F32 = 0, XSDBA_F64 = 1 };
+enum { XSDBA_INTERP_NEAREST = 0, XSDBA_INTERP_LINEAR = 1 };
+enum { XSDBA_EXTRAP_CONSTANT = 0, XSDBA_EXTRAP_NAN = 1 };
+
+enum {
+    XSDBA_E_ARG = -1,          /* bad argument (null pointer, size, dtype, kind, group index out of range) */
+    XSDBA_E_NOMEM = -2,        /* host allocation failed */
+    XSDBA_E_UNSUPPORTED = -3,  /* e.g. grouped interp="linear"/"cubic" (Qhull in the reference, utils.py:391-396) */
+    XSDBA_E_DEGREE = -4,       /* PolyDetrend degree other than 0 or 1 */
+    XSDBA_E_ROW_TOO_LONG = -5, /* a group row does not fit the LDS sort (see DESIGN.md limits) */
+    XSDBA_E_NO_DEVICE = -6     /* no usable gfx950 device / kernel image */
+};
+
+typedef struct xsdba_hip_ctx xsdba_hip_ctx;
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+int xsdba_hip_abi_version(void);
+int xsdba_hip_device_count(int *count);
+int xsdba_hip_create(int device, xsdba_hip_ctx **ctx);
+int xsdba_hip_destroy(xsdba_hip_ctx *ctx);
+int xsdba_hip_last_error(char *buf, size_t buflen);
+int xsdba_hip_synchronize(xsdba_hip_ctx *ctx);
+/* the hipStream_t every kernel of this context is launched on (for event timing / stream ordering) */
+int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream);
+int xsdba_hip_malloc(xsdba_hip_ctx *ctx, size_t bytes, void **dptr);
+int xsdba_hip_free(xsdba_hip_ctx *ctx, void *dptr);
+int xsdba_hip_memcpy_h2d(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int xsdba_hip_memcpy_d2h(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int xsdba_hip_memset(xsdba_hip_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
+ * enable != 0 brackets every kernel launch with an event pair; xsdba_hip_profile_read synchronises the
+ * stream and returns, for up to `cap` distinct kernels, name / launch count / total milliseconds
+ * (names are static strings); *n = number of entries.  reset != 0 clears the table afterwards. */
+int xsdba_hip_profile_enable(xsdba_hip_ctx *ctx, int enable);
+int xsdba_hip_profile_read(xsdba_hip_ctx *ctx, const char **names, int64_t *counts, double *total_ms, int cap,
+                           int *n, int reset);
+/* whole-region timing: record events on the context's stream around a region */
+int xsdba_hip_timer_start(xsdba_hip_ctx *ctx);
+int xsdba_hip_timer_stop(xsdba_hip_ctx *ctx, double *elapsed_ms);
+
+/* ---- a4: nbutils.quantile through Grouper.apply (nbutils.py:113-148, 198-271; base.py:347-457) ----
+ * out[c][g][k] = type-7 NaN-skipping quantile q[k] of the row of group g of cell c. */
+int xsdba_hip_quantile_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
+                              int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
+                              int32_t window, const void *q, int32_t nq, void *out);
+
+/* ---- a9: _adjustment.eqm_train (_adjustment.py:193-286), called by EmpiricalQuantileMapping._train and
+ * QuantileDeltaMapping (adjustment.py:485-495, 674).  af = ref_q - hist_q or ref_q / hist_q. */
+int xsdba_hip_eqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t n_time,
+                        int64_t n_cell, int64_t stride_t, int64_t stride_c, const int32_t *group_of_time,
+                        int32_t n_groups, int32_t window, const void *q, int32_t nq, char kind, void *af,
+                        void *hist_q);
+
+/* ---- a10: _adjustment.dqm_train (_adjustment.py:95-190; adjustment.py:615-625): quantiles of the
+ * group-mean-normalised series, plus scaling = mean(ref) - mean(hist) or mean(ref)/mean(hist). */
+int xsdba_hip_dqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t n_time,
+                        int64_t n_cell, int64_t stride_t, int64_t stride_c, const int32_t *group_of_time,
+                        int32_t n_groups, int32_t window, const void *q, int32_t nq, char kind, void *af,
+                        void *hist_q, void *scaling);
+
+/* ---- a11-a14: _adjustment.qm_adjust (_adjustment.py:594-676; adjustment.py:519-528) =
+ * utils.interp_on_quantiles(sim, hist_q, af) (utils.py:408-513) + apply_correction.
+ * n_groups == 1 is the ungrouped 1-D path (scipy interp1d semantics, utils.py:350-377; nearest or linear);
+ * n_groups > 1 is the grouped path on the cyclically extended table (utils.py:284-314, 380-400) with the
+ * true 2-D nearest neighbour and nbutils._extrapolate_on_quantiles (nbutils.py:397-416); interp must be
+ * NEAREST there.  kind == 0 returns the interpolated factor itself.  node_index (nullable, int32
+ * [cell][time]): flat index r*nq+k of the chosen node on the (n_groups+2)-row extended table, -1 when
+ * the value came from extrapolation / NaN (parity instrumentation). */
+int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                        int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q, int32_t n_groups,
+                        int32_t nq, const int32_t *group_of_time, int interp, int extrap, char kind, void *scen,
+                        int64_t out_stride_t, int64_t out_stride_c, int32_t *node_index);
+
+/* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
+ * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`
+ * (detrending.py:165-208; float64 abscissa, e.g. ns since 1970 as xarray.polyfit uses), quantile
+ * mapping of the detrended series, retrend.  trend (nullable) has the layout of scen. */
+int xsdba_hip_dqm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                         int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q,
+                         const void *scaling, int32_t n_groups, int32_t nq, const int32_t *group_of_time,
+                         int32_t window, const double *time_num, int32_t degree, int interp, int extrap, char kind,
+                         void *scen, void *trend, int64_t out_stride_t, int64_t out_stride_c);
+
+/* ---- a18-a19: _adjustment.qdm_adjust (_adjustment.py:783-886; adjustment.py:728-737): sim_q =
+ * utils.rank(pct=True) within the exact group (rank_window == 0) or the windowed row (rank_window != 0)
+ * (utils.py:573-638), af interpolated on the quantile axis, applied to sim.  sim_q (nullable) is float64
+ * with the layout of scen. */
+int xsdba_hip_qdm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                         int64_t stride_t, int64_t stride_c, const void *af, const void *quantiles,
+                         int32_t n_groups, int32_t nq, const int32_t *group_of_time, int32_t window,
+                         int rank_window, int interp, int extrap, char kind, void *scen, double *sim_q,
+                         int64_t out_stride_t, int64_t out_stride_c);
+
+/* ---- a18: utils.rank(pct=True) through Grouper.apply (utils.py:573-638): float64 out[c*osc + t*ost] */
+int xsdba_hip_rank_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
+                          int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
+                          int32_t window, int rank_window, double *out, int64_t out_stride_t, int64_t out_stride_c);
+
+/* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
+int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
+                                int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
+                                int32_t window, const double *time_num, int32_t degree, void *trend,
+                                int64_t out_stride_t, int64_t out_stride_c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XSDBA_HIP_H */

@@ -182,3 +182,16 @@ def rank_groups(x, gidx, G, W, rank_window=False):
                                           C.c_int(W), C.c_int(int(bool(rank_window))), _p(out), _i64(1), _i64(T)),
            "rank_groups")
     return out
+
+
+def polydetrend_trend(x, gidx, G, W, time_num, degree=1):
+    x = np.asarray(x)
+    Cn, T = x.shape
+    gidx = np.ascontiguousarray(gidx, np.int32)
+    tn = np.ascontiguousarray(time_num, np.float64)
+    out = np.empty((Cn, T), x.dtype)
+    st, sc = _strides(x)
+    _check(lib().xsdba_oracle_polydetrend_trend(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(gidx),
+                                                C.c_int(G), C.c_int(W), _p(tn), C.c_int(degree), _p(out), _i64(1),
+                                                _i64(T)), "polydetrend_trend")
+    return out

@@ -239,3 +239,35 @@ API int xsdba_oracle_rank_groups(const void *x, int dtype, int64_t T, int64_t C,
     plan_free(&pl);
     return 0;
 }
+
+/* PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208): out[c*osc + t*ost] */
+API int xsdba_oracle_polydetrend_trend(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                       const int32_t *gidx, int G, int W, const double *time_num, int degree,
+                                       void *trend, int64_t ost, int64_t osc)
+{
+    if (degree < 0 || degree > 1) return -4;
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (rc) { plan_free(&pl); return rc; }
+#pragma omp parallel
+    {
+        void *buf = malloc((dtype ? 8 : 4) * (size_t)T * 3);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t c = 0; c < C; c++) {
+            if (dtype == 0) {
+                float *xc = (float *)buf, *tr = xc + T, *m = tr + T;
+                for (int64_t t = 0; t < T; t++) xc[t] = ((const float *)x)[c * sc + t * st];
+                group_trend_f32(xc, T, &pl, time_num, degree, tr, m);
+                for (int64_t t = 0; t < T; t++) ((float *)trend)[c * osc + t * ost] = tr[t];
+            } else {
+                double *xc = (double *)buf, *tr = xc + T, *m = tr + T;
+                for (int64_t t = 0; t < T; t++) xc[t] = ((const double *)x)[c * sc + t * st];
+                group_trend_f64(xc, T, &pl, time_num, degree, tr, m);
+                for (int64_t t = 0; t < T; t++) ((double *)trend)[c * osc + t * ost] = tr[t];
+            }
+        }
+        free(buf);
+    }
+    plan_free(&pl);
+    return 0;
+}

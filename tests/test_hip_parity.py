@@ -1,0 +1,347 @@
+"""GPU parity: the HIP path (through the C ABI of libxsdba_hip.so) against the CPU oracle on the same
+inputs, and against the committed golden vectors generated from the reference's own kernels.
+
+Bars:
+  * integer artefacts — valid counts / order-statistic selection (seen through hist_q), nearest-node
+    indexes, ranks (sim_q) — bit-exact against the oracle;
+  * float32/float64 values: bit-exact against the oracle for EQM/QDM (same arithmetic, fp-contract off
+    on both sides); DQM quantities within 2 ulp (float64 block-reduction order of the group mean);
+  * against the reference-generated golden vectors: 1e-5 relative (float tolerance of north_star), with
+    exact nearest-neighbour distance ties accepted (cKDTree's choice is implementation-defined).
+"""
+from __future__ import annotations
+
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import assert_close, assert_close_or_tie
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from xsdba_amd import hip as h
+
+    h.default_context(0)  # raises loudly if the library or the GPU is missing
+    return h
+
+
+def _doy_month(T, start=0):
+    d0 = (np.arange(T) + start) % 365
+    cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
+    return d0.astype(np.int32), (np.searchsorted(cum, d0, side="right") - 1).astype(np.int32)
+
+
+def _nodes(n, dtype=np.float32):
+    return ((np.arange(n) + 0.5) / n).astype(dtype)
+
+
+def _synth(rng, C, T, kind, dtype=np.float32, nan_frac=0.0):
+    doy, _ = _doy_month(T)
+    t = np.arange(T)
+    if kind == "+":
+        off = rng.standard_normal((C, 1)) * 3
+        ref = 280 - 20 * np.cos(2 * np.pi * (doy + 1) / 365) + 2 * rng.random((C, T)) + 0.1 * t / 365 + off
+        hist = 280 - 18 * np.cos(2 * np.pi * (doy + 1) / 365) + 2 * rng.random((C, T)) + 0.11 * t / 365 + off
+        sim = 281 - 18 * np.cos(2 * np.pi * (doy + 1) / 365) + 2.2 * rng.random((C, T)) + 0.15 * t / 365 + off
+    else:
+        ref, hist, sim = rng.gamma(4, 7.5, (C, T)), rng.gamma(8.15, 3.68, (C, T)), rng.gamma(16, 2.63, (C, T))
+    out = [a.astype(dtype) for a in (ref, hist, sim)]
+    if nan_frac:
+        for a in out:
+            a[rng.random(a.shape) < nan_frac] = np.nan
+    return out
+
+
+GROUPINGS = {
+    "time": lambda T: (np.zeros(T, np.int32), 1, 1),
+    "month": lambda T: (_doy_month(T)[1], 12, 1),
+    "doy31": lambda T: (_doy_month(T)[0], 365, 31),
+    "doy1": lambda T: (_doy_month(T)[0], 365, 1),
+    "month5": lambda T: (_doy_month(T)[1], 12, 5),
+    "doy30_even": lambda T: (_doy_month(T)[0], 365, 30),
+}
+
+
+# ------------------------------------------------------------------------------------------------
+# train
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gname", list(GROUPINGS))
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_eqm_train_bit_exact_vs_oracle(hip, gname, kind, dtype):
+    rng = np.random.default_rng(zlib.crc32(f"{gname}{kind}".encode()))
+    T, C = 3650 if gname != "time" else 2500, 5
+    gidx, G, W = GROUPINGS[gname](T)
+    ref, hist, _ = _synth(rng, C, T, kind, dtype, nan_frac=0.02)
+    ref[3] = np.nan  # an all-NaN cell
+    hist[4, : T // 2] = np.nan
+    q = _nodes(20, dtype)
+    af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
+    eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    assert_close(hq, ehq, rtol=0.0, what="hist_q")
+    assert_close(af, eaf, rtol=0.0, what="af")
+
+
+@pytest.mark.parametrize("gname", ["time", "month", "doy31"])
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_train_vs_oracle(hip, gname, kind):
+    rng = np.random.default_rng(7)
+    T, C = 3650, 4
+    gidx, G, W = GROUPINGS[gname](T)
+    ref, hist, _ = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+    q = _nodes(20)
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind)
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+    scale = float(np.nanmax(np.abs(ref)))
+    atol = 2.4e-7 * scale if kind == "+" else 2.4e-7
+    assert_close(sc, esc, rtol=2.4e-7, atol=atol, what="scaling")
+    assert_close(hq, ehq, rtol=2.4e-7, atol=atol, what="hist_q")
+    assert_close(af, eaf, rtol=5e-7, atol=2 * atol, what="af")
+
+
+def test_quantile_groups_layouts_and_edges(hip):
+    rng = np.random.default_rng(3)
+    T, C = 1460, 7
+    doy, month = _doy_month(T)
+    x = (rng.standard_normal((C, T)) * 5 + 10).astype(np.float32)
+    x[0] = np.nan  # all-NaN -> NaN (tests/test_nbutils.py:31-34)
+    x[1, 1:] = np.nan  # single valid value -> every quantile equals it (tests/test_nbutils.py:26-29)
+    q = np.linspace(0.1, 0.99, 50).astype(np.float32)
+    exp = oracle.quantile_groups(x, month, 12, 1, q)
+    got_cm = hip.quantile_groups(x, month, 12, 1, q)
+    got_tm = hip.quantile_groups(np.ascontiguousarray(x.T).T, month, 12, 1, q)  # time-major storage
+    assert_close(got_cm, exp, rtol=0.0, what="cell-major")
+    assert_close(got_tm, exp, rtol=0.0, what="time-major")
+    assert np.isnan(got_cm[0]).all()
+    assert (got_cm[1, 0] == x[1, 0]).all()
+    # ragged groups with an empty one, and times that belong to no group
+    g = month.copy()
+    g[g == 5] = -1
+    exp = oracle.quantile_groups(x, g, 12, 1, q)
+    got = hip.quantile_groups(x, g, 12, 1, q)
+    assert_close(got, exp, rtol=0.0, what="empty group")
+    assert np.isnan(got[:, 5]).all()
+
+
+def test_quantile_long_row_group_time(hip):
+    # group="time" on a 30-year daily series: one 10950-long row per cell (16384-key LDS sort)
+    rng = np.random.default_rng(5)
+    x = rng.gamma(2.0, 3.0, (3, 10950)).astype(np.float32)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    q = _nodes(20)
+    g = np.zeros(10950, np.int32)
+    got = hip.quantile_groups(x, g, 1, 1, q)
+    assert_close(got, oracle.quantile_groups(x, g, 1, 1, q), rtol=0.0, what="long row")
+    # reference tests/test_nbutils.py:12-21: equals np.nanquantile to 6 decimals (relative to scale here)
+    np.testing.assert_allclose(got[:, 0], np.nanquantile(x.astype(np.float64), q.astype(np.float64), axis=1).T, rtol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# adjust
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("gname", ["time", "month", "doy31", "doy1"])
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_qm_adjust_bit_exact_vs_oracle(hip, gname, kind):
+    rng = np.random.default_rng(11)
+    T, C = 3650, 4
+    gidx, G, W = GROUPINGS[gname](T)
+    ref, hist, sim = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+    q = _nodes(20)
+    af, hq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    af[1, G // 2, 3] = np.nan  # holes in the tables
+    hq[2, 0, :] = np.nan
+    interps = ("nearest", "linear") if G == 1 else ("nearest",)
+    for interp in interps:
+        for extrap in ("constant", "nan"):
+            got, node = hip.qm_adjust(sim, af, hq, gidx, interp, extrap, kind, return_nodes=True)
+            exp, enode = oracle.qm_adjust(sim, af, hq, gidx, interp, extrap, kind, return_nodes=True)
+            assert_close(got, exp, rtol=0.0, what=f"scen {interp}/{extrap}")
+            if interp == "nearest":
+                np.testing.assert_array_equal(node, enode)  # nearest-node indexes: bit-exact
+    # time-major input and output
+    got_tm = hip.qm_adjust(np.ascontiguousarray(sim.T).T, af, hq, gidx, "nearest", "constant", kind, out_time_major=True)
+    assert_close(got_tm, oracle.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind), rtol=0.0, what="time-major")
+
+
+@pytest.mark.parametrize("gname", ["time", "doy31", "month"])
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_adjust_vs_oracle(hip, gname, kind):
+    rng = np.random.default_rng(13)
+    T, C = 3650, 3
+    gidx, G, W = GROUPINGS[gname](T)
+    ref, hist, sim = _synth(rng, C, T, kind, np.float32, nan_frac=0.005)
+    q = _nodes(20)
+    af, hq, sc = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+    tnum = (np.arange(T, dtype=np.float64) + 10957) * 86400e9
+    interps = ("nearest", "linear") if G == 1 else ("nearest",)
+    for interp in interps:
+        scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, interp, "constant", kind)
+        escen, etrend = oracle.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, interp, "constant", kind)
+        assert_close(trend, etrend, rtol=2.4e-7, what="trend")
+        ok = ~np.isnan(escen)
+        assert np.array_equal(np.isnan(scen), ~ok)
+        err = np.abs(scen[ok].astype(np.float64) - escen[ok]) / np.abs(escen[ok])
+        # a 1-ulp trend difference can move a detrended value across a table node: vanishing fraction
+        assert (err > 1e-6).mean() < 1e-3
+
+
+@pytest.mark.parametrize("gname", ["time", "doy31", "doy1", "month"])
+@pytest.mark.parametrize("rank_window", [False, True])
+def test_qdm_adjust_bit_exact_vs_oracle(hip, gname, rank_window):
+    rng = np.random.default_rng(17)
+    T, C = 1825, 3
+    gidx, G, W = GROUPINGS[gname](T)
+    kind = "*"
+    ref, hist, sim = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+    sim[0, : T // 3] = np.round(sim[0, : T // 3])  # ties -> average ranks
+    q = _nodes(20)
+    af, _ = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind)
+    escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind)
+    assert_close(sim_q, esim_q, rtol=0.0, what="sim_q (ranks)")
+    assert_close(scen, escen, rtol=0.0, what="scen")
+    r = hip.rank_groups(sim, gidx, G, W, rank_window)
+    assert_close(r, esim_q, rtol=0.0, what="rank_groups")
+
+
+def test_polydetrend_ramp(hip):
+    # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
+    T = int(20 * 365.25)
+    x = np.arange(T, dtype=np.float64)[None, :]
+    tnum = np.arange(T, dtype=np.float64) * 86400e9 + 9.6e17
+    trend = hip.polydetrend_trend(x, None, 1, 1, tnum, 1)
+    np.testing.assert_array_almost_equal(x - trend, 0)
+    assert_close(trend, oracle.polydetrend_trend(x, np.zeros(T, np.int32), 1, 1, tnum, 1), rtol=1e-12, what="trend")
+
+
+# ------------------------------------------------------------------------------------------------
+# golden vectors produced by the reference's own kernels
+# ------------------------------------------------------------------------------------------------
+PIPES = ["time_add", "time_mul", "month_add", "month_mul", "doy31_add", "doy31_mul", "doy1_add", "doy1_mul",
+         "month5_add", "month5_mul"]
+
+
+@pytest.mark.parametrize("name", PIPES)
+def test_golden_eqm_pipeline(hip, golden, name):
+    d = golden(f"pipeline_{name}")
+    gidx, G, W, kind = d["gidx"], int(d["G"]), int(d["W"]), str(d["kind"])
+    af, hq = hip.eqm_train(d["ref"], d["hist"], gidx, G, W, d["q"], kind)
+    scale_q = float(np.nanmax(np.abs(d["eqm_hist_q"])))
+    assert_close(hq, d["eqm_hist_q"], rtol=1e-5, what="hist_q")
+    assert_close(af, d["eqm_af"], rtol=1e-5, atol=1e-6 * scale_q if kind == "+" else 0, what="af")
+    for key in d.files:
+        if key.startswith("eqm_scen_"):
+            _, _, interp, extrap = key.split("_")
+            got = hip.qm_adjust(d["sim"], d["eqm_af"], d["eqm_hist_q"], gidx, interp, extrap, kind)
+            if G > 1:
+                assert_close_or_tie(got, d[key], d["sim"], d["eqm_hist_q"], d["eqm_af"], gidx, kind, 1e-5, what=key)
+            else:
+                assert_close(got, d[key], rtol=1e-5, what=key)
+
+
+@pytest.mark.parametrize("name", [p for p in PIPES if not p.startswith("month5")])
+def test_golden_qdm_dqm_pipeline(hip, golden, name):
+    d = golden(f"pipeline_{name}")
+    gidx, G, W, kind = d["gidx"], int(d["G"]), int(d["W"]), str(d["kind"])
+    for rw in (0, 1):
+        key = f"qdm_scen_nearest_rw{rw}"
+        scen, sim_q = hip.qdm_adjust(d["sim"], d["eqm_af"], d["q"], gidx, W, bool(rw), "nearest", "constant", kind)
+        assert_close(sim_q, d[f"qdm_simq_rw{rw}"], rtol=0.0, what="sim_q")  # ranks: bit-exact vs the reference
+        if G > 1:
+            assert_close_or_tie(scen, d[key], d["sim"], d["q"], d["eqm_af"], gidx, kind, 1e-5, what=key, newx=sim_q)
+        else:
+            assert_close(scen, d[key], rtol=1e-5, what=key)
+    if "dqm_af" in d.files:
+        scale = float(np.nanmax(np.abs(d["ref"])))
+        atol = 2e-6 * scale if kind == "+" else 2e-6
+        af, hq, sc = hip.dqm_train(d["ref"], d["hist"], gidx, G, W, d["q"], kind)
+        assert_close(sc, d["dqm_scaling"], rtol=1e-5, atol=atol, what="scaling")
+        assert_close(hq, d["dqm_hist_q"], rtol=1e-5, atol=atol, what="dqm hist_q")
+        scen, trend = hip.dqm_adjust(d["sim"], d["dqm_af"], d["dqm_hist_q"], d["dqm_scaling"], gidx, W, d["tns"], 1,
+                                     "nearest", "constant", kind)
+        assert_close(trend, d["dqm_trend"], rtol=1e-5, atol=atol, what="trend")
+        exp = d["dqm_scen_nearest"]
+        ok = ~np.isnan(exp)
+        assert np.array_equal(np.isnan(scen), ~ok)
+        err = np.abs(scen[ok].astype(np.float64) - exp[ok]) / np.maximum(np.abs(exp[ok]), 1e-30)
+        assert (err > 1e-5).mean() < 2e-3
+
+
+def test_golden_known_answer_qm(hip, golden):
+    # reference tests/test_adjustment.py:947-989 on float64 data
+    d = golden("known_answer_qm")
+    x, y, q = d["x"], d["y"], d["q50"]
+    for kind, tag in (("+", "add"), ("*", "mul")):
+        af, hq = hip.eqm_train(y[None], x[None], None, 1, 1, q, kind)
+        assert_close(af, d[f"eqm_af_{tag}"], rtol=0.0, what="af (float64, bit-exact vs reference kernel)")
+        p = hip.qm_adjust(x[None], af, hq, None, "linear", "constant", kind)
+        assert_close(p, d[f"eqm_p_linear_{tag}"], rtol=1e-15, what="p")
+        middle = (d["u"] > 1e-2) & (d["u"] < 0.99)
+        np.testing.assert_array_almost_equal(p[0][middle], y[middle], 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at larger sizes (oracle would take too long at BASELINE sizes)
+# ------------------------------------------------------------------------------------------------
+def test_properties_large(hip):
+    rng = np.random.default_rng(23)
+    C, T = 512, 10950
+    gidx, G, W = GROUPINGS["doy31"](T)
+    ref, hist, sim = _synth(rng, C, T, "+", np.float32)
+    q = _nodes(20)
+    af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
+    # quantiles are sorted along q and lie inside the data range
+    assert (np.diff(hq, axis=-1) >= 0).all()
+    assert (hq.min(axis=(1, 2)) >= hist.min(axis=1)).all() and (hq.max(axis=(1, 2)) <= hist.max(axis=1)).all()
+    # training on identical series gives zero additive factors (idempotence of the mapping)
+    af0, _ = hip.eqm_train(hist, hist, gidx, G, W, q, "+")
+    assert (af0 == 0).all()
+    scen0 = hip.qm_adjust(sim, af0, hq, gidx, "nearest", "constant", "+")
+    np.testing.assert_array_equal(scen0, sim)
+    # a subsample of cells agrees with the oracle bit for bit
+    sub = slice(0, 16)
+    eaf, ehq = oracle.eqm_train(ref[sub], hist[sub], gidx, G, W, q, "+")
+    assert_close(hq[sub], ehq, rtol=0.0, what="hist_q subsample")
+    assert_close(af[sub], eaf, rtol=0.0, what="af subsample")
+    scen = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", "+")
+    assert_close(scen[sub], oracle.qm_adjust(sim[sub], eaf, ehq, gidx, "nearest", "constant", "+"), rtol=0.0, what="scen")
+    # adjusting hist itself maps it onto ref's quantiles: group-wise means move toward ref
+    adj = hip.qm_adjust(hist, af, hq, gidx, "nearest", "constant", "+")
+    assert abs(float(adj.mean() - ref.mean())) < abs(float(hist.mean() - ref.mean())) + 1e-3
+
+
+def test_device_resident_roundtrip(hip):
+    """device pointers in -> device pointers out (the bench path): same numbers as host buffers."""
+    rng = np.random.default_rng(29)
+    C, T = 64, 3650
+    gidx, G, W = GROUPINGS["month"](T)
+    ref, hist, sim = _synth(rng, C, T, "+", np.float32)
+    q = _nodes(20)
+    ctx = hip.default_context(0)
+    dref, dhist, dsim = ctx.to_device(ref), ctx.to_device(hist), ctx.to_device(sim)
+    daf, dhq = hip.eqm_train(dref, dhist, gidx, G, W, q, "+")
+    dscen = hip.qm_adjust(dsim, daf, dhq, gidx, "nearest", "constant", "+")
+    ctx.synchronize()
+    af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
+    np.testing.assert_array_equal(daf.download(), af)
+    np.testing.assert_array_equal(dscen.download(), hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", "+"))
+    for a in (dref, dhist, dsim, daf, dhq, dscen):
+        a.free()
+
+
+def test_errors(hip):
+    from xsdba_amd._lib import XsdbaHipError
+
+    x = np.zeros((2, 100), np.float32)
+    q = _nodes(5)
+    with pytest.raises(XsdbaHipError):  # group index out of range
+        hip.quantile_groups(x, np.full(100, 7, np.int32), 4, 1, q)
+    with pytest.raises(XsdbaHipError):  # grouped linear interpolation is not implemented
+        hip.qm_adjust(x, np.zeros((2, 4, 5), np.float32), np.zeros((2, 4, 5), np.float32), np.zeros(100, np.int32), "linear")
+    with pytest.raises(TypeError):
+        hip.quantile_groups(x.astype(np.int32), None, 1, 1, q)

@@ -1,0 +1,197 @@
+"""ctypes binding of ``libxsdba_hip.so`` (C ABI: ``include/xsdba_hip.h``).
+
+The library is the only compute backend of this package: if it is missing, was not built for the GPU
+that is present, or no MI355X is visible, the calls below raise — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import threading
+from pathlib import Path
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "lib" / "libxsdba_hip.so"
+CSRC = _PKG / "csrc"
+
+F32, F64 = 0, 1
+INTERP = {"nearest": 0, "linear": 1}
+EXTRAP = {"constant": 0, "nan": 1}
+
+# every symbol include/xsdba_hip.h declares (checked by tests/test_cabi_symbols.py against the header)
+SYMBOLS = [
+    "xsdba_hip_abi_version", "xsdba_hip_device_count", "xsdba_hip_create", "xsdba_hip_destroy",
+    "xsdba_hip_last_error", "xsdba_hip_synchronize", "xsdba_hip_get_stream", "xsdba_hip_malloc", "xsdba_hip_free",
+    "xsdba_hip_memcpy_h2d", "xsdba_hip_memcpy_d2h", "xsdba_hip_memset", "xsdba_hip_profile_enable",
+    "xsdba_hip_profile_read", "xsdba_hip_timer_start", "xsdba_hip_timer_stop", "xsdba_hip_quantile_groups",
+    "xsdba_hip_eqm_train", "xsdba_hip_dqm_train", "xsdba_hip_qm_adjust", "xsdba_hip_dqm_adjust",
+    "xsdba_hip_qdm_adjust", "xsdba_hip_rank_groups", "xsdba_hip_polydetrend_trend",
+]
+
+
+class XsdbaHipError(RuntimeError):
+    """A call into libxsdba_hip.so returned a non-zero status."""
+
+    def __init__(self, code: int, message: str, what: str):
+        super().__init__(f"{what}: [{code}] {message}")
+        self.code = code
+
+
+def build(force: bool = False) -> Path:
+    """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / "api.hip", CSRC / "kernels.hpp", CSRC / "device_math.hpp", _PKG.parent / "include" / "xsdba_hip.h"]
+    if force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
+        env = dict(os.environ)
+        proc = subprocess.run(["make", "-C", str(CSRC)], env=env, capture_output=True, text=True)
+        if proc.returncode != 0:
+            raise RuntimeError(f"building libxsdba_hip.so failed:\n{proc.stdout}\n{proc.stderr}")
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (no implicit build, no fallback)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not LIB_PATH.exists():
+                raise ImportError(
+                    f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or `make -C xsdba_amd/csrc`). xsdba_amd has no CPU fallback."
+                )
+            lib = C.CDLL(str(LIB_PATH))
+            for s in SYMBOLS:
+                getattr(lib, s).restype = C.c_int
+            _lib = lib
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(1024)
+    load().xsdba_hip_last_error(buf, C.c_size_t(1024))
+    return buf.value.decode(errors="replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise XsdbaHipError(rc, last_error(), what)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    check(load().xsdba_hip_device_count(C.byref(n)), "device_count")
+    return n.value
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise TypeError(f"xsdba_amd supports float32/float64 data, got {dt}")
+
+
+class DeviceArray:
+    """A dense device buffer with numpy-like shape/dtype/strides metadata (element strides)."""
+
+    def __init__(self, ctx: "Context", shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(load().xsdba_hip_malloc(ctx.handle, C.c_size_t(max(self.nbytes, 1)), C.byref(p)), "malloc")
+        self.ptr = p.value
+
+    def upload(self, host: np.ndarray) -> "DeviceArray":
+        host = np.ascontiguousarray(host, self.dtype)
+        assert host.shape == self.shape
+        check(load().xsdba_hip_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
+                                          C.c_size_t(self.nbytes)), "memcpy_h2d")
+        return self
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        check(load().xsdba_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                          C.c_size_t(self.nbytes)), "memcpy_d2h")
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            check(load().xsdba_hip_free(self.ctx.handle, C.c_void_p(self.ptr)), "free")
+            self.ptr = None
+
+
+class Context:
+    """One per (process, device): owns the stream, scratch and cached group plans."""
+
+    def __init__(self, device: int = 0):
+        self.handle = C.c_void_p()
+        check(load().xsdba_hip_create(C.c_int(device), C.byref(self.handle)), "create")
+        self.device = device
+
+    def close(self):
+        if self.handle:
+            load().xsdba_hip_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(load().xsdba_hip_synchronize(self.handle), "synchronize")
+
+    def stream(self) -> int:
+        p = C.c_void_p()
+        check(load().xsdba_hip_get_stream(self.handle, C.byref(p)), "get_stream")
+        return p.value or 0
+
+    def empty(self, shape, dtype) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, host: np.ndarray) -> DeviceArray:
+        host = np.ascontiguousarray(host)
+        return DeviceArray(self, host.shape, host.dtype).upload(host)
+
+    def profile_enable(self, on: bool = True):
+        check(load().xsdba_hip_profile_enable(self.handle, C.c_int(int(on))), "profile_enable")
+
+    def profile_read(self, reset: bool = True) -> dict:
+        cap = 32
+        names = (C.c_char_p * cap)()
+        counts = (C.c_int64 * cap)()
+        ms = (C.c_double * cap)()
+        n = C.c_int(0)
+        check(load().xsdba_hip_profile_read(self.handle, names, counts, ms, C.c_int(cap), C.byref(n), C.c_int(int(reset))),
+              "profile_read")
+        return {names[i].decode(): {"count": int(counts[i]), "total_ms": float(ms[i])} for i in range(n.value)}
+
+    def timer_start(self):
+        check(load().xsdba_hip_timer_start(self.handle), "timer_start")
+
+    def timer_stop(self) -> float:
+        ms = C.c_double(0)
+        check(load().xsdba_hip_timer_stop(self.handle, C.byref(ms)), "timer_stop")
+        return ms.value
+
+
+_default_ctx: dict[int, Context] = {}
+
+
+def default_context(device: int | None = None) -> Context:
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", os.environ.get("XSDBA_AMD_DEVICE", "0")))
+        device = device % max(device_count(), 1)
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

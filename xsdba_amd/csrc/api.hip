@@ -1,0 +1,797 @@
+// api.hip — host side of libxsdba_hip.so: context, group plans, staging, launches, C ABI (include/xsdba_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/xsdba_hip.h"
+#include "kernels.hpp"
+
+#define API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail((int)e_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// Host-side description of the grouping: built once per (group_of_time, window) and cached.
+struct Plan {
+    uint64_t hash = 0;
+    int64_t T = 0;
+    int G = 0, W = 0;
+    int max_row = 0, max_mem = 0;
+    std::vector<int> row_ptr, row_idx, mem_ptr, mem_idx;
+    int *d_gidx = nullptr, *d_row_ptr = nullptr, *d_row_idx = nullptr, *d_mem_ptr = nullptr, *d_mem_idx = nullptr;
+};
+
+struct ProfEntry {
+    const char *name;
+    int64_t count = 0;
+    double ms = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct xsdba_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<std::unique_ptr<Plan>> plans;
+    DevBuf scratch[12];
+    std::vector<void *> user_allocs;
+    bool profiling = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    int lds_limit = 160 * 1024;
+};
+
+namespace {
+
+enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC };
+
+int ensure(xsdba_hip_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    DevBuf &b = ctx->scratch[slot];
+    if (b.cap < bytes) {
+        if (b.p) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+        size_t cap = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return 0;
+}
+
+bool is_device_ptr(const void *p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+// returns a device view of `p` (nbytes); host data are copied into scratch slot `slot`
+int stage_in(xsdba_hip_ctx *ctx, int slot, const void *p, size_t nbytes, const void **dev)
+{
+    if (is_device_ptr(p)) { *dev = p; return 0; }
+    void *d;
+    int rc = ensure(ctx, slot, nbytes, &d);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d, p, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return 0;
+}
+
+struct OutStage {
+    void *user = nullptr, *dev = nullptr;
+    size_t nbytes = 0;
+    bool copy_back = false;
+};
+
+int stage_out(xsdba_hip_ctx *ctx, int slot, void *p, size_t nbytes, OutStage *o)
+{
+    o->user = p; o->nbytes = nbytes;
+    if (!p) { o->dev = nullptr; o->copy_back = false; return 0; }
+    if (is_device_ptr(p)) { o->dev = p; o->copy_back = false; return 0; }
+    int rc = ensure(ctx, slot, nbytes, &o->dev);
+    if (rc) return rc;
+    o->copy_back = true;
+    return 0;
+}
+
+int finish_out(xsdba_hip_ctx *ctx, OutStage *o)
+{
+    if (o->copy_back) HIP_TRY(hipMemcpyAsync(o->user, o->dev, o->nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+// ---- profiling ------------------------------------------------------------------------------
+ProfEntry &prof_entry(xsdba_hip_ctx *ctx, const char *name)
+{
+    for (auto &e : ctx->prof) if (e.name == name || !strcmp(e.name, name)) return e;
+    ctx->prof.push_back(ProfEntry{name});
+    return ctx->prof.back();
+}
+
+hipEvent_t get_event(xsdba_hip_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct LaunchScope {
+    xsdba_hip_ctx *ctx;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    LaunchScope(xsdba_hip_ctx *c, const char *n) : ctx(c), name(n)
+    {
+        if (ctx->profiling) { a = get_event(ctx); b = get_event(ctx); (void)hipEventRecord(a, ctx->stream); }
+    }
+    ~LaunchScope()
+    {
+        if (ctx->profiling) { (void)hipEventRecord(b, ctx->stream); prof_entry(ctx, name).pending.emplace_back(a, b); }
+    }
+};
+
+int check_launch(const char *name)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "launch of %s failed: %s", name, hipGetErrorString(e));
+    return 0;
+}
+
+// ---- plans ------------------------------------------------------------------------------------
+uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+int upload_ints(xsdba_hip_ctx *ctx, const std::vector<int> &v, int **d)
+{
+    size_t n = std::max<size_t>(v.size(), 1);
+    HIP_TRY(hipMalloc((void **)d, n * sizeof(int)));
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+// base.py:232-272 — rolling(center=True, window).construct puts x[t' + j - window/2] in slot j of centre t';
+// groupby then collects the centres of each group.  row_idx keeps multiplicities (coarse group + window).
+int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G, int W, Plan **out)
+{
+    if (T <= 0 || T > (1ll << 30) || G <= 0 || W <= 0) return fail(XSDBA_E_ARG, "bad n_time/n_groups/window (%lld, %d, %d)", (long long)T, G, W);
+    std::vector<int> g((size_t)T, 0);
+    if (group_of_time) {
+        if (is_device_ptr(group_of_time)) {
+            HIP_TRY(hipMemcpyAsync(g.data(), group_of_time, (size_t)T * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } else memcpy(g.data(), group_of_time, (size_t)T * sizeof(int));
+    } else if (G != 1) return fail(XSDBA_E_ARG, "group_of_time is required when n_groups > 1");
+    uint64_t h = fnv(g.data(), (size_t)T * sizeof(int));
+    int64_t meta[3] = {T, G, W};
+    h = fnv(meta, sizeof meta, h);
+    for (auto &p : ctx->plans) if (p->hash == h && p->T == T && p->G == G && p->W == W) { *out = p.get(); return 0; }
+
+    auto pl = std::make_unique<Plan>();
+    pl->hash = h; pl->T = T; pl->G = G; pl->W = W;
+    pl->row_ptr.assign((size_t)G + 1, 0);
+    pl->mem_ptr.assign((size_t)G + 1, 0);
+    const int hw = W / 2;
+    for (int64_t t = 0; t < T; t++) {
+        int gg = g[(size_t)t];
+        if (gg < 0) continue;
+        if (gg >= G) return fail(XSDBA_E_ARG, "group_of_time[%lld] = %d out of range [0,%d)", (long long)t, gg, G);
+        int64_t lo = std::max<int64_t>(0, t - hw), hi = std::min<int64_t>(T - 1, t - hw + W - 1);
+        if ((int64_t)pl->row_ptr[gg + 1] + (hi - lo + 1) > (1ll << 30)) return fail(XSDBA_E_ROW_TOO_LONG, "group row too long");
+        pl->row_ptr[gg + 1] += (int)(hi - lo + 1);
+        pl->mem_ptr[gg + 1] += 1;
+    }
+    for (int i = 0; i < G; i++) {
+        pl->max_row = std::max(pl->max_row, pl->row_ptr[i + 1]);
+        pl->max_mem = std::max(pl->max_mem, pl->mem_ptr[i + 1]);
+        if ((int64_t)pl->row_ptr[i] + pl->row_ptr[i + 1] > (1ll << 31) - 2) return fail(XSDBA_E_ROW_TOO_LONG, "windowed rows exceed 2^31 entries");
+        pl->row_ptr[i + 1] += pl->row_ptr[i];
+        pl->mem_ptr[i + 1] += pl->mem_ptr[i];
+    }
+    pl->row_idx.resize((size_t)pl->row_ptr[G]);
+    pl->mem_idx.resize((size_t)pl->mem_ptr[G]);
+    std::vector<int> rp(pl->row_ptr.begin(), pl->row_ptr.end() - 1), mp(pl->mem_ptr.begin(), pl->mem_ptr.end() - 1);
+    for (int64_t t = 0; t < T; t++) {
+        int gg = g[(size_t)t];
+        if (gg < 0) continue;
+        pl->mem_idx[(size_t)mp[gg]++] = (int)t;
+        for (int j = 0; j < W; j++) {
+            int64_t tt = t + j - hw;
+            if (tt >= 0 && tt < T) pl->row_idx[(size_t)rp[gg]++] = (int)tt;
+        }
+    }
+    int rc;
+    if ((rc = upload_ints(ctx, g, &pl->d_gidx))) return rc;
+    if ((rc = upload_ints(ctx, pl->row_ptr, &pl->d_row_ptr))) return rc;
+    if ((rc = upload_ints(ctx, pl->row_idx, &pl->d_row_idx))) return rc;
+    if ((rc = upload_ints(ctx, pl->mem_ptr, &pl->d_mem_ptr))) return rc;
+    if ((rc = upload_ints(ctx, pl->mem_idx, &pl->d_mem_idx))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors must outlive the copies
+    *out = pl.get();
+    ctx->plans.push_back(std::move(pl));
+    return 0;
+}
+
+void free_plan(Plan *p)
+{
+    (void)hipFree(p->d_gidx); (void)hipFree(p->d_row_ptr); (void)hipFree(p->d_row_idx);
+    (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
+}
+
+// ---- series staging: any (host|device, strides) -> cell-major contiguous device view ---------------
+template <typename E>
+int launch_transpose(xsdba_hip_ctx *ctx, const E *src, int64_t rows, int64_t cols, int64_t srs, int64_t scs, E *dst,
+                     int64_t drs, int64_t dcs)
+{
+    dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+    if (grid.y > 65535u) return fail(XSDBA_E_ARG, "series too long for the layout kernel");
+    LaunchScope ls(ctx, "k_transpose_tile");
+    hipLaunchKernelGGL(xs::k_transpose_tile<E>, grid, dim3(256), 0, ctx->stream, src, rows, cols, srs, scs, dst, drs, dcs);
+    return check_launch("k_transpose_tile");
+}
+
+struct SeriesIn {
+    const void *dev = nullptr;  // device pointer the kernels read
+    int64_t st = 1, sc = 0;
+};
+
+template <typename R>
+int series_in(xsdba_hip_ctx *ctx, int slot_raw, int slot_cm, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc,
+              SeriesIn *out)
+{
+    if (!x) return fail(XSDBA_E_ARG, "null series pointer");
+    if (st <= 0 || sc <= 0) return fail(XSDBA_E_ARG, "strides must be positive");
+    const void *d;
+    size_t nbytes = (size_t)T * (size_t)C * sizeof(R);
+    int rc = stage_in(ctx, slot_raw, x, nbytes, &d);
+    if (rc) return rc;
+    if (st == 1) { out->dev = d; out->st = 1; out->sc = sc; return 0; }
+    void *cm;
+    if ((rc = ensure(ctx, slot_cm, nbytes, &cm))) return rc;
+    // rows = time (r), cols = cell (cc): src[t*st + c*sc] -> dst[c*T + t]
+    if ((rc = launch_transpose<R>(ctx, (const R *)d, T, C, st, sc, (R *)cm, 1, T))) return rc;
+    out->dev = cm; out->st = 1; out->sc = T;
+    return 0;
+}
+
+// output series: kernels always write cell-major; if the caller wants other strides (or a host buffer)
+// the result goes through scratch and a layout kernel / copy.
+struct SeriesOut {
+    void *user = nullptr;
+    void *kernel_dst = nullptr;  // cell-major [C][T] device buffer the kernel writes
+    void *dev_final = nullptr;   // device buffer in the caller's layout
+    int64_t ost = 1, osc = 0;
+    size_t nbytes = 0;
+    bool need_layout = false, copy_back = false;
+};
+
+template <typename E>
+int series_out_begin(xsdba_hip_ctx *ctx, int slot_final, int slot_cm, void *user, int64_t T, int64_t C, int64_t ost,
+                     int64_t osc, SeriesOut *o)
+{
+    o->user = user; o->ost = ost; o->osc = osc; o->nbytes = (size_t)T * (size_t)C * sizeof(E);
+    if (!user) return 0;
+    if (ost <= 0 || osc <= 0) return fail(XSDBA_E_ARG, "output strides must be positive");
+    int rc;
+    if (is_device_ptr(user)) o->dev_final = user;
+    else { if ((rc = ensure(ctx, slot_final, o->nbytes, &o->dev_final))) return rc; o->copy_back = true; }
+    if (ost == 1 && osc == T) { o->kernel_dst = o->dev_final; o->need_layout = false; }
+    else { if ((rc = ensure(ctx, slot_cm, o->nbytes, &o->kernel_dst))) return rc; o->need_layout = true; }
+    return 0;
+}
+
+template <typename E> int series_out_end(xsdba_hip_ctx *ctx, SeriesOut *o, int64_t T, int64_t C)
+{
+    if (!o->user) return 0;
+    int rc;
+    if (o->need_layout)  // rows = cell, cols = time: src[c*T + t] -> dst[c*osc + t*ost]
+        if ((rc = launch_transpose<E>(ctx, (const E *)o->kernel_dst, C, T, T, 1, (E *)o->dev_final, o->osc, o->ost))) return rc;
+    if (o->copy_back) HIP_TRY(hipMemcpyAsync(o->user, o->dev_final, o->nbytes, hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+int sync_if(xsdba_hip_ctx *ctx, bool need)
+{
+    if (need) HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+template <typename K> int set_lds(K kernel, size_t bytes, xsdba_hip_ctx *ctx, const char *what)
+{
+    if (bytes > (size_t)ctx->lds_limit) return fail(XSDBA_E_ROW_TOO_LONG, "%s needs %zu B of LDS (> %d)", what, bytes, ctx->lds_limit);
+    if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return 0;
+}
+
+int check_kind(char kind, bool allow_zero)
+{
+    if (kind == '+' || kind == '*' || (allow_zero && kind == 0)) return 0;
+    return fail(XSDBA_E_ARG, "kind must be '+' or '*'");
+}
+
+// ---- train ------------------------------------------------------------------------------------------
+template <typename R>
+int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int64_t T, int64_t C, int64_t st,
+               int64_t sc, const int32_t *gidx, int G, int W, const void *q, int Q, char kind, void *af, void *hq,
+               void *scaling)
+{
+    using U = typename xs::KeyOf<R>::U;
+    if (C <= 0 || Q <= 0 || !q || !hq || (mode && (!x1 || !af)) || (mode == 2 && !scaling)) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((int64_t)C * G > (1ll << 31) - 1) return fail(XSDBA_E_ARG, "n_cell * n_groups exceeds 2^31");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn s0, s1;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x0, T, C, st, sc, &s0))) return rc;
+    if (mode && (rc = series_in<R>(ctx, S_IN1, S_CM1, x1, T, C, st, sc, &s1))) return rc;
+    const void *dq;
+    if ((rc = stage_in(ctx, S_Q, q, (size_t)Q * sizeof(R), &dq))) return rc;
+    size_t tab = (size_t)C * G * Q * sizeof(R);
+    OutStage oaf, ohq, osc;
+    if ((rc = stage_out(ctx, S_TAB0, af, tab, &oaf))) return rc;
+    if ((rc = stage_out(ctx, S_TAB1, hq, tab, &ohq))) return rc;
+    if ((rc = stage_out(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &osc))) return rc;
+
+    int P = 2;
+    while (P < pl->max_row) P <<= 1;
+    int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+    size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * sizeof(U) + (size_t)Q * sizeof(R);
+    if ((rc = set_lds(xs::k_train_rows<R>, lds, ctx, "the row sort"))) return rc;
+    {
+        LaunchScope ls(ctx, "k_train_rows");
+        hipLaunchKernelGGL(xs::k_train_rows<R>, dim3((unsigned)((int64_t)C * G)), dim3(NT), lds, ctx->stream,
+                           (const R *)s0.dev, (const R *)s1.dev, s0.st, s0.sc, pl->d_row_ptr, pl->d_row_idx, G,
+                           (const R *)dq, Q, (int)kind, mode, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, P);
+        if ((rc = check_launch("k_train_rows"))) return rc;
+    }
+    if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
+    return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
+}
+
+// ---- adjust -----------------------------------------------------------------------------------------
+template <typename R>
+int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *af, const R *hq, int G, int Q,
+                     const int *d_gidx, int interp, int extrap, char kind, R *scen_cm, int *node, const R *scaling,
+                     const R *trend_cm)
+{
+    size_t lds = xs::tab_lds_bytes<R>(G, Q);
+    int rc;
+    if ((rc = set_lds(xs::k_qm_adjust<R>, lds, ctx, "the factor table"))) return rc;
+    LaunchScope ls(ctx, scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust");
+    hipLaunchKernelGGL(xs::k_qm_adjust<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
+                       af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node, scaling, trend_cm);
+    return check_launch("k_qm_adjust");
+}
+
+template <typename R>
+int qm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                   const void *hq, int G, int Q, const int32_t *gidx, int interp, int extrap, char kind, void *scen,
+                   int64_t ost, int64_t osc, int32_t *node)
+{
+    if (C <= 0 || Q <= 0 || !af || !hq || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (G > 1 && interp != XSDBA_INTERP_NEAREST)
+        return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented (Qhull triangulation in the reference)");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    size_t tab = (size_t)C * G * Q * sizeof(R);
+    const void *daf, *dhq;
+    if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    OutStage on;
+    if ((rc = stage_out(ctx, S_MISC, node, (size_t)C * T * sizeof(int), &on))) return rc;
+    if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
+                                  (R *)o.kernel_dst, (int *)on.dev, nullptr, nullptr))) return rc;
+    if ((rc = series_out_end<R>(ctx, &o, T, C)) || (rc = finish_out(ctx, &on))) return rc;
+    return sync_if(ctx, o.copy_back || on.copy_back || !is_device_ptr(sim));
+}
+
+template <typename R>
+int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *scaling, Plan *pl, char kind,
+                 const double *d_tnum, int degree, R *trend_cm)
+{
+    size_t lds = sizeof(double) * 3 * (size_t)pl->G + (size_t)T * sizeof(R);
+    int rc;
+    if ((rc = set_lds(xs::k_group_trend<R>, lds, ctx, "the detrending series"))) return rc;
+    LaunchScope ls(ctx, "k_group_trend");
+    hipLaunchKernelGGL(xs::k_group_trend<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
+                       scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr, pl->d_mem_idx, d_tnum, degree, trend_cm);
+    return check_launch("k_group_trend");
+}
+
+template <typename R>
+int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                    const void *hq, const void *scaling, int G, int Q, const int32_t *gidx, int W, const double *tnum,
+                    int degree, int interp, int extrap, char kind, void *scen, void *trend, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || Q <= 0 || !af || !hq || !scaling || !scen || !tnum) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (degree < 0 || degree > 1) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    if (G > 1 && interp != XSDBA_INTERP_NEAREST) return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    size_t tab = (size_t)C * G * Q * sizeof(R);
+    const void *daf, *dhq, *dsc, *dtn;
+    if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq)) ||
+        (rc = stage_in(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &dsc)) ||
+        (rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
+    SeriesOut o, otr;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    // the trend is always needed on device in cell-major form
+    if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
+    else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
+    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+    if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
+                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, (const R *)otr.kernel_dst))) return rc;
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    if (trend && (rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || otr.copy_back || !is_device_ptr(sim) || !is_device_ptr(tnum));
+}
+
+template <typename R>
+int trend_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t *gidx, int G,
+               int W, const double *tnum, int degree, void *trend, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || !trend || !tnum) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (degree < 0 || degree > 1) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x, T, C, st, sc, &s))) return rc;
+    const void *dtn;
+    if ((rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
+    SeriesOut otr;
+    if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc;
+    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, '+', (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+    if ((rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
+    return sync_if(ctx, true);
+}
+
+template <typename R>
+int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+             const void *quantiles, int G, int Q, const int32_t *gidx, int W, int rank_window, int interp, int extrap,
+             char kind, void *scen, double *sim_q, int64_t ost, int64_t osc)
+{
+    const bool ranks_only = af == nullptr;
+    if (C <= 0 || (!ranks_only && (Q <= 0 || !quantiles || !scen)) || (ranks_only && !sim_q)) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (!ranks_only && G > 1 && interp != XSDBA_INTERP_NEAREST) return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    const void *daf = nullptr, *dqn = nullptr;
+    if (!ranks_only) {
+        if ((rc = stage_in(ctx, S_TAB0, af, (size_t)C * G * Q * sizeof(R), &daf)) ||
+            (rc = stage_in(ctx, S_Q, quantiles, (size_t)Q * sizeof(R), &dqn))) return rc;
+    }
+    SeriesOut o, oq;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    if ((rc = series_out_begin<double>(ctx, S_OUT1, S_CM2, sim_q, T, C, ost, osc, &oq))) return rc;
+    size_t lds = (ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15)) +
+                 ((sizeof(int) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
+    if ((rc = set_lds(xs::k_qdm_adjust<R>, lds, ctx, "the ranking series + factor table"))) return rc;
+    const bool rw = rank_window && W > 1;
+    {
+        LaunchScope ls(ctx, "k_qdm_adjust");
+        hipLaunchKernelGGL(xs::k_qdm_adjust<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
+                           (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, rw ? pl->d_row_ptr : pl->d_mem_ptr,
+                           rw ? pl->d_row_idx : pl->d_mem_idx, interp, extrap, (int)kind, (R *)o.kernel_dst,
+                           (double *)oq.kernel_dst, (int64_t)1, T);
+        if ((rc = check_launch("k_qdm_adjust"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C)) || (rc = series_out_end<double>(ctx, &oq, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || oq.copy_back || !is_device_ptr(sim));
+}
+
+int check_ctx(xsdba_hip_ctx *ctx)
+{
+    if (!ctx) return fail(XSDBA_E_ARG, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return 0;
+}
+
+#define DISPATCH(dtype, call_f32, call_f64)                                        \
+    ((dtype) == XSDBA_F32 ? (call_f32) : (dtype) == XSDBA_F64 ? (call_f64) : fail(XSDBA_E_ARG, "dtype must be XSDBA_F32 or XSDBA_F64"))
+
+}  // namespace
+
+// =================================================== C ABI ===================================================
+API int xsdba_hip_abi_version(void) { return XSDBA_HIP_ABI_VERSION; }
+
+API int xsdba_hip_last_error(char *buf, size_t buflen)
+{
+    if (!buf || !buflen) return XSDBA_E_ARG;
+    snprintf(buf, buflen, "%s", g_err.c_str());
+    return 0;
+}
+
+API int xsdba_hip_device_count(int *count)
+{
+    if (!count) return fail(XSDBA_E_ARG, "null count");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return 0;
+}
+
+API int xsdba_hip_create(int device, xsdba_hip_ctx **out)
+{
+    if (!out) return fail(XSDBA_E_ARG, "null out pointer");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return fail(XSDBA_E_NO_DEVICE, "no HIP device visible"); }
+    if (device < 0 || device >= n) return fail(XSDBA_E_ARG, "device %d out of range [0,%d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(XSDBA_E_NO_DEVICE, "device %d is %s; this library carries gfx950 (MI355X) code only", device, prop.gcnArchName);
+    auto *ctx = new (std::nothrow) xsdba_hip_ctx();
+    if (!ctx) return fail(XSDBA_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor > 0 ? (int)std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, 160 * 1024) : 64 * 1024;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ctx; return fail((int)e, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    (void)hipEventCreate(&ctx->t0);
+    (void)hipEventCreate(&ctx->t1);
+    *out = ctx;
+    return 0;
+}
+
+API int xsdba_hip_destroy(xsdba_hip_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->plans) free_plan(p.get());
+    for (auto &b : ctx->scratch) if (b.p) (void)hipFree(b.p);
+    for (void *p : ctx->user_allocs) (void)hipFree(p);
+    for (auto &e : ctx->prof) for (auto &pr : e.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+API int xsdba_hip_synchronize(xsdba_hip_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return fail(XSDBA_E_ARG, "null argument");
+    *stream = (void *)ctx->stream;
+    return 0;
+}
+
+API int xsdba_hip_malloc(xsdba_hip_ctx *ctx, size_t bytes, void **dptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!dptr) return fail(XSDBA_E_ARG, "null out pointer");
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    ctx->user_allocs.push_back(*dptr);
+    return 0;
+}
+
+API int xsdba_hip_free(xsdba_hip_ctx *ctx, void *dptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!dptr) return 0;
+    auto it = std::find(ctx->user_allocs.begin(), ctx->user_allocs.end(), dptr);
+    if (it == ctx->user_allocs.end()) return fail(XSDBA_E_ARG, "pointer was not allocated by xsdba_hip_malloc on this context");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(dptr));
+    ctx->user_allocs.erase(it);
+    return 0;
+}
+
+API int xsdba_hip_memcpy_h2d(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_memcpy_d2h(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_memset(xsdba_hip_ctx *ctx, void *dst, int value, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_profile_enable(xsdba_hip_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(XSDBA_E_ARG, "null context");
+    ctx->profiling = enable != 0;
+    return 0;
+}
+
+API int xsdba_hip_profile_read(xsdba_hip_ctx *ctx, const char **names, int64_t *counts, double *total_ms, int cap, int *n,
+                               int reset)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!n) return fail(XSDBA_E_ARG, "null argument");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int k = 0;
+    for (auto &e : ctx->prof) {
+        for (auto &pr : e.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { e.ms += ms; e.count++; }
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        e.pending.clear();
+        if (k < cap && names && counts && total_ms) { names[k] = e.name; counts[k] = e.count; total_ms[k] = e.ms; }
+        k++;
+    }
+    *n = std::min(k, cap);
+    if (reset) for (auto &e : ctx->prof) { e.count = 0; e.ms = 0; }
+    return 0;
+}
+
+API int xsdba_hip_timer_start(xsdba_hip_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->t0, ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_timer_stop(xsdba_hip_ctx *ctx, double *elapsed_ms)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!elapsed_ms) return fail(XSDBA_E_ARG, "null argument");
+    HIP_TRY(hipEventRecord(ctx->t1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(ctx->t1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *elapsed_ms = ms;
+    return 0;
+}
+
+API int xsdba_hip_quantile_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                  const int32_t *gidx, int32_t G, int32_t W, const void *q, int32_t Q, void *out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (train_impl<float>(ctx, 0, x, nullptr, T, C, st, sc, gidx, G, W, q, Q, '+', nullptr, out, nullptr)),
+                    (train_impl<double>(ctx, 0, x, nullptr, T, C, st, sc, gidx, G, W, q, Q, '+', nullptr, out, nullptr)));
+}
+
+API int xsdba_hip_eqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
+                            int64_t sc, const int32_t *gidx, int32_t G, int32_t W, const void *q, int32_t Q, char kind,
+                            void *af, void *hist_q)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    return DISPATCH(dtype, (train_impl<float>(ctx, 1, ref, hist, T, C, st, sc, gidx, G, W, q, Q, kind, af, hist_q, nullptr)),
+                    (train_impl<double>(ctx, 1, ref, hist, T, C, st, sc, gidx, G, W, q, Q, kind, af, hist_q, nullptr)));
+}
+
+API int xsdba_hip_dqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
+                            int64_t sc, const int32_t *gidx, int32_t G, int32_t W, const void *q, int32_t Q, char kind,
+                            void *af, void *hist_q, void *scaling)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    return DISPATCH(dtype, (train_impl<float>(ctx, 2, ref, hist, T, C, st, sc, gidx, G, W, q, Q, kind, af, hist_q, scaling)),
+                    (train_impl<double>(ctx, 2, ref, hist, T, C, st, sc, gidx, G, W, q, Q, kind, af, hist_q, scaling)));
+}
+
+API int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                            const void *af, const void *hist_q, int32_t G, int32_t Q, const int32_t *gidx, int interp,
+                            int extrap, char kind, void *scen, int64_t ost, int64_t osc, int32_t *node_index)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, true))) return rc;
+    return DISPATCH(dtype, (qm_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, gidx, interp, extrap, kind, scen, ost, osc, node_index)),
+                    (qm_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, gidx, interp, extrap, kind, scen, ost, osc, node_index)));
+}
+
+API int xsdba_hip_dqm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                             const void *af, const void *hist_q, const void *scaling, int32_t G, int32_t Q,
+                             const int32_t *gidx, int32_t W, const double *time_num, int32_t degree, int interp, int extrap,
+                             char kind, void *scen, void *trend, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    return DISPATCH(dtype, (dqm_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, scaling, G, Q, gidx, W, time_num, degree, interp, extrap, kind, scen, trend, ost, osc)),
+                    (dqm_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, scaling, G, Q, gidx, W, time_num, degree, interp, extrap, kind, scen, trend, ost, osc)));
+}
+
+API int xsdba_hip_qdm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                             const void *af, const void *quantiles, int32_t G, int32_t Q, const int32_t *gidx, int32_t W,
+                             int rank_window, int interp, int extrap, char kind, void *scen, double *sim_q, int64_t ost,
+                             int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    if (!af) return fail(XSDBA_E_ARG, "null af");
+    return DISPATCH(dtype, (qdm_impl<float>(ctx, sim, T, C, st, sc, af, quantiles, G, Q, gidx, W, rank_window, interp, extrap, kind, scen, sim_q, ost, osc)),
+                    (qdm_impl<double>(ctx, sim, T, C, st, sc, af, quantiles, G, Q, gidx, W, rank_window, interp, extrap, kind, scen, sim_q, ost, osc)));
+}
+
+API int xsdba_hip_rank_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                              const int32_t *gidx, int32_t G, int32_t W, int rank_window, double *out, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (qdm_impl<float>(ctx, x, T, C, st, sc, nullptr, nullptr, G, 0, gidx, W, rank_window, 0, 0, '+', nullptr, out, ost, osc)),
+                    (qdm_impl<double>(ctx, x, T, C, st, sc, nullptr, nullptr, G, 0, gidx, W, rank_window, 0, 0, '+', nullptr, out, ost, osc)));
+}
+
+API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                    const int32_t *gidx, int32_t G, int32_t W, const double *time_num, int32_t degree,
+                                    void *trend, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)),
+                    (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)));
+}

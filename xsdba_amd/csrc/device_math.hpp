@@ -1,0 +1,178 @@
+// device_math.hpp — per-element numerics shared by the gfx950 kernels.
+//
+// Every routine restates one reference function (citations: /root/reference/src/xsdba/...) and is the
+// device twin of the same-named routine in oracle/oracle_impl.inc; the library is built with
+// -ffp-contract=off so that float expressions round exactly like the numpy/numba code they follow.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace xs {
+
+template <typename R> struct KeyOf;
+template <> struct KeyOf<float> {
+    using U = uint32_t;
+    static constexpr U MAXK = 0xFFFFFFFFu;
+};
+template <> struct KeyOf<double> {
+    using U = uint64_t;
+    static constexpr U MAXK = 0xFFFFFFFFFFFFFFFFull;
+};
+
+// Order-preserving bijection float -> unsigned (ascending, -0 < +0); every NaN maps to MAXK so that NaNs
+// (and row padding) sort last exactly like numba's arr.sort() (nbutils.py:137).
+__device__ __forceinline__ uint32_t to_key(float v)
+{
+    if (v != v) return 0xFFFFFFFFu;
+    uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ uint64_t to_key(double v)
+{
+    if (v != v) return 0xFFFFFFFFFFFFFFFFull;
+    uint64_t u = (uint64_t)__double_as_longlong(v);
+    return (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ float from_key(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ double from_key(uint64_t k)
+{
+    uint64_t u = (k & 0x8000000000000000ull) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+template <typename R> __device__ __forceinline__ R nan_of() { return (R)__builtin_nan(""); }
+
+// utils.get_correction / apply_correction / invert (utils.py:130-177), evaluated in the data dtype
+template <typename R> __device__ __forceinline__ R get_corr(R x, R y, int kind) { return kind == '+' ? y - x : y / x; }
+template <typename R> __device__ __forceinline__ R apply_corr(R x, R f, int kind) { return kind == '+' ? x + f : x * f; }
+template <typename R> __device__ __forceinline__ R invert(R x, int kind) { return kind == '+' ? -x : (R)1 / x; }
+
+// nbutils._nan_quantile_1d on a row already sorted ascending with its n valid values first
+// (nbutils.py:113-148 with _get_indexes :29-68 and _linear_interpolation :76-105, numba typing:
+// virtual index in float64 from the dtype-rounded q; gamma cast to the data dtype; gamma >= 0.5
+// branch evaluated in float64 and rounded once; NaN result -> arr[n-1]).
+template <typename R, typename Load> __device__ __forceinline__ R quantile_sorted(Load a, int n, R q)
+{
+    if (n == 0) return nan_of<R>();
+    double qk = (double)q;
+    double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
+    R res;
+    if (vi != vi || vi >= (double)(n - 1)) res = a(n - 1);
+    else if (vi < 0.0) res = a(0);
+    else {
+        int lo = (int)floor(vi);
+        R left = a(lo), right = a(lo + 1);
+        R gamma = (R)(vi - (double)lo);
+        R diff = right - left;
+        if (gamma >= (R)0.5) res = (R)((double)right - (double)diff * (1.0 - (double)gamma));
+        else res = left + diff * gamma;
+        if (res != res) res = a(n - 1);
+    }
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interpolation of the trained factors on quantiles.  A cell's table lives in LDS as G rows of
+// compacted (x, y) pairs (NaN pairs removed in place, order kept) + per-row metadata; the cyclic
+// extension rows 0 and G+1 (utils.py:284-314, 489-490) are the same storage seen through ext_row().
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct CellTab {
+    const R *xs;        // [G][Q] compacted abscissae (hist_q, or the quantile nodes for QDM)
+    const R *ys;        // [G][Q] compacted factors
+    const int *rn;      // [G] valid pairs per row
+    const double *xfirst, *xlast;  // [G] first/last non-NaN abscissa (NaN if none) — nbutils.py:380-389
+    const R *yfirst, *ylast;       // [G] first/last non-NaN factor
+    int G, Q, any_valid;
+};
+
+__device__ __forceinline__ int ext_row(int rr, int G) { return rr == 0 ? G - 1 : (rr == G + 1 ? 0 : rr - 1); }
+
+// utils._interp_on_quantiles_1D (utils.py:350-377) with scipy.interpolate.interp1d 'nearest'
+// (x_bds = x/2 summed pairwise in the table dtype, searchsorted side='left': ties go DOWN) or 'linear'
+// (slope in the table dtype; evaluation in float64 when the abscissa is float64, the QDM path).
+template <typename R>
+__device__ __forceinline__ R interp1d_eval(double x, bool x_is_double, const R *xs, const R *ys, int n, R yfirst,
+                                           R ylast, int interp, int extrap, int *node)
+{
+    if (node) *node = -1;
+    if (x != x || n == 0) return nan_of<R>();
+    if (x < (double)xs[0]) return extrap == 0 ? yfirst : nan_of<R>();
+    if (x > (double)xs[n - 1]) return extrap == 0 ? ylast : nan_of<R>();
+    if (interp == 0) {
+        int lo = 0, hi = n - 1;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            R b = xs[mid] / (R)2.0 + xs[mid + 1] / (R)2.0;
+            if ((double)b < x) lo = mid + 1; else hi = mid;
+        }
+        if (node) *node = lo;
+        return ys[lo];
+    }
+    if (n == 1) return nan_of<R>();
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)xs[mid] < x) lo = mid + 1; else hi = mid; }
+    int idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+    R slope = (ys[idx] - ys[idx - 1]) / (xs[idx] - xs[idx - 1]);
+    if (x_is_double) return (R)((double)slope * (x - (double)xs[idx - 1]) + (double)ys[idx - 1]);
+    return slope * ((R)x - xs[idx - 1]) + ys[idx - 1];
+}
+
+template <typename R> __device__ __forceinline__ double row_nearest(double x, const R *xs, int n, int *which)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)xs[mid] < x) lo = mid + 1; else hi = mid; }
+    double best = __builtin_inf();
+    int bi = -1;
+    if (lo > 0) { double d = x - (double)xs[lo - 1]; best = d * d; bi = lo - 1; }
+    if (lo < n) { double d = x - (double)xs[lo]; if (d * d < best) { best = d * d; bi = lo; } }
+    *which = bi;
+    return best;
+}
+
+// utils._interp_on_quantiles_2d with method="nearest" (utils.py:380-400: scipy griddata -> exact 2-D
+// Euclidean nearest neighbour over (xq, group coordinate) in float64) followed by
+// nbutils._extrapolate_on_quantiles (nbutils.py:397-416), for an integer group coordinate r = g0+1.
+// Rows are visited outward (r, r-1, r+1, r-2, ...) while dr^2 < best; exact distance ties keep the
+// first visited node (cKDTree's choice at ties is implementation-defined).
+template <typename R>
+__device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R> &ct, int extrap, int *node)
+{
+    if (node) *node = -1;
+    if (x != x || !ct.any_valid) return nan_of<R>();
+    const int G = ct.G, Q = ct.Q, r = g0 + 1;
+    if (x < ct.xfirst[g0]) return extrap == 0 ? ct.yfirst[g0] : nan_of<R>();
+    if (x > ct.xlast[g0]) return extrap == 0 ? ct.ylast[g0] : nan_of<R>();
+    double best = __builtin_inf();
+    R val = nan_of<R>();
+    for (int dr = 0; dr <= G + 1; dr++) {
+        double d2r = (double)dr * (double)dr;
+        if (d2r >= best) break;
+        for (int s = 0; s < (dr ? 2 : 1); s++) {
+            int rr = s ? r + dr : r - dr;
+            if (rr < 0 || rr > G + 1) continue;
+            int g = ext_row(rr, G);
+            int n = ct.rn[g];
+            if (n == 0) continue;
+            int w;
+            double d2 = row_nearest<R>(x, ct.xs + (size_t)g * Q, n, &w) + d2r;
+            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; if (node) *node = rr * Q + w; }
+        }
+    }
+    return val;
+}
+
+template <typename R>
+__device__ __forceinline__ R celltab_eval(const CellTab<R> &ct, double x, bool x_is_double, int g0, int interp,
+                                          int extrap, int *node)
+{
+    if (ct.G == 1)
+        return interp1d_eval<R>(x, x_is_double, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, node);
+    if (g0 < 0) { if (node) *node = -1; return nan_of<R>(); }
+    return interp2d_nearest<R>(x, g0, ct, extrap, node);
+}
+
+}  // namespace xs

@@ -1,0 +1,399 @@
+// kernels.hpp — gfx950 kernels of the quantile-mapping hot path (generic "row" formulation).
+//
+// Layout inside the kernels is cell-major: series x[c*sc + t*st] with st == 1 on the fast paths (the
+// host side transposes time-major cubes once on the way in / out, see api.hip).  One workgroup owns one
+// (cell, group) row for training and one cell for adjusting; everything a row/cell needs is staged in
+// LDS once (sort buffer or factor table), so HBM sees each input element once per kernel.
+#pragma once
+#include "device_math.hpp"
+
+namespace xs {
+
+// ---------------------------------------------------------------------------------------------
+// block-wide helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// red: LDS scratch of >= 2*(blockDim/64)+2 doubles.  Returns the block-wide (sum, count) to every thread.
+__device__ __forceinline__ void block_sum_count(double &s, int &n, double *red)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    s = wave_sum(s);
+    n = wave_sum(n);
+    __syncthreads();
+    if (lane == 0) { red[2 * wid] = s; red[2 * wid + 1] = (double)n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0, tn = 0;
+        for (int w = 0; w < nw; w++) { ts += red[2 * w]; tn += red[2 * w + 1]; }
+        red[2 * nw] = ts; red[2 * nw + 1] = tn;
+    }
+    __syncthreads();
+    s = red[2 * nw];
+    n = (int)red[2 * nw + 1];
+    __syncthreads();
+}
+
+// In-LDS bitonic sort of P (power of two) keys by the whole block.
+template <typename U> __device__ __forceinline__ void block_bitonic_sort(U *keys, int P)
+{
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                int r = l | j;
+                U a = keys[l], b = keys[r];
+                bool up = (l & k) == 0;
+                if ((a > b) == up) { keys[l] = b; keys[r] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: rows -> sort -> type-7 quantiles (-> correction factors).
+//   mode 0: out_hq[c][g][:] = quantiles of x0's rows                      (nbutils.quantile, a4)
+//   mode 1: EQM train: hist_q, af = corr(hist_q, ref_q)                   (_adjustment.py:253-286)
+//   mode 2: DQM train: rows normalised by their NaN-skipping mean first,  (_adjustment.py:150-190)
+//           scaling = corr(mean(hist), mean(ref))
+// grid.x = n_cell * n_groups (block b -> cell b / G, group b % G); dynamic LDS:
+//   [red: 2*(NT/64)+2 doubles][keys: P_max * sizeof(U)][rq: Q * sizeof(R)]
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1, int64_t st, int64_t sc,
+                             const int *__restrict__ row_ptr, const int *__restrict__ row_idx, int G,
+                             const R *__restrict__ q, int Q, int kind, int mode, R *__restrict__ af,
+                             R *__restrict__ out_hq, R *__restrict__ scaling, int P_max)
+{
+    using U = typename KeyOf<R>::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nw = (blockDim.x + 63) >> 6;
+    double *red = reinterpret_cast<double *>(smem);
+    U *keys = reinterpret_cast<U *>(red + 2 * nw + 2);
+    R *vals = reinterpret_cast<R *>(keys);
+    R *rq = reinterpret_cast<R *>(keys + P_max);
+
+    const int64_t b = blockIdx.x;
+    const int64_t c = b / G;
+    const int g = (int)(b - c * G);
+    const int r0 = row_ptr[g], L = row_ptr[g + 1] - r0;
+    int P = 2;
+    while (P < L) P <<= 1;
+    const size_t obase = ((size_t)c * G + g) * (size_t)Q;
+
+    R mu[2] = {nan_of<R>(), nan_of<R>()};
+    const int npass = mode == 0 ? 1 : 2;
+    for (int pass = 0; pass < npass; pass++) {
+        const R *x = (pass == 0 ? x0 : x1) + c * sc;
+        R inv = (R)0;
+        if (mode == 2) {
+            double s = 0; int n = 0;
+            for (int i = threadIdx.x; i < L; i += blockDim.x) {
+                R v = x[(int64_t)row_idx[r0 + i] * st];
+                vals[i] = v;
+                if (v == v) { s += (double)v; n++; }
+            }
+            block_sum_count(s, n, red);
+            mu[pass] = n ? (R)(s / (double)n) : nan_of<R>();
+            inv = invert<R>(mu[pass], kind);
+        }
+        int nvalid = 0;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            U k = KeyOf<R>::MAXK;
+            if (i < L) {
+                R v = mode == 2 ? apply_corr<R>(vals[i], inv, kind) : x[(int64_t)row_idx[r0 + i] * st];
+                k = to_key(v);
+                nvalid += (v == v);
+            }
+            keys[i] = k;
+        }
+        double dummy = 0;
+        block_sum_count(dummy, nvalid, red);  // also the barrier between key writes and the sort
+        block_bitonic_sort<U>(keys, P);
+        auto load = [&](int i) { return from_key(keys[i]); };
+        for (int k = threadIdx.x; k < Q; k += blockDim.x) {
+            R v = quantile_sorted<R>(load, nvalid, q[k]);
+            if (mode == 0) out_hq[obase + k] = v;
+            else if (pass == 0) rq[k] = v;  // ref_q stays on chip
+            else {
+                out_hq[obase + k] = v;
+                af[obase + k] = get_corr<R>(v, rq[k], kind);
+            }
+        }
+        __syncthreads();
+    }
+    if (mode == 2 && threadIdx.x == 0) scaling[(size_t)c * G + g] = get_corr<R>(mu[1], mu[0], kind);
+}
+
+// ---------------------------------------------------------------------------------------------
+// table staging shared by the adjust kernels: copies a cell's [G][Q] (xq, yq) into LDS, compacts the
+// NaN pairs of every row in place and fills the row metadata (nbutils._first_and_last_nonnull).
+// xq_row_stride == 0 broadcasts one abscissa row to all groups (QDM: the quantile nodes).
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct TabLds {
+    R *xs, *ys;
+    int *rn;
+    double *xfirst, *xlast;
+    R *yfirst, *ylast;
+    int *any;
+};
+
+template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q)
+{
+    size_t n = (size_t)G * Q;
+    return 2 * sizeof(double) * (size_t)G + 2 * sizeof(R) * n + 2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16;
+}
+
+template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q)
+{
+    TabLds<R> t;
+    size_t n = (size_t)G * Q;
+    t.xfirst = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
+    t.xlast = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
+    t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * n;
+    t.ys = reinterpret_cast<R *>(p); p += sizeof(R) * n;
+    t.yfirst = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
+    t.ylast = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
+    t.rn = reinterpret_cast<int *>(p); p += sizeof(int) * (size_t)G;
+    t.any = reinterpret_cast<int *>(p);
+    return t;
+}
+
+template <typename R>
+__device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__restrict__ xq, int64_t xq_row_stride,
+                                                const R *__restrict__ yq, int G, int Q)
+{
+    const int n = G * Q;
+    if (threadIdx.x == 0) *t.any = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        int g = i / Q, k = i - g * Q;
+        t.xs[i] = xq[(size_t)g * xq_row_stride + k];
+        t.ys[i] = yq[i];
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        R *xr = t.xs + (size_t)g * Q, *yr = t.ys + (size_t)g * Q;
+        int m = 0;
+        bool fx = false, fy = false;
+        double xf = __builtin_nan(""), xl = __builtin_nan("");
+        R yf = nan_of<R>(), yl = nan_of<R>();
+        for (int k = 0; k < Q; k++) {
+            R xv = xr[k], yv = yr[k];
+            if (xv == xv) { if (!fx) { xf = (double)xv; fx = true; } xl = (double)xv; }
+            if (yv == yv) { if (!fy) { yf = yv; fy = true; } yl = yv; }
+            if (xv == xv && yv == yv) { xr[m] = xv; yr[m] = yv; m++; }
+        }
+        t.rn[g] = m; t.xfirst[g] = xf; t.xlast[g] = xl; t.yfirst[g] = yf; t.ylast[g] = yl;
+        if (m) atomicOr(t.any, 1);
+    }
+    __syncthreads();
+    CellTab<R> ct;
+    ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
+    ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any;
+    return ct;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: qm_adjust (_adjustment.py:594-676) and the mapping stage of dqm_adjust (:748-773).
+// One block per cell; the cell's (hist_q, af) table is staged in LDS once, then the block streams the
+// series.  scaling/trend non-null -> DQM: x = (sim (+|*) scaling[g]) detrended by trend[t]
+// (detrending.py:102-120), mapped, retrended.  trend is cell-major contiguous [cell][time].
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc, const R *__restrict__ af,
+                            const R *__restrict__ hist_q, int G, int Q, const int *__restrict__ gidx, int interp,
+                            int extrap, int kind, R *__restrict__ scen, int64_t ost, int64_t osc,
+                            int *__restrict__ node, const R *__restrict__ scaling, const R *__restrict__ trend)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t c = blockIdx.x;
+    TabLds<R> tl = tab_carve<R>(smem, G, Q);
+    CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
+    const R *x = sim + c * sc;
+    R *o = scen + c * osc;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        R v = x[t * st];
+        int g0 = G > 1 ? gidx[t] : 0;
+        R tr = (R)0;
+        if (scaling) {
+            int gs = gidx[t];
+            R s = gs >= 0 ? scaling[(size_t)c * G + gs] : nan_of<R>();
+            v = apply_corr<R>(v, s, kind);
+            tr = trend[(size_t)c * T + t];
+            v = apply_corr<R>(v, invert<R>(tr, kind), kind);
+        }
+        int nd;
+        R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, node ? &nd : nullptr);
+        R y = kind ? apply_corr<R>(v, a, kind) : a;
+        if (scaling) y = apply_corr<R>(y, tr, kind);
+        o[t * ost] = y;
+        if (node) node[(size_t)c * T + t] = nd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: PolyDetrend(degree 0/1) trend per group (detrending.py:196-208) of the (optionally scaled) series.
+// One block per cell: series in LDS -> NaN-skipping centred window means (partial at the ends) ->
+// per-group least squares in float64 against time_num -> trend written cell-major.  The window means
+// are parked in the trend buffer itself between the two phases.
+// dynamic LDS: [coef: 3*G doubles][xs: T * sizeof(R)]
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
+                              const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
+                              const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
+                              const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *coef = reinterpret_cast<double *>(smem);
+    R *xs = reinterpret_cast<R *>(coef + 3 * (size_t)G);
+    const int64_t c = blockIdx.x;
+    const R *x = sim + c * sc;
+    R *m = trend_cm + (size_t)c * T;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        R v = x[t * st];
+        if (scaling) {
+            int g = gidx[t];
+            v = apply_corr<R>(v, g >= 0 ? scaling[(size_t)c * G + g] : nan_of<R>(), kind);
+        }
+        xs[t] = v;
+    }
+    __syncthreads();
+    const int h = W / 2;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        R mv;
+        if (W == 1) mv = xs[t];
+        else {
+            double s = 0; int n = 0;
+            for (int j = 0; j < W; j++) {
+                int64_t tt = t + j - h;
+                if (tt >= 0 && tt < T) { R v = xs[tt]; if (v == v) { s += (double)v; n++; } }
+            }
+            mv = n ? (R)(s / n) : nan_of<R>();
+        }
+        m[t] = mv;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
+        int n = 0; double sx = 0, sy = 0;
+        for (int p = p0; p < p1; p++) { int t = mem_idx[p]; R v = m[t]; if (v == v) { sx += tnum[t]; sy += (double)v; n++; } }
+        double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan(""), slope = 0.0;
+        if (degree >= 1 && n >= 2) {
+            double sxx = 0, sxy = 0;
+            for (int p = p0; p < p1; p++) {
+                int t = mem_idx[p]; R v = m[t];
+                if (v == v) { double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+            }
+            slope = sxx > 0 ? sxy / sxx : 0.0;
+        }
+        coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
+    }
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        int g = gidx[t];
+        m[t] = g >= 0 ? (R)(coef[3 * g + 1] + coef[3 * g + 2] * (tnum[t] - coef[3 * g])) : nan_of<R>();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: qdm_adjust (_adjustment.py:783-886): percent ranks of sim within its group (utils.rank, utils.py:573-638;
+// average ties, NaN -> NaN, p = r/N rescaled with the extreme ranks) + interpolation of af on the quantile
+// axis + apply.  af == nullptr -> ranks only (utils.rank through Grouper.apply).
+// One block per cell; dynamic LDS: [table (if af)][gstat: 4*G ints][xs: T * sizeof(R)]
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc, const R *__restrict__ af,
+                             const R *__restrict__ quantiles, int G, int Q, const int *__restrict__ gidx,
+                             const int *__restrict__ grp_ptr, const int *__restrict__ grp_idx, int interp, int extrap,
+                             int kind, R *__restrict__ scen, double *__restrict__ sim_q, int64_t ost, int64_t osc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t c = blockIdx.x;
+    unsigned char *p = smem;
+    CellTab<R> ct;
+    if (af) {
+        TabLds<R> tl = tab_carve<R>(p, G, Q);
+        ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
+        p += (tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
+    }
+    int *gstat = reinterpret_cast<int *>(p);  // per group: N valid, #==min, #==max
+    p += ((sizeof(int) * 3 * (size_t)G) + 15) & ~(size_t)15;
+    R *xs = reinterpret_cast<R *>(p);
+    const R *x = sim + c * sc;
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t * st];
+    __syncthreads();
+    // per-group statistics over the ranking row (grp_* = windowed rows when rank_window, else the exact groups)
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
+        int N = 0;
+        R mn = nan_of<R>(), mx = nan_of<R>();
+        for (int i = p0; i < p1; i++) {
+            R v = xs[grp_idx[i]];
+            if (v == v) { if (N == 0 || v < mn) mn = v; if (N == 0 || v > mx) mx = v; N++; }
+        }
+        int nmin = 0, nmax = 0;
+        for (int i = p0; i < p1; i++) { R v = xs[grp_idx[i]]; nmin += (v == mn); nmax += (v == mx); }
+        gstat[3 * g] = N; gstat[3 * g + 1] = nmin; gstat[3 * g + 2] = nmax;
+    }
+    __syncthreads();
+    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+        R v = xs[t];
+        int g = gidx[t];
+        double sq = __builtin_nan("");
+        if (v == v && g >= 0) {
+            int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
+            int less = 0, eq = 0;
+            for (int i = p0; i < p1; i++) { R u = xs[grp_idx[i]]; less += (u < v); eq += (u == v); }
+            double N = (double)gstat[3 * g], nmin = (double)gstat[3 * g + 1], nmax = (double)gstat[3 * g + 2];
+            double r = (double)less + (double)(eq + 1) / 2.0;
+            double pr = r / N;
+            double pmin = ((nmin + 1.0) / 2.0) / N;
+            double pmax = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
+            sq = pmax * (pr - pmin) / (pmax - pmin);
+        }
+        if (sim_q) sim_q[c * osc + t * ost] = sq;
+        if (af) {
+            R a = celltab_eval<R>(ct, sq, true, G > 1 ? g : 0, interp, extrap, nullptr);
+            scen[c * osc + t * ost] = apply_corr<R>(v, a, kind);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout kernels: time-major / arbitrary strides <-> cell-major contiguous [cell][time]
+// ---------------------------------------------------------------------------------------------
+template <typename E>
+__global__ void k_transpose_tile(const E *__restrict__ src, int64_t rows, int64_t cols, int64_t src_rs,
+                                 int64_t src_cs, E *__restrict__ dst, int64_t dst_rs, int64_t dst_cs)
+{
+    // dst[j*dst_rs' ...]: reads a 64x64 tile with src contiguous along `cols` (src_cs == 1) and writes it with
+    // dst contiguous along `rows` (dst_rs == 1); LDS tile padded by one column to stay conflict-free.
+    __shared__ E tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 256 threads: 4 rows per pass
+    for (int i = ty; i < 64; i += 4) {
+        int64_t r = r0 + i, cc = c0 + tx;
+        if (r < rows && cc < cols) tile[i][tx] = src[r * src_rs + cc * src_cs];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        int64_t cc = c0 + i, r = r0 + tx;
+        if (r < rows && cc < cols) dst[r * dst_rs + cc * dst_cs] = tile[tx][i];
+    }
+}
+
+}  // namespace xs

@@ -1,0 +1,225 @@
+"""Array-level front-end of the HIP library: the functions the labelled (xarray-like) layer calls.
+
+Every series argument is logically ``x[cell, time]``: a 2-D numpy array with ANY dense strides (so the
+transposed view of a ``(time, cell)`` array is passed as is — the library reads time-major cubes through a
+tiled layout kernel, no host copy) or a :class:`DeviceArray` (``.cell_time_strides`` tells the layout).
+Results are numpy arrays for numpy inputs and :class:`DeviceArray` for device inputs.
+
+Reference functions behind each call: see ``include/xsdba_hip.h``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import EXTRAP, INTERP, Context, DeviceArray, check, default_context, dtype_code, load
+
+
+def _vp(a):
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return C.c_void_p(a.ptr)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _i64(v):
+    return C.c_int64(int(v))
+
+
+class _Series:
+    """Normalised (pointer, n_cell, n_time, stride_t, stride_c) view of a logical [cell, time] block."""
+
+    def __init__(self, x, dtype=None):
+        if isinstance(x, DeviceArray):
+            self.dev = True
+            self.arr = x
+            self.C, self.T = x.shape if getattr(x, "logical_shape", None) is None else x.logical_shape
+            sc, st = getattr(x, "cell_time_strides", (self.T, 1))
+            self.st, self.sc = int(st), int(sc)
+            self.dtype = x.dtype
+        else:
+            x = np.asarray(x)
+            if x.ndim != 2:
+                raise ValueError("series must be 2-D [cell, time]")
+            if dtype is not None and x.dtype != dtype:
+                x = x.astype(dtype)
+            self.C, self.T = x.shape
+            sc, st = (s // x.itemsize for s in x.strides)
+            cell_major = st == 1 and sc == self.T
+            time_major = sc == 1 and st == self.C
+            if not (cell_major or time_major) or self.C == 1 or self.T == 1:
+                # sliced / broadcast / negative strides (or a degenerate axis): one dense host copy
+                x = np.ascontiguousarray(x)
+                sc, st = self.T, 1
+            self.dev = False
+            self.arr = x
+            self.st, self.sc = int(st), int(sc)
+            self.dtype = x.dtype
+
+    @property
+    def ptr(self):
+        return _vp(self.arr)
+
+
+def _gidx(gidx, T, G):
+    if gidx is None:
+        if G != 1:
+            raise ValueError("group index required")
+        return None
+    g = np.ascontiguousarray(gidx, np.int32)
+    if g.shape != (T,):
+        raise ValueError(f"group_of_time must have shape ({T},), got {g.shape}")
+    return g
+
+
+def _out(ctx, dev, shape, dtype):
+    return ctx.empty(shape, dtype) if dev else np.empty(shape, dtype)
+
+
+def _table(tab, dtype, shape=None):
+    if isinstance(tab, DeviceArray):
+        return tab
+    t = np.ascontiguousarray(tab, dtype)
+    if shape is not None and t.shape != shape:
+        raise ValueError(f"table shape {t.shape} != {shape}")
+    return t
+
+
+def quantile_groups(x, gidx, G, W, q, ctx: Context | None = None):
+    """nbutils.quantile per (cell, group) -> [C, G, Q]"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    q = np.ascontiguousarray(q, s.dtype)
+    g = _gidx(gidx, s.T, G)
+    out = _out(ctx, s.dev, (s.C, G, q.size), s.dtype)
+    check(load().xsdba_hip_quantile_groups(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st),
+                                           _i64(s.sc), _vp(g), C.c_int(G), C.c_int(W), _vp(q), C.c_int(q.size), _vp(out)),
+          "quantile_groups")
+    return out
+
+
+def _train(fn, name, ref, hist, gidx, G, W, q, kind, with_scaling, ctx):
+    ctx = ctx or default_context()
+    r = _Series(ref)
+    h = _Series(hist, r.dtype)
+    if (h.C, h.T) != (r.C, r.T):
+        raise ValueError("ref and hist must have the same shape")
+    if (h.st, h.sc) != (r.st, r.sc) or h.dev != r.dev:
+        if r.dev or h.dev:
+            raise ValueError("ref and hist device arrays must share one layout")
+        r = _Series(np.ascontiguousarray(r.arr))
+        h = _Series(np.ascontiguousarray(h.arr))
+    q = np.ascontiguousarray(q, r.dtype)
+    g = _gidx(gidx, r.T, G)
+    af = _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
+    hq = _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
+    args = [ctx.handle, r.ptr, h.ptr, dtype_code(r.dtype), _i64(r.T), _i64(r.C), _i64(r.st), _i64(r.sc), _vp(g),
+            C.c_int(G), C.c_int(W), _vp(q), C.c_int(q.size), C.c_char(kind.encode()), _vp(af), _vp(hq)]
+    if with_scaling:
+        sc = _out(ctx, r.dev, (r.C, G), r.dtype)
+        check(fn(*args, _vp(sc)), name)
+        return af, hq, sc
+    check(fn(*args), name)
+    return af, hq
+
+
+def eqm_train(ref, hist, gidx, G, W, q, kind, ctx=None):
+    """_adjustment.eqm_train -> (af, hist_q) each [C, G, Q]"""
+    return _train(load().xsdba_hip_eqm_train, "eqm_train", ref, hist, gidx, G, W, q, kind, False, ctx)
+
+
+def dqm_train(ref, hist, gidx, G, W, q, kind, ctx=None):
+    """_adjustment.dqm_train -> (af, hist_q, scaling)"""
+    return _train(load().xsdba_hip_dqm_train, "dqm_train", ref, hist, gidx, G, W, q, kind, True, ctx)
+
+
+def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="+", return_nodes=False, ctx=None,
+              out_time_major=False):
+    """_adjustment.qm_adjust -> scen [C, T]; ``kind=None`` returns the interpolated factors
+    (utils.interp_on_quantiles)."""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G, Q = (af.shape[1], af.shape[2])
+    af = _table(af, s.dtype, (s.C, G, Q))
+    hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
+    g = _gidx(gidx, s.T, G)
+    scen = _out(ctx, s.dev, (s.T, s.C) if out_time_major else (s.C, s.T), s.dtype)
+    ost, osc = (s.C, 1) if out_time_major else (1, s.T)
+    node = np.empty((s.C, s.T), np.int32) if return_nodes else None
+    k = C.c_char(kind.encode()) if kind else C.c_char(b"\0")
+    check(load().xsdba_hip_qm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                     _vp(af), _vp(hist_q), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(INTERP[interp]),
+                                     C.c_int(EXTRAP[extrap]), k, _vp(scen), _i64(ost), _i64(osc), _vp(node)), "qm_adjust")
+    if out_time_major and not s.dev:
+        scen = scen.T
+    return (scen, node) if return_nodes else scen
+
+
+def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
+               ctx=None):
+    """_adjustment.dqm_adjust -> (scen, trend) each [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G, Q = (af.shape[1], af.shape[2])
+    af = _table(af, s.dtype, (s.C, G, Q))
+    hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
+    scaling = _table(scaling, s.dtype, (s.C, G))
+    g = _gidx(gidx, s.T, G)
+    tn = np.ascontiguousarray(time_num, np.float64)
+    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    trend = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_dqm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                      _vp(af), _vp(hist_q), _vp(scaling), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
+                                      _vp(tn), C.c_int(degree), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),
+                                      C.c_char(kind.encode()), _vp(scen), _vp(trend), _i64(1), _i64(s.T)), "dqm_adjust")
+    return scen, trend
+
+
+def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest", extrap="constant", kind="+",
+               want_sim_q=True, ctx=None):
+    """_adjustment.qdm_adjust -> (scen, sim_q)"""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G, Q = (af.shape[1], af.shape[2])
+    af = _table(af, s.dtype, (s.C, G, Q))
+    quantiles = np.ascontiguousarray(quantiles, s.dtype)
+    g = _gidx(gidx, s.T, G)
+    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    sim_q = _out(ctx, s.dev, (s.C, s.T), np.float64) if want_sim_q else None
+    check(load().xsdba_hip_qdm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                      _vp(af), _vp(quantiles), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
+                                      C.c_int(int(bool(rank_window))), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),
+                                      C.c_char(kind.encode()), _vp(scen), _vp(sim_q), _i64(1), _i64(s.T)), "qdm_adjust")
+    return scen, sim_q
+
+
+def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
+    """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    g = _gidx(gidx, s.T, G)
+    out = _out(ctx, s.dev, (s.C, s.T), np.float64)
+    check(load().xsdba_hip_rank_groups(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                       _vp(g), C.c_int(G), C.c_int(W), C.c_int(int(bool(rank_window))), _vp(out),
+                                       _i64(1), _i64(s.T)), "rank_groups")
+    return out
+
+
+def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
+    """PolyDetrend(degree).fit(x).ds.trend -> [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    g = _gidx(gidx, s.T, G)
+    tn = np.ascontiguousarray(time_num, np.float64)
+    out = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_polydetrend_trend(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st),
+                                             _i64(s.sc), _vp(g), C.c_int(G), C.c_int(W), _vp(tn), C.c_int(degree), _vp(out),
+                                             _i64(1), _i64(s.T)), "polydetrend_trend")
+    return out
+
+
+__all__ = ["quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "rank_groups",
+           "polydetrend_trend", "Context", "DeviceArray", "default_context"]
