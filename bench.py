@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py — grid-cells/s of the quantile-mapping hot path on MI355X (contract: see the task brief).
+
+One "step" = one full train + adjust pass of the workload over the rank's block of grid cells, with the
+synthetic (cell, time) cubes already resident in HBM (generated on the device).  Default
+workload = the one BASELINE.json's metric names: EmpiricalQuantileMapping, Grouper("time.dayofyear",
+window=31), kind "+", 30 years of daily data (10950 noleap days), nquantiles 20, interp "nearest", on the
+360x180 grid of configs[1] (64800 cells per GPU; weak scaling: every rank owns its own block of cells, no
+data-path collective).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time.
+
+N > 1: launched by torch.distributed.run, one process per GPU; torch is used only for the rendezvous,
+the barrier and the MAX over ranks (and the optional final RCCL gather of scen, timed separately).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
+
+WORKLOADS = {
+    # name: (method, group, window, kind, generator)
+    "eqm_doy31": ("eqm", "dayofyear", 31, "+", 0),
+    "eqm_month": ("eqm", "month", 1, "+", 0),
+    "eqm_time": ("eqm", "time", 1, "+", 0),
+    "dqm_doy31": ("dqm", "dayofyear", 31, "+", 0),
+    "qdm_doy31": ("qdm", "dayofyear", 31, "*", 1),
+}
+
+
+def group_index(group: str, T: int):
+    d0 = np.arange(T) % 365
+    if group == "dayofyear":
+        return d0.astype(np.int32), 365
+    if group == "month":
+        cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
+        return (np.searchsorted(cum, d0, side="right") - 1).astype(np.int32), 12
+    return np.zeros(T, np.int32), 1
+
+
+def algorithmic_bytes_per_cell(method, T, G, Q, itemsize=4):
+    """compulsory HBM traffic per grid cell (train, adjust)."""
+    train = 2 * T * itemsize + 2 * G * Q * itemsize + (G * itemsize if method == "dqm" else 0)
+    if method == "qdm":
+        adjust = T * itemsize + G * Q * itemsize + T * itemsize
+    else:
+        adjust = T * itemsize + 2 * G * Q * itemsize + T * itemsize
+        if method == "dqm":
+            adjust += G * itemsize + T * itemsize
+    return train, adjust
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="eqm_doy31", choices=sorted(WORKLOADS))
+    ap.add_argument("--cells", type=int, default=360 * 180, help="grid cells per GPU (default: the 360x180 grid)")
+    ap.add_argument("--days", type=int, default=10950)
+    ap.add_argument("--nquantiles", type=int, default=20)
+    ap.add_argument("--time-major", action="store_true", help="store the cubes as (time, cell) instead of (cell, time)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
+    ap.add_argument("--gather", action="store_true", help="N>1: also time the final RCCL gather of scen to rank 0")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from xsdba_amd import hip
+
+    ctx = hip.Context(local_rank)
+    method, group, W, kind, gen = WORKLOADS[args.workload]
+    C, T, Q = args.cells, args.days, args.nquantiles
+    gidx, G = group_index(group, T)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    tnum = (np.arange(T, dtype=np.float64) + 10950.0) * 86400e9
+    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3}.get(args.workload, 1)
+    cell0 = rank * C
+    ref = ctx.synth((C, T), np.float32, gen, 0, seed, cell0, time_major=args.time_major)
+    hist = ctx.synth((C, T), np.float32, gen, 1, seed, cell0, time_major=args.time_major)
+    sim = ctx.synth((C, T), np.float32, gen, 2, seed, cell0, time_major=args.time_major)
+    ctx.synchronize()
+
+    def step():
+        """one pass of the hot path over this rank's cells; returns the device outputs"""
+        if method == "dqm":
+            af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx)
+            scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind, ctx=ctx)
+            return [af, hq, sc, scen, trend]
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx)
+        if method == "qdm":
+            scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, False, "nearest", "constant", kind, want_sim_q=False, ctx=ctx)
+        else:
+            scen = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind, ctx=ctx)
+        return [af, hq, scen]
+
+    def free(outs):
+        for o in outs:
+            o.free()
+
+    def barrier():
+        ctx.synchronize()
+        if dist is not None:
+            import torch
+
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        free(step())
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    outs = None
+    for _ in range(args.steps):
+        if outs is not None:
+            free(outs)
+        outs = step()
+    ctx.synchronize()
+    if dist is not None:
+        import torch
+
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    if dist is not None:
+        import torch
+
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    gather_ms = None
+    if dist is not None and args.gather:
+        import torch
+
+        scen_dev = outs[-1] if method != "dqm" else outs[3]
+        scen_t = torch.empty((C, T), dtype=torch.float32, device="cuda")
+        # device-to-device copy of the library's buffer into a torch tensor, then one RCCL gather over xGMI
+        import ctypes
+
+        from xsdba_amd._lib import check, load
+
+        check(load().xsdba_hip_memcpy_d2h(ctx.handle, ctypes.c_void_p(scen_t.data_ptr()), ctypes.c_void_p(scen_dev.ptr),
+                                          ctypes.c_size_t(scen_dev.nbytes)), "d2d copy")
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        gl = [torch.empty_like(scen_t) for _ in range(world)] if rank == 0 else None
+        dist.gather(scen_t, gl, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        cells_total = C * world
+        value = cells_total / (elapsed / args.steps)
+        tb, ab = algorithmic_bytes_per_cell(method, T, G, Q)
+        # dominant kernel: the one with the largest total time inside the timed region (HIP events on the
+        # library's stream, recorded around every launch)
+        kern = {k: v for k, v in prof.items() if v["count"] > 0}
+        dom = max(kern, key=lambda k: kern[k]["total_ms"])
+        dom_avg_ms = kern[dom]["total_ms"] / kern[dom]["count"]
+        dom_bytes = C * (tb if dom.startswith("k_train") else ab)  # algorithmic bytes one launch moves
+        achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9
+        roof = {
+            "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
+            "kernels": {k: {"count": v["count"], "avg_ms": round(v["total_ms"] / v["count"], 4)} for k, v in kern.items()},
+        }
+        out = {
+            "metric": "grid-cells/sec for EQM train+adjust, DOY-grouped, 30yr daily; 1/2/4/8 GPU",
+            "value": round(value, 2), "unit": "grid-cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic (device-generated, counter-based)",
+            "config": {
+                "workload": f"{args.workload}: {method.upper()} train+adjust, group={group}, window={W}, kind='{kind}', "
+                            f"nquantiles={Q}, interp=nearest, {C} cells/GPU x {T} days fp32, "
+                            f"{'time-major (time,cell)' if args.time_major else 'cell-major (cell,time)'} cubes resident in HBM",
+                "cells_per_gpu": C, "days": T, "groups": G, "window": W, "parallelism": f"cells sharded over {world} GPU(s)",
+            },
+            "roofline": roof,
+        }
+        if gather_ms is not None:
+            out["gather_ms"] = round(gather_ms, 3)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
+                                               args.cpu_seconds, args.time_major)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major):
+    """The CPU oracle (a restatement of the reference algorithm, kind="port") timed on this box's host cores
+    on a bounded sample of the SAME device-generated cells; reported beside the GPU number, never the target."""
+    import oracle
+
+    threads = oracle.num_threads()
+
+    def fetch(dev, n):
+        full = dev.download()
+        return np.ascontiguousarray(full.T[:n] if time_major else full[:n])
+
+    def run(r, h, s):
+        t0 = time.perf_counter()
+        if method == "dqm":
+            af, hq, sc = oracle.dqm_train(r, h, gidx, G, W, q, kind)
+            oracle.dqm_adjust(s, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind)
+        else:
+            af, hq = oracle.eqm_train(r, h, gidx, G, W, q, kind)
+            if method == "qdm":
+                oracle.qdm_adjust(s, af, q, gidx, W, False, "nearest", "constant", kind)
+            else:
+                oracle.qm_adjust(s, af, hq, gidx, "nearest", "constant", kind)
+        return time.perf_counter() - t0
+
+    nmax = min(C, 8192)
+    r, h, s = fetch(ref, nmax), fetch(hist, nmax), fetch(sim, nmax)
+    probe = min(nmax, max(threads * 2, 16))
+    tp = run(r[:probe], h[:probe], s[:probe])
+    n = int(min(nmax, max(probe, probe * target_s / max(tp, 1e-6))))
+    n = max(threads, (n // threads) * threads)
+    tt = run(r[:n], h[:n], s[:n])
+    return {
+        "value": round(n / tt, 2), "unit": "grid-cells/s", "cores": threads, "kind": "port",
+        "sample": f"{n} of the {C} cells of rank 0 (same device-generated data), full train+adjust, {tt:.1f} s wall, "
+                  f"OpenMP over cells on {threads} threads of {os.cpu_count()} host CPUs; CPU restatement of the reference "
+                  "algorithm (oracle/xsdba_oracle.c), not the reference's dask/numba stack",
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,14 @@ int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, in
                                 int32_t window, const double *time_num, int32_t degree, void *trend,
                                 int64_t out_stride_t, int64_t out_stride_c);
 
+/* ---- bench / test utility: fill a DEVICE series block with the synthetic cubes of SURVEY §8d.
+ * generator 0 = seasonal temperature-like, 1 = gamma precipitation-like; array_id 0/1/2 = ref/hist/sim;
+ * value = f(seed, array_id, cell_offset + c, t): any cell block can be regenerated independently.
+ * nan_cell_frac: fraction of cells that are entirely NaN; nan_iid_frac: i.i.d. NaN elsewhere. */
+int xsdba_hip_synth_series(xsdba_hip_ctx *ctx, void *dst, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                           int64_t stride_c, int generator, int array_id, uint64_t seed, int64_t cell_offset,
+                           float nan_cell_frac, float nan_iid_frac);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ SYMBOLS = [
     "xsdba_hip_memcpy_h2d", "xsdba_hip_memcpy_d2h", "xsdba_hip_memset", "xsdba_hip_profile_enable",
     "xsdba_hip_profile_read", "xsdba_hip_timer_start", "xsdba_hip_timer_stop", "xsdba_hip_quantile_groups",
     "xsdba_hip_eqm_train", "xsdba_hip_dqm_train", "xsdba_hip_qm_adjust", "xsdba_hip_dqm_adjust",
-    "xsdba_hip_qdm_adjust", "xsdba_hip_rank_groups", "xsdba_hip_polydetrend_trend",
+    "xsdba_hip_qdm_adjust", "xsdba_hip_rank_groups", "xsdba_hip_polydetrend_trend", "xsdba_hip_synth_series",
 ]
 
 
@@ -110,6 +110,18 @@ class DeviceArray:
         check(load().xsdba_hip_malloc(ctx.handle, C.c_size_t(max(self.nbytes, 1)), C.byref(p)), "malloc")
         self.ptr = p.value
 
+    @classmethod
+    def from_ptr(cls, ctx: "Context", ptr: int, shape, dtype) -> "DeviceArray":
+        """Non-owning view of device memory allocated elsewhere (e.g. a torch tensor's data_ptr())."""
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        self.ptr = int(ptr)
+        self.foreign = True
+        return self
+
     def upload(self, host: np.ndarray) -> "DeviceArray":
         host = np.ascontiguousarray(host, self.dtype)
         assert host.shape == self.shape
@@ -124,6 +136,9 @@ class DeviceArray:
         return out
 
     def free(self) -> None:
+        if getattr(self, "foreign", False):
+            self.ptr = None
+            return
         if self.ptr:
             check(load().xsdba_hip_free(self.ctx.handle, C.c_void_p(self.ptr)), "free")
             self.ptr = None
@@ -162,6 +177,21 @@ class Context:
     def to_device(self, host: np.ndarray) -> DeviceArray:
         host = np.ascontiguousarray(host)
         return DeviceArray(self, host.shape, host.dtype).upload(host)
+
+    def synth(self, shape_ct, dtype, generator: int, array_id: int, seed: int, cell_offset: int = 0,
+              nan_cell_frac: float = 0.0, nan_iid_frac: float = 0.0, time_major: bool = False) -> DeviceArray:
+        """Device-generated synthetic [cell, time] block (bench / tests); see xsdba_hip_synth_series."""
+        Cn, T = shape_ct
+        arr = DeviceArray(self, (T, Cn) if time_major else (Cn, T), dtype)
+        if time_major:
+            arr.logical_shape = (Cn, T)
+            arr.cell_time_strides = (1, Cn)
+        st, sc = (Cn, 1) if time_major else (1, T)
+        check(load().xsdba_hip_synth_series(self.handle, C.c_void_p(arr.ptr), C.c_int(dtype_code(dtype)), C.c_int64(T),
+                                            C.c_int64(Cn), C.c_int64(st), C.c_int64(sc), C.c_int(generator),
+                                            C.c_int(array_id), C.c_uint64(seed), C.c_int64(cell_offset),
+                                            C.c_float(nan_cell_frac), C.c_float(nan_iid_frac)), "synth_series")
+        return arr
 
     def profile_enable(self, on: bool = True):
         check(load().xsdba_hip_profile_enable(self.handle, C.c_int(int(on))), "profile_enable")

@@ -650,7 +650,7 @@ API int xsdba_hip_memcpy_d2h(xsdba_hip_ctx *ctx, void *dst, const void *src, siz
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));  // also device -> device
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -794,4 +794,23 @@ API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype
     if (rc) return rc;
     return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)),
                     (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)));
+}
+
+API int xsdba_hip_synth_series(xsdba_hip_ctx *ctx, void *dst, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                               int generator, int array_id, uint64_t seed, int64_t cell_offset, float nan_cell_frac,
+                               float nan_iid_frac)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!dst || !is_device_ptr(dst) || T <= 0 || C <= 0 || generator < 0 || generator > 1 || array_id < 0 || array_id > 2)
+        return fail(XSDBA_E_ARG, "synth_series needs a device destination and generator in {0,1}, array_id in {0,1,2}");
+    LaunchScope ls(ctx, "k_synth");
+    if (dtype == XSDBA_F32)
+        hipLaunchKernelGGL(xs::k_synth<float>, dim3(4096), dim3(256), 0, ctx->stream, (float *)dst, T, C, st, sc, generator,
+                           array_id, seed, cell_offset, nan_cell_frac, nan_iid_frac);
+    else if (dtype == XSDBA_F64)
+        hipLaunchKernelGGL(xs::k_synth<double>, dim3(4096), dim3(256), 0, ctx->stream, (double *)dst, T, C, st, sc, generator,
+                           array_id, seed, cell_offset, nan_cell_frac, nan_iid_frac);
+    else return fail(XSDBA_E_ARG, "bad dtype");
+    return check_launch("k_synth");
 }

@@ -396,4 +396,52 @@ __global__ void k_transpose_tile(const E *__restrict__ src, int64_t rows, int64_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// synthetic cubes for bench.py / tests: counter-based, value = f(seed, array, cell, t), so any
+// cell block can be regenerated independently on any rank.  generator 0: seasonal temperature-like
+// (tests/test_utils.py:118-133 style); generator 1: gamma precipitation-like (testing/helpers.py:23-35
+// shape/scale, Wilson-Hilferty transform of a normal deviate).  noleap calendar: doy = t mod 365.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float u01(uint64_t h) { return ((float)(uint32_t)(h >> 40) + 0.5f) * (1.0f / 16777216.0f); }
+
+template <typename R>
+__global__ void k_synth(R *__restrict__ dst, int64_t T, int64_t C, int64_t st, int64_t sc, int generator, int array_id,
+                        uint64_t seed, int64_t cell0, float nan_cell_frac, float nan_iid_frac)
+{
+    const int64_t n = T * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        // enumerate in storage order so that stores coalesce for either layout
+        int64_t c, t;
+        if (st == 1) { c = i / T; t = i - c * T; } else { t = i / C; c = i - t * C; }
+        const uint64_t gc = (uint64_t)(cell0 + c);
+        const uint64_t hc = mix64(seed * 0x100000001B3ull + gc);                       // per cell
+        const uint64_t h = mix64(hc ^ mix64(((uint64_t)array_id << 40) + (uint64_t)t));  // per element
+        float u = u01(h), u2 = u01(mix64(h));
+        float v;
+        if (generator == 0) {
+            float off = 3.0f * sqrtf(-2.0f * logf(u01(hc))) * cospif(2.0f * u01(mix64(hc)));
+            float amp = array_id == 0 ? 20.0f : 18.0f, base = array_id == 2 ? 281.0f : 280.0f;
+            float noise = array_id == 2 ? 2.2f : 2.0f, tr = array_id == 0 ? 0.10f : (array_id == 1 ? 0.11f : 0.15f);
+            int doy = (int)(t % 365) + 1;
+            v = base - amp * cospif(2.0f * (float)doy / 365.0f) + noise * u + tr * (float)t / 365.0f + off;
+        } else {
+            float k = array_id == 0 ? 4.0f : (array_id == 1 ? 8.15f : 16.0f);
+            float th = array_id == 0 ? 7.5f : (array_id == 1 ? 3.68f : 2.63f);
+            float z = sqrtf(-2.0f * logf(u)) * cospif(2.0f * u2);
+            float w = 1.0f - 1.0f / (9.0f * k) + z / (3.0f * sqrtf(k));
+            v = fmaxf(k * th * w * w * w, 1e-3f);
+        }
+        if (nan_cell_frac > 0.f && u01(mix64(hc ^ 0xABCDEFull)) < nan_cell_frac) v = __builtin_nanf("");
+        if (nan_iid_frac > 0.f && u01(mix64(h ^ 0x123457ull)) < nan_iid_frac) v = __builtin_nanf("");
+        dst[c * sc + t * st] = (R)v;
+    }
+}
+
 }  // namespace xs
