@@ -1,0 +1,281 @@
+"""The reference's own tests of the path, re-expressed against xsdba_amd (GPU): tests/test_adjustment.py
+TestQM (:945-1031), TestDQM (:318-385), TestQDM (:700-744, :862-889), tests/test_utils.py
+interp_on_quantiles (:68-146) and rank (:197-205), tests/test_nbutils.py (:10-34),
+tests/test_detrending.py (:18-30).  They read like the originals: same inputs, same assertions."""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+import pytest
+from scipy.stats import norm, uniform
+
+import xsdba_amd as xs
+from xsdba_amd import nbutils as nbu
+from xsdba_amd import utils as u
+from xsdba_amd.labeled import DataArray
+from xsdba_amd.utils import ADDITIVE, MULTIPLICATIVE, apply_correction, get_correction, invert
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from xsdba_amd import hip
+
+    hip.default_context(0)
+
+
+@pytest.fixture
+def random():
+    return np.random.default_rng(seed=list(map(ord, "𝕽𝔞𝖓𝔡𝖔𝔪")))
+
+
+def timelonlatseries(values, attrs=None, start="2000-01-01"):
+    """reference testing/helpers.py:51-66 (time, lon, lat) builder on the standard calendar"""
+    values = np.asarray(values)
+    dims = ("time", "lon", "lat")[: values.ndim]
+    coords = {"time": xs.date_range(start, values.shape[0], "standard").values}
+    for d, n in zip(dims[1:], values.shape[1:]):
+        coords[d] = np.arange(n)
+    return DataArray(values, dims, coords, attrs or {})
+
+
+def timeseries(values, start="2000-07-01", units=None, calendar=None):
+    t = xs.date_range(start, len(values), calendar or "standard")
+    return DataArray(np.asarray(values), ("time",), {"time": t.values}, {"units": units} if units else {})
+
+
+MON_TRI = np.array(list(range(1, 7)) + list(range(7, 1, -1))) / 7
+
+
+def mon_timelonlatseries(values, attrs):
+    x = timelonlatseries(values, attrs)
+    month = xs.Grouper("time.month").get_index(x).values
+    factor = timelonlatseries(MON_TRI[month - 1], attrs)
+    return DataArray(apply_correction(x, factor, attrs["kind"]).values, x.dims, x.coords, attrs)
+
+
+class TestQM:
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_quantiles(self, kind, units, random):
+        u_ = random.random(10000)
+        xd, yd = uniform(loc=10, scale=1), norm(loc=12, scale=1)
+        x, y = xd.ppf(u_), yd.ppf(u_)
+        hist = sim = timelonlatseries(x, attrs={"units": units})
+        ref = timelonlatseries(y, attrs={"units": units})
+        QM = xs.EmpiricalQuantileMapping.train(ref, hist, kind=kind, group="time", nquantiles=50)
+        p = QM.adjust(sim, interp="linear")
+        q = QM.ds.coords["quantiles"].values
+        expected = get_correction(xd.ppf(q), yd.ppf(q), kind)[np.newaxis, :]
+        np.testing.assert_array_almost_equal(QM.ds.af.values[:, 2:-2], expected[:, 2:-2], 1)
+        middle = (u_ > 1e-2) * (u_ < 0.99)
+        np.testing.assert_array_almost_equal(p.values[middle], ref.values[middle], 1)
+        # trained dataset layout
+        assert QM.ds.af.dims == ("group", "quantiles") and QM.ds.sizes["group"] == 1
+        assert set(QM.ds.data_vars) == {"af", "hist_q", "hist_q_raw"} and np.isnan(QM.ds.hist_q_raw.values).all()
+        assert QM.ds.attrs["group"] == "time" and QM.ds.attrs["group_window"] == 1
+        assert "Bias-adjusted with EmpiricalQuantileMapping(" in p.attrs["history"] and p.attrs["units"] == units
+        assert p.attrs["bias_adjustment"].endswith(".adjust(sim, interp='linear')")
+
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_mon_u(self, kind, units, random):
+        u_ = random.random(10000)
+        xd, yd, noise = uniform(loc=2, scale=0.1), uniform(loc=4, scale=0.1), uniform(loc=0, scale=1e-7)
+        x, y = xd.ppf(u_), yd.ppf(u_) + noise.ppf(u_)
+        attrs = {"units": units, "kind": kind}
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        ref = mon_timelonlatseries(y, attrs=attrs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            QM = xs.EmpiricalQuantileMapping.train(ref, hist, kind=kind, group="time.month", nquantiles=5)
+            p = QM.adjust(sim)
+        mqm = QM.ds.af.mean(dim="quantiles")
+        expected = apply_correction(MON_TRI, 2, kind)
+        np.testing.assert_array_almost_equal(mqm.values, expected, 1)
+        np.testing.assert_array_almost_equal(p.values, ref.values, 2)
+
+    def test_grid_and_layouts(self, random):
+        """(time, lon, lat) cubes go through without host transposes; result matches per-cell training"""
+        T = 1460
+        vals = random.random((T, 3, 4)).astype(np.float32) * 5 + 280
+        t = xs.date_range("2001-01-01", T, "noleap").values
+        mk = lambda v: DataArray(v, ("time", "lon", "lat"), {"time": t, "lon": np.arange(3), "lat": np.arange(4)}, {"units": "K"})  # noqa: E731
+        ref, hist = mk(vals), mk(vals[::-1].copy())
+        EQM = xs.EmpiricalQuantileMapping.train(ref, hist, group=xs.Grouper("time.dayofyear", window=31), nquantiles=10)
+        assert EQM.ds.af.dims == ("lon", "lat", "dayofyear", "quantiles") and EQM.ds.af.dtype == np.float32
+        scen = EQM.adjust(hist)
+        assert set(scen.dims) == {"time", "lon", "lat"} and scen.dtype == np.float32
+        one = xs.EmpiricalQuantileMapping.train(ref.isel(lon=1, lat=2), hist.isel(lon=1, lat=2),
+                                                group=xs.Grouper("time.dayofyear", window=31), nquantiles=10)
+        np.testing.assert_array_equal(one.ds.af.values, EQM.ds.af.values[1, 2])
+        np.testing.assert_array_equal(one.adjust(hist.isel(lon=1, lat=2)).values, scen.transpose("lon", "lat", "time").values[1, 2])
+
+
+class TestDQM:
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_quantiles(self, kind, units, random):
+        ns = 10000
+        u_ = random.random(ns)
+        xd, yd = uniform(loc=10, scale=1), norm(loc=12, scale=1)
+        x, y = xd.ppf(u_), yd.ppf(u_)
+        attrs = {"units": units, "kind": kind}
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        ref = timelonlatseries(y, attrs=attrs)
+        DQM = xs.DetrendedQuantileMapping.train(ref, hist, kind=kind, group="time", nquantiles=50)
+        p = DQM.adjust(sim, interp="linear")
+        q = DQM.ds.coords["quantiles"].values
+        ex = apply_correction(xd.ppf(q), invert(xd.mean(), kind), kind)
+        ey = apply_correction(yd.ppf(q), invert(yd.mean(), kind), kind)
+        expected = get_correction(ex, ey, kind)
+        np.testing.assert_array_almost_equal(DQM.ds.af.values[:, 2:-2], expected[np.newaxis, 2:-2], 1)
+        middle = (u_ > 1e-2) * (u_ < 0.99)
+        np.testing.assert_array_almost_equal(p.values[middle], ref.values[middle], 1)
+        # with an actual trend in sim (:375-385)
+        trend = timelonlatseries(np.linspace(-0.2, 0.2, ns) + (1 if kind == MULTIPLICATIVE else 0), attrs=attrs)
+        sim3 = DataArray(apply_correction(sim, trend, kind).values, sim.dims, sim.coords, attrs)
+        ref3 = apply_correction(ref, trend, kind)
+        p3 = DQM.adjust(sim3, interp="linear")
+        np.testing.assert_array_almost_equal(p3.values[middle], ref3.values[middle], 1)
+        assert "scaling" in DQM.ds.data_vars and DQM.ds.scaling.dims == ("group",)
+
+    def test_doy_window_360(self):
+        # reference :455-491 test_360: doy window 31 on a 360-day calendar -> sizes {dayofyear: 360, quantiles: 50}
+        rng = np.random.default_rng(0)
+        T = 360 * 6
+        t = xs.date_range("2000-01-01", T, "360_day").values
+        mk = lambda v: DataArray(v, ("time",), {"time": t}, {"units": "K"})  # noqa: E731
+        ref, hist = mk(rng.random(T) + 280), mk(rng.random(T) + 281)
+        DQM = xs.DetrendedQuantileMapping.train(ref, hist, group=xs.Grouper("time.dayofyear", window=31), nquantiles=50)
+        assert dict(DQM.ds.af.sizes) == {"dayofyear": 360, "quantiles": 50}
+        scen = DQM.adjust(hist)
+        assert np.isfinite(scen.values).all()
+
+    def test_from_dataset_roundtrip(self, random):
+        # reference :434-452: the trained dataset alone restores the object
+        T = 1460
+        t = xs.date_range("2001-01-01", T, "noleap").values
+        mk = lambda v: DataArray(v, ("time",), {"time": t}, {"units": "K"})  # noqa: E731
+        ref, hist = mk(random.random(T) + 280), mk(random.random(T) + 281)
+        DQM = xs.DetrendedQuantileMapping.train(ref, hist, group="time.dayofyear", window=31, nquantiles=10)
+        DQM2 = xs.DetrendedQuantileMapping.from_dataset(DQM.ds)
+        assert repr(DQM2) == repr(DQM) and DQM2.group.window == 31
+        np.testing.assert_array_equal(DQM.adjust(hist).values, DQM2.adjust(hist).values)
+
+
+class TestQDM:
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_quantiles(self, kind, units, random):
+        u_ = random.random(10000)
+        xd, yd = uniform(loc=1, scale=1), uniform(loc=2, scale=4)
+        x, y = xd.ppf(u_), yd.ppf(u_)
+        attrs = {"units": units, "kind": kind}
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        ref = timelonlatseries(y, attrs=attrs)
+        QDM = xs.QuantileDeltaMapping.train(ref.astype("float32"), hist.astype("float32"), kind=kind, group="time", nquantiles=10)
+        p = QDM.adjust(sim.astype("float32"), interp="linear")
+        q = QDM.ds.coords["quantiles"].values
+        expected = get_correction(xd.ppf(q), yd.ppf(q), kind)[np.newaxis, :]
+        np.testing.assert_array_almost_equal(QDM.ds.af.values, expected, 1)
+        middle = (u_ > 1e-2) * (u_ < 0.99)
+        np.testing.assert_array_almost_equal(p.values[middle], ref.values[middle], 1)
+        assert QDM.ds.af.dtype == "float32" and p.dtype == "float32"  # dtype control (:743-744)
+
+    def test_qdm_adjust_rank_window(self):
+        def _daily_series(start, periods, offset=0):
+            steps = np.arange(periods)
+            values = 280 + np.sin(2 * np.pi * (steps % 365) / 365) + 0.01 * steps + offset
+            return DataArray(values, ("time",), {"time": xs.date_range(start, periods, "noleap").values}, {"units": "K"})
+
+        hist = _daily_series("2001-01-01", 2 * 365)
+        ref = DataArray(hist.values + 2, hist.dims, hist.coords, {"units": "K"})
+        sim = _daily_series("2003-01-01", 365, offset=1)
+        group = xs.Grouper("time.dayofyear", window=31)
+        QDM = xs.QuantileDeltaMapping.train(ref, hist, kind="+", group=group, nquantiles=10)
+        with pytest.warns(DeprecationWarning, match="same window as used in the training.*will be deprecated in"):
+            scen_default = QDM.adjust(sim)
+        assert bool(np.isnan(scen_default.values).all())
+        scen_window = QDM.adjust(sim, rank_window=True)
+        assert bool(np.isfinite(scen_window.values).all())
+        with xs.set_options(extra_output=True):
+            out = QDM.adjust(sim, rank_window=True)
+        assert bool(np.isfinite(out.sim_q.values).all())
+
+
+@pytest.mark.parametrize("interp,expi", [("nearest", 2.9), ("linear", 2.95)])
+@pytest.mark.parametrize("extrap,expe", [("constant", 4.4), ("nan", np.nan)])
+def test_interp_on_quantiles_constant(interp, expi, extrap, expe):
+    # reference tests/test_utils.py:68-113 ('cubic' is outside the device path)
+    quantiles = np.linspace(0, 1, num=25)
+    xq = DataArray(np.linspace(205, 229, num=25), ("quantiles",), {"quantiles": quantiles})
+    yq = DataArray(np.linspace(2, 4.4, num=25), ("quantiles",), {"quantiles": quantiles})
+    v = np.linspace(240, 200, num=41) - 0.5
+    newx = DataArray(np.where(v > 201, v, np.nan), ("time",), {"time": xs.date_range("1900-03-01", 41, "standard").values})
+    xq, yq, newx = xq.expand_dims(lat=[1, 2, 3]), yq.expand_dims(lat=[1, 2, 3]), newx.expand_dims(lat=[1, 2, 3])
+    for punch in (False, True):
+        if punch:
+            xq, yq = xq.where(xq != 220), yq.where(yq != 3)
+        out = u.interp_on_quantiles(newx, xq, yq, group="time", method=interp, extrapolation=extrap)
+        if np.isnan(expe):
+            assert out.isel(time=0).isnull().all()
+        else:
+            assert out.isel(lat=1, time=0) == expe
+        np.testing.assert_allclose(out.isel(time=25).values, expi)
+        assert out.isel(time=-1).isnull().all()
+
+
+def test_interp_on_quantiles_monthly(random):
+    # reference tests/test_utils.py:116-146: no NaN with constant extrapolation on the month path
+    T = 365 * 31
+    t = xs.date_range("2000-01-01", T, "noleap")
+    doy, days = t.dayofyear, np.arange(T)
+    mk = lambda v: DataArray(v, ("time",), {"time": t.values}, {"units": "K"})  # noqa: E731
+    ref = mk(-20 * np.cos(2 * np.pi * doy / 365) + 2 * random.random(T) + 273.15 + 0.1 * days / 365)
+    sim = mk(-18 * np.cos(2 * np.pi * doy / 365) + 2 * random.random(T) + 273.15 + 0.11 * days / 365)
+    n = 365 * 15
+    refc, hist = ref.isel(time=slice(0, n)), sim.isel(time=slice(0, n))
+    group = xs.Grouper("time.month")
+    quantiles = u.equally_spaced_nodes(15, eps=1e-6)
+    ref_q = group.apply(nbu.quantile, refc, main_only=True, q=quantiles)
+    hist_q = group.apply(nbu.quantile, hist, main_only=True, q=quantiles)
+    af = u.get_correction(hist_q, ref_q, "+")
+    afi = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="nearest", extrapolation="constant")
+    assert afi.isnull().sum("time") == 0
+    with pytest.raises(NotImplementedError):  # grouped linear/cubic: Qhull path of the reference
+        u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="linear")
+
+
+def test_rank(random):
+    # reference tests/test_utils.py:197-205
+    arr = random.random((10, 10, 1000))
+    ranks = u.rank(DataArray(arr, ("x", "y", "time")), dim="time", pct=False)
+    np.testing.assert_array_equal(ranks.values, arr.argsort().argsort() + 1)
+    # ties get average ranks (:208-217 data)
+    tie = u.rank(DataArray(np.array([1, 26, 2, 4.0, 6, 2, 2]), ("time",)), dim="time", pct=False)
+    np.testing.assert_array_equal(tie.values, [1, 7, 3, 5, 6, 3, 3])
+
+
+def test_nbutils_quantile(random):
+    # reference tests/test_nbutils.py: equals nanquantile to 6 decimals; single-value and all-NaN edge cases
+    x = random.gamma(2.0, 3.0, (5, 2190))
+    da = DataArray(x, ("location", "time"))
+    q = np.linspace(0.1, 0.99, 50)
+    out = nbu.quantile(da, q, dim="time")
+    assert out.dims == ("location", "quantiles")
+    np.testing.assert_array_almost_equal(out.values, np.quantile(x, q, axis=1).T)
+    one = DataArray(np.array([1] + [np.nan] * 100), ("dim_0",))
+    np.testing.assert_array_equal(nbu.quantile(one, q, dim="dim_0").values, np.full_like(q, 1))
+    allnan = DataArray(np.array([np.nan] * 100), ("dim_0",))
+    np.testing.assert_array_equal(nbu.quantile(allnan, q, dim="dim_0").values, np.full_like(q, np.nan))
+
+
+def test_poly_detrend():
+    # reference tests/test_detrending.py:18-30
+    x = timeseries(np.arange(20 * 365.25), units="K")
+    fx = xs.PolyDetrend(degree=1).fit(x)
+    dx = fx.detrend(x)
+    xt = fx.retrend(dx)
+    np.testing.assert_array_almost_equal(dx.values, 0)
+    np.testing.assert_array_almost_equal(xt.values, x.values)
+    fx2 = xs.PolyDetrend.from_dataset(fx.ds)
+    np.testing.assert_array_equal(fx2.detrend(x).values, dx.values)

@@ -1,0 +1,225 @@
+"""The compute functions behind the adjustment classes, with the reference's names and signatures
+(xsdba._adjustment: eqm_train :193-286, dqm_train :95-190, qm_adjust :594-676, dqm_adjust :679-780,
+qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` like the reference, but its
+body is ONE call into the HIP library that covers every group of every cell of the block.
+
+Not yet on the device path (rows "next" of SURVEY §8f; they raise NotImplementedError instead of running
+anything on the CPU): ``adapt_freq_thresh``, ``jitter_*``, ``max_tail_factor``, ``add_dims``,
+grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import hip
+from . import nbutils as nbu
+from . import utils as u
+from .base import Grouper, map_blocks, map_groups
+from .detrending import PolyDetrend
+from .labeled import Coordinate, DataArray, Dataset, as_dataarray, full_like
+from .utils import cell_time_view, table_view
+
+
+def _unsupported(**opts):
+    bad = {k: v for k, v in opts.items() if v is not None}
+    if bad:
+        raise NotImplementedError(
+            f"option(s) {sorted(bad)} are not implemented on the HIP path yet (pre-processing rows of SURVEY §8f)"
+        )
+
+
+def _check_group(group: Grouper, ds):
+    if group.add_dims:
+        raise NotImplementedError("Grouper(add_dims=...) is not implemented on the HIP path yet")
+
+
+def _common_dtype(*arrays):
+    dt = max((np.asarray(a).dtype for a in arrays), key=lambda d: d.itemsize)  # base.py:681-685
+    return np.result_type(dt, np.float32)
+
+
+def _train_dataset(ref: DataArray, group: Grouper, quantiles, cell_dims, cell_shape, **tables):
+    """Dataset with the reference's variables/dims/coords: (cells..., <prop>, quantiles) (base.py:653-694)."""
+    prop = group.prop
+    crd = group.get_coordinate(ref)
+    G, Q = crd.size, len(quantiles)
+    coords = {k: c for k, c in ref.coords.items() if k in cell_dims}
+    coords[prop] = Coordinate(prop, crd.values)
+    coords["quantiles"] = Coordinate("quantiles", np.asarray(quantiles))
+    out = {}
+    for name, tab in tables.items():
+        if tab.ndim == 3:
+            out[name] = DataArray(tab.reshape(cell_shape + (G, Q)), cell_dims + (prop, "quantiles"), coords)
+        else:
+            c2 = {k: c for k, c in coords.items() if k != "quantiles"}
+            out[name] = DataArray(tab.reshape(cell_shape + (G,)), cell_dims + (prop,), c2)
+    return Dataset(out)
+
+
+def _prep_train(ds, group):
+    _check_group(group, ds)
+    ref, hist = as_dataarray(ds["ref"]), as_dataarray(ds["hist"])
+    dt = _common_dtype(ref.values, hist.values)
+    hist = hist.transpose(*ref.dims)
+    r2, cell_dims, cell_shape = cell_time_view(ref.astype(dt) if ref.dtype != dt else ref, group.dim)
+    h2, _, _ = cell_time_view(hist.astype(dt) if hist.dtype != dt else hist, group.dim)
+    gidx, G = group.group_index(ref)
+    return ref, r2, h2, gidx, G, cell_dims, cell_shape, dt
+
+
+def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
+                     jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
+                 max_tail_factor=max_tail_factor)
+    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    q = np.asarray(quantiles, dt)
+    af, hq = hip.eqm_train(r2, h2, gidx, G, group.window, q, kind)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq,
+                         hist_q_raw=np.full_like(hq, np.nan))  # dummy unless max_tail_factor (:273-275)
+    out["af"].attrs["kind"] = kind
+    return out
+
+
+def _fused_dqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
+                     jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
+                 max_tail_factor=max_tail_factor)
+    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    q = np.asarray(quantiles, dt)
+    af, hq, sc = hip.dqm_train(r2, h2, gidx, G, group.window, q, kind)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq,
+                         hist_q_raw=np.full_like(hq, np.nan), scaling=sc)
+    out["af"].attrs["kind"] = kind
+    out["scaling"].attrs["kind"] = kind
+    return out
+
+
+@map_groups(
+    fused=_fused_dqm_train,
+    af=[Grouper.PROP, "quantiles"],
+    hist_q=[Grouper.PROP, "quantiles"],
+    hist_q_raw=[Grouper.PROP, "quantiles"],
+    scaling=[Grouper.PROP],
+)
+def dqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
+              jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None) -> Dataset:
+    """Train step on one group (the per-group body kept for ``Grouper.apply(dqm_train.func, ...)``;
+    _adjustment.py:150-190): group-mean normalisation, quantiles, af, scaling."""
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
+                 max_tail_factor=max_tail_factor)
+    ref_dim = Grouper.filter_dim(ds.ref, dim)
+    sim_dim = Grouper.filter_dim(ds.hist, dim)
+    mu_ref, mu_hist = ds.ref.mean(ref_dim), ds.hist.mean(sim_dim)
+    refn = u.apply_correction(ds.ref, u.invert(mu_ref, kind), kind)
+    histn = u.apply_correction(ds.hist, u.invert(mu_hist, kind), kind)
+    ref_q = nbu.quantile(refn, quantiles, ref_dim)
+    hist_q = nbu.quantile(histn, quantiles, sim_dim)
+    af = u.get_correction(hist_q, ref_q, kind)
+    scaling = u.get_correction(mu_hist, mu_ref, kind=kind)
+    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": full_like(hist_q, np.nan), "scaling": scaling})
+
+
+@map_groups(
+    fused=_fused_eqm_train,
+    af=[Grouper.PROP, "quantiles"],
+    hist_q=[Grouper.PROP, "quantiles"],
+    hist_q_raw=[Grouper.PROP, "quantiles"],
+)
+def eqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
+              jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None) -> Dataset:
+    """EQM: train step on one group (per-group body, _adjustment.py:253-286)."""
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
+                 max_tail_factor=max_tail_factor)
+    ref_q = nbu.quantile(ds.ref, quantiles, Grouper.filter_dim(ds.ref, dim))
+    hist_q = nbu.quantile(ds.hist, quantiles, Grouper.filter_dim(ds.hist, dim))
+    af = u.get_correction(hist_q, ref_q, kind)
+    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": full_like(hist_q, np.nan)})
+
+
+def _prep_adjust(ds, group: Grouper, interp: str):
+    _check_group(group, ds)
+    if interp not in ("nearest", "linear", "cubic"):
+        raise ValueError(f"interp must be 'nearest', 'linear' or 'cubic', got {interp!r}")
+    if interp == "cubic" or (interp != "nearest" and group.prop != "group"):
+        raise NotImplementedError(
+            f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path: the reference routes it "
+            "through scipy.griddata's Qhull triangulation (utils.py:391-396); use interp='nearest' (its default)"
+        )
+    sim = as_dataarray(ds["sim"])
+    dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
+    s2, cell_dims, cell_shape = cell_time_view(sim.astype(dt) if sim.dtype != dt else sim, group.dim)
+    gidx, G = group.group_index(sim)
+    return sim, s2, gidx, G, cell_dims, cell_shape, dt
+
+
+def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=None):
+    coords = {k: c for k, c in sim.coords.items() if k in cell_dims or k == dim}
+    return DataArray(arr.reshape(cell_shape + (arr.shape[-1],)), cell_dims + (dim,), coords, attrs or {}, name)
+
+
+@map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[])
+def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
+    """QM (DQM and EQM): adjust step on one block (_adjustment.py:594-676)."""
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
+    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
+    scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
+    return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
+
+
+@map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], trend=[])
+def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
+    """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
+    means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device."""
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    if isinstance(detrend, PolyDetrend):
+        if detrend.group.name != group.name or detrend.group.window != group.window or detrend.kind != kind or detrend.preserve_mean or detrend.mult_skip_zeros:
+            raise NotImplementedError("dqm_adjust on the HIP path takes detrend=<int> or a PolyDetrend on the same group/kind")
+        degree = int(detrend.degree)
+    elif isinstance(detrend, (int, np.integer)):
+        degree = int(detrend)
+    else:
+        raise NotImplementedError("dqm_adjust on the HIP path supports polynomial detrending (an int degree) only")
+    if degree not in (0, 1):
+        raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0 or 1)")
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
+    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
+    sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    tnum = group._time_index(sim).numeric_ns
+    scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
+    return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
+                    "trend": _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")})
+
+
+@map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], sim_q=[])
+def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, rank_window=None, max_tail_factor=None) -> Dataset:
+    """QDM adjustment on one block (_adjustment.py:783-886)."""
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    if rank_window is None:
+        rank_window = False
+        if group.window > 1:
+            warnings.warn(
+                "QDM method can now perform the adjustment step by expanding the time dimension "
+                "with the same window as used in the training. This can already be used by setting "
+                "`rank_window = True`. This will be the only possible behaviour in `xsdba>=0.8`.  "
+                "The current behaviour is obtained by setting `rank_window = False` and will be "
+                "deprecated in `xsdba>=0.8`. It will still be possible to use the old behaviour by "
+                "monkeypatching the group argument in the QDM class between the training and "
+                "adjustment, though this behaviour is not recommended.",
+                category=DeprecationWarning,
+                stacklevel=2,
+            )
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
+    quantiles = np.asarray(ds["quantiles"].values, dt)
+    scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
+    return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
+                    "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})

@@ -1,0 +1,275 @@
+"""Adjustment classes of the hot path with the reference's interface (xsdba.adjustment:
+BaseAdjustment :68-206, TrainAdjust :209-332, EmpiricalQuantileMapping :414-528, DetrendedQuantileMapping
+:531-671, QuantileDeltaMapping :674-742).
+
+Same call pattern — ``Cls.train(ref, hist, **kw)`` then ``obj.adjust(sim, **kw)`` —, same checks and errors,
+same trained dataset (``af``, ``hist_q``, ``hist_q_raw``[, ``scaling``], attrs ``group``,
+``group_compute_dims``, ``group_window``, ``_xsdba_adjustment``, ``adj_params``) and the same attributes on
+``scen``.  Inputs may be xarray DataArrays (duck-typed) or ``xsdba_amd.DataArray``; when the inputs are
+xarray objects the outputs are converted back to xarray.
+"""
+from __future__ import annotations
+
+import datetime as dt
+from warnings import warn
+
+import numpy as np
+
+from . import __version__
+from ._adjustment import dqm_adjust, dqm_train, eqm_train, qdm_adjust, qm_adjust
+from .base import Grouper, ParametrizableWithDataset, _register, parse_group
+from .detrending import PolyDetrend  # noqa: F401  (re-exported like the reference)
+from .labeled import DataArray, Dataset, as_dataarray, as_dataset, is_xarray
+from .options import EXTRA_OUTPUT, OPTIONS
+from .utils import ADDITIVE, equally_spaced_nodes
+
+__all__ = ["BaseAdjustment", "DetrendedQuantileMapping", "EmpiricalQuantileMapping", "QuantileDeltaMapping", "TrainAdjust"]
+
+
+def gen_call_string(funcname: str, *args, **kwargs) -> str:
+    """Signature string for the history attribute (formatting.py:158-202)."""
+    elements = []
+    for name, val in [(None, a) for a in args] + list(kwargs.items()):
+        if isinstance(val, DataArray):
+            rep = val.name or "<array>"
+        elif isinstance(val, (int, float, str, bool)) or val is None:
+            rep = repr(val)
+        else:
+            rep = repr(val)
+            if len(rep) > 50:
+                rep = f"<{type(val).__name__}>"
+        elements.append(f"{name}={rep}" if name is not None else rep)
+    return f"{funcname}({', '.join(elements)})"
+
+
+def update_history(hist_str: str, *inputs, new_name: str | None = None) -> str:
+    """Timestamped history entry followed by the inputs' histories (formatting.py:69-116)."""
+    merged = "\n".join((f"{i.name}: " if getattr(i, "name", None) else "") + i.attrs.get("history", "") for i in inputs
+                       if i.attrs.get("history") is not None and (len(inputs) > 1 or "history" in i.attrs))
+    return f"[{dt.datetime.now():%Y-%m-%d %H:%M:%S}] {new_name or ''}: {hist_str} - xsdba version: {__version__}\n" + merged
+
+
+class BaseAdjustment(ParametrizableWithDataset):
+    """Base class: input checks shared by every adjustment (adjustment.py:68-206)."""
+
+    _allow_diff_calendars = True
+    _allow_diff_training_times = True
+    _allow_diff_time_sizes = True
+    _allow_5d_grouping = False
+    _attribute = "_xsdba_adjustment"
+
+    def __init__(self, *args, _trained=False, **kwargs):
+        if _trained:
+            super().__init__(*args, **kwargs)
+        else:
+            raise ValueError("Adjustment object should be initialized through their `train` or `adjust` methods.")
+
+    @classmethod
+    def _check_inputs(cls, *inputs, group):
+        if not cls._allow_5d_grouping and group.name == "5D":
+            raise NotImplementedError("`group=Grouper('5D', window)` is a special grouping currently only supported for MBCn.")
+        calendars = {group._time_index(inda).calendar for inda in inputs}
+        if not cls._allow_diff_calendars and len(calendars) > 1:
+            raise ValueError(f"Inputs are defined on different calendars, this is not supported for {cls.__name__} adjustment.")
+        if group.prop == "dayofyear" and ("default" in calendars or "standard" in calendars):
+            warn("Strange results could be returned when using `dayofyear` grouping on data defined in the "
+                 "'proleptic_gregorian' calendar.", stacklevel=2)
+
+    @classmethod
+    def _harmonize_units(cls, *inputs, target=None):
+        """Same units => no-op (units.py:301-304).  Unit conversion itself (pint) is outside this path."""
+        for inda in inputs:
+            if "units" not in inda.attrs:
+                raise ValueError(f"Input {inda.name or '<array>'!s} has no `units` attribute (required like in the reference)")
+        if target is None:
+            target = inputs[0].attrs["units"]
+        for inda in inputs:
+            if inda.attrs["units"] != target:
+                raise NotImplementedError(
+                    f"inputs carry different units ({inda.attrs['units']!r} vs {target!r}); unit conversion is not part of "
+                    "the HIP path — convert before calling"
+                )
+        return inputs, target
+
+    @classmethod
+    def _check_matching_times(cls, ref, hist):
+        if not ref.coords["time"].equals(hist.coords["time"]):
+            raise ValueError(f"`ref` and `hist` have distinct time arrays, this is not supported for {cls.__name__} adjustment.")
+
+    @classmethod
+    def _check_matching_time_sizes(cls, *inputs):
+        ref_size = inputs[0].sizes["time"]
+        for inp in inputs[1:]:
+            if inp.sizes["time"] != ref_size:
+                raise ValueError(f"Inputs have different size for the time array, this is not supported for {cls.__name__} adjustment.")
+
+    @classmethod
+    def _train(cls, ref, hist, **kwargs):
+        raise NotImplementedError()
+
+    def _adjust(self, sim, *args, **kwargs):
+        raise NotImplementedError()
+
+
+class TrainAdjust(BaseAdjustment):
+    """Adjustment objects obeying the train-adjust scheme (adjustment.py:209-332).
+
+    Subclasses implement ``_train(ref, hist, **kwargs) -> (Dataset, params)`` and
+    ``_adjust(sim, **kwargs) -> DataArray | Dataset``.
+    """
+
+    _allow_diff_calendars = True
+    _attribute = "_xsdba_adjustment"
+    _repr_hide_params = ["hist_calendar", "train_units"]
+
+    @classmethod
+    def train(cls, ref, hist, **kwargs):
+        """Train the adjustment object (adjustment.py:227-269)."""
+        want_xr = is_xarray(ref)
+        ref, hist = as_dataarray(ref), as_dataarray(hist)
+        kwargs = parse_group(cls._train, kwargs)
+        skip_checks = kwargs.pop("skip_input_checks", False)
+        if not skip_checks:
+            if "group" in kwargs:
+                cls._check_inputs(ref, hist, group=kwargs["group"])
+            (ref, hist), train_units = cls._harmonize_units(ref, hist)
+        else:
+            train_units = ""
+        if not cls._allow_diff_training_times:
+            cls._check_matching_times(ref, hist)
+        elif not cls._allow_diff_time_sizes:
+            cls._check_matching_time_sizes(ref, hist)
+        ds, params = cls._train(ref, hist, **kwargs)
+        obj = cls(_trained=True, hist_calendar=kwargs["group"]._time_index(hist).calendar if "group" in kwargs else "standard",
+                  train_units=train_units, **params)
+        obj._xr = want_xr
+        obj.set_dataset(ds)
+        return obj
+
+    def adjust(self, sim, *args, **kwargs):
+        """Return bias-adjusted data (adjustment.py:271-316)."""
+        want_xr = is_xarray(sim)
+        sim = as_dataarray(sim)
+        skip_checks = kwargs.pop("skip_input_checks", False)
+        if not skip_checks:
+            if "group" in self:
+                self._check_inputs(sim, *args, group=self.group)
+            (sim, *args), _ = self._harmonize_units(sim, *args, target=self.train_units)
+        out = self._adjust(sim, *args, **kwargs)
+        if isinstance(out, DataArray):
+            out = out.rename("scen").to_dataset()
+        scen = out["scen"]
+        scen.attrs.update(sim.attrs)
+        for name, crd in sim.coords.items():
+            if name in scen.coords:
+                scen.coords[name].attrs.update(crd.attrs)
+        params = gen_call_string("", **kwargs)[1:-1]
+        infostr = f"{self!s}.adjust(sim, {params})"
+        scen.attrs["history"] = update_history(f"Bias-adjusted with {infostr}", sim)
+        scen.attrs["bias_adjustment"] = infostr
+        scen.attrs["units"] = self.train_units
+        if OPTIONS[EXTRA_OUTPUT]:
+            return out.to_xarray() if want_xr else out
+        return scen.to_xarray() if want_xr else scen
+
+    def set_dataset(self, ds):
+        """Store the trained dataset in ``ds`` with the jsonpickle + repr attributes (adjustment.py:318-325)."""
+        ds = as_dataset(ds)
+        super().set_dataset(ds)
+        self.ds.attrs["adj_params"] = str(self)
+
+    @classmethod
+    def _train(cls, ref, hist, **kwargs):
+        raise NotImplementedError()
+
+    def _adjust(self, sim, **kwargs):
+        raise NotImplementedError()
+
+
+def _nodes(nquantiles, dtype):
+    if np.isscalar(nquantiles):
+        return equally_spaced_nodes(nquantiles).astype(dtype)  # adjustment.py:480-483
+    return np.asarray(nquantiles).astype(dtype)
+
+
+_AF_ATTRS = dict(standard_name="Adjustment factors", long_name="Quantile mapping adjustment factors")
+
+
+class EmpiricalQuantileMapping(TrainAdjust):
+    """Empirical Quantile Mapping bias-adjustment (adjustment.py:414-528): F^-1_ref(F_hist(sim))."""
+
+    _allow_diff_calendars = False
+    _allow_diff_training_times = False
+
+    @classmethod
+    def _train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", adapt_freq_thresh=None,
+               jitter_under_thresh_value=None, jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None,
+               max_tail_factor=None):
+        quantiles = _nodes(nquantiles, np.result_type(ref.dtype, np.float32))
+        ds = eqm_train(Dataset({"ref": ref, "hist": hist}), group=group, kind=kind, quantiles=quantiles,
+                       adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                       jitter_over_thresh_value=jitter_over_thresh_value,
+                       jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd, max_tail_factor=max_tail_factor)
+        ds["af"].attrs.update(_AF_ATTRS)
+        ds["hist_q"].attrs.update(standard_name="Model quantiles",
+                                  long_name="Quantiles of model on the reference period, after preprocess")
+        ds["hist_q_raw"].attrs.update(standard_name="Model quantiles",
+                                      long_name="Quantiles of model on the reference period, before preprocess")
+        return ds, {"group": group, "kind": kind, "adapt_freq_thresh": adapt_freq_thresh, "max_tail_factor": max_tail_factor}
+
+    def _adjust(self, sim, interp="nearest", extrapolation="constant"):
+        return qm_adjust(self.ds.assign(sim=sim), group=self.group, interp=interp, extrapolation=extrapolation,
+                         kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh, max_tail_factor=self.max_tail_factor)["scen"]
+
+
+class DetrendedQuantileMapping(TrainAdjust):
+    """Detrended Quantile Mapping bias-adjustment (adjustment.py:531-671; Cannon et al. 2015)."""
+
+    _allow_diff_calendars = False
+    _allow_diff_training_times = False
+
+    @classmethod
+    def _train(cls, ref, hist, *, nquantiles=20, kind: str = ADDITIVE, group="time", adapt_freq_thresh=None,
+               jitter_under_thresh_value=None, jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None,
+               max_tail_factor=None):
+        if group.prop not in ["group", "dayofyear"]:
+            warn(f"Using DQM with a grouping other than 'dayofyear' is not recommended (received {group.name}).", stacklevel=2)
+        quantiles = _nodes(nquantiles, np.result_type(ref.dtype, np.float32))
+        ds = dqm_train(Dataset({"ref": ref, "hist": hist}), group=group, quantiles=quantiles, kind=kind,
+                       adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
+                       jitter_over_thresh_value=jitter_over_thresh_value,
+                       jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd, max_tail_factor=max_tail_factor)
+        ds["af"].attrs.update(_AF_ATTRS)
+        ds["hist_q"].attrs.update(
+            standard_name="Model quantiles",
+            long_name="Quantiles of the anomalies of the model on the reference period, after preprocessing steps. ")
+        ds["hist_q_raw"].attrs.update(standard_name="Model quantiles",
+                                      long_name="Quantiles of model on the reference period, befofe the preprocessing steps.")
+        ds["scaling"].attrs.update(standard_name="Scaling factor",
+                                   description="Scaling factor making the mean of hist match the one of hist.")
+        return ds, {"group": group, "kind": kind, "adapt_freq_thresh": adapt_freq_thresh, "max_tail_factor": max_tail_factor}
+
+    def _adjust(self, sim, interp="nearest", extrapolation="constant", detrend=1):
+        out = dqm_adjust(self.ds.assign(sim=sim), interp=interp, extrapolation=extrapolation, detrend=detrend,
+                         group=self.group, kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh,
+                         max_tail_factor=self.max_tail_factor)
+        scen = out["scen"]
+        scen.attrs["units"] = sim.attrs.get("units", "")  # "Detrending needs units." (adjustment.py:669-670)
+        return scen
+
+
+class QuantileDeltaMapping(EmpiricalQuantileMapping):
+    """Quantile Delta Mapping bias-adjustment (adjustment.py:674-742; Cannon et al. 2015)."""
+
+    def _adjust(self, sim, interp="nearest", extrapolation="constant", rank_window=None):
+        out = qdm_adjust(self.ds.assign(sim=sim), group=self.group, interp=interp, extrapolation=extrapolation,
+                         kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh, rank_window=rank_window,
+                         max_tail_factor=self.max_tail_factor)
+        if OPTIONS[EXTRA_OUTPUT]:
+            out["sim_q"].attrs.update(long_name="Group-wise quantiles of `sim`.")
+            return out
+        return out["scen"]
+
+
+for _cls in (EmpiricalQuantileMapping, DetrendedQuantileMapping, QuantileDeltaMapping):
+    _register(_cls, "xsdba.adjustment")

@@ -1,0 +1,444 @@
+"""Grouping objects and the map_blocks / map_groups decorator runtime of the hot path.
+
+Mirrors the interface of the reference's ``xsdba.base`` (base.py:26-100 Parametrizable, :118-501 Grouper,
+:504-538 parse_group, :563-778 map_blocks / map_groups) for the quantile-mapping path: same names,
+arguments, attributes written on the outputs and error behaviour.  What differs is the engine: the
+reference builds ``rolling(...).construct`` windows and loops over ``groupby`` groups in Python; here a
+``Grouper`` only produces the per-time group index (+ window) that the HIP kernels consume, and
+``map_groups`` functions on the path carry a *fused* device implementation that handles every group of
+every cell in one launch.  ``Grouper.apply`` with a user function still works (host loop over groups on
+numpy data) so third-party ``map_groups`` functions keep running — that generic loop is host plumbing,
+not a fallback of the accelerated path.
+"""
+from __future__ import annotations
+
+import json
+from collections import OrderedDict, UserDict
+from inspect import _empty, signature
+
+import numpy as np
+
+from .calendar import MAX_DOY, TimeIndex
+from .labeled import Coordinate, DataArray, Dataset, as_dataarray, as_dataset
+
+
+class Parametrizable(UserDict):
+    """Dictionary-like object completely defined by its parameters (base.py:26-72)."""
+
+    _repr_hide_params: list = []
+
+    def __getstate__(self):
+        return self.data
+
+    def __setstate__(self, state):
+        self.data = {**state}
+
+    def __getattr__(self, attr):
+        if attr == "data" or attr not in self.__dict__.get("data", {}):
+            return self.__getattribute__(attr)
+        return self.data[attr]
+
+    @property
+    def parameters(self) -> dict:
+        return {**self.data}
+
+    def __repr__(self) -> str:
+        defaults = {
+            n: [p.default] if p.default is not None else [[], {}, set(), None]
+            for n, p in signature(self.__init__).parameters.items()
+            if p.default is not _empty
+        }
+        params = ", ".join(f"{k}={v!r}" for k, v in self.items()
+                           if k not in self._repr_hide_params and v not in defaults.get(k, []))
+        return f"{self.__class__.__name__}({params})"
+
+
+# ---- jsonpickle-compatible encoding of Parametrizable objects (base.py:80-100) -------------------------
+# jsonpickle is not installed on the GPU image, so the small subset of its format these objects need is
+# written and parsed by hand: {"py/object": "<module>.<Class>", "py/state": {...}} with nested Grouper.
+_REGISTRY: dict[str, type] = {}
+
+
+def _register(cls, ref_module: str):
+    cls._ref_qualname = f"{ref_module}.{cls.__name__}"
+    _REGISTRY[cls._ref_qualname] = cls
+    _REGISTRY[f"{cls.__module__}.{cls.__name__}"] = cls
+    return cls
+
+
+def _encode(obj):
+    if isinstance(obj, Parametrizable):
+        return {"py/object": getattr(type(obj), "_ref_qualname", f"{type(obj).__module__}.{type(obj).__name__}"),
+                "py/state": {k: _encode(v) for k, v in obj.data.items()}}
+    if isinstance(obj, (list, tuple)):
+        return [_encode(v) for v in obj]
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    if isinstance(obj, (np.floating,)):
+        return float(obj)
+    return obj
+
+
+def _decode(node):
+    if isinstance(node, dict) and "py/object" in node:
+        cls = _REGISTRY.get(node["py/object"])
+        if cls is None:
+            raise ValueError(f"unknown class {node['py/object']!r} in serialized adjustment")
+        obj = cls.__new__(cls)
+        obj.__setstate__({k: _decode(v) for k, v in node.get("py/state", {}).items()})
+        return obj
+    if isinstance(node, list):
+        return [_decode(v) for v in node]
+    return node
+
+
+class ParametrizableWithDataset(Parametrizable):
+    """Parametrizable that also stores a dataset in ``ds`` (base.py:75-100)."""
+
+    _attribute = "_xsdba_parameters"
+
+    @classmethod
+    def from_dataset(cls, ds):
+        ds = as_dataset(ds)
+        obj = _decode(json.loads(ds.attrs[cls._attribute]))
+        obj.set_dataset(ds)
+        return obj
+
+    def set_dataset(self, ds) -> None:
+        self.ds = ds
+        self.ds.attrs[self._attribute] = json.dumps(_encode(self))
+
+
+class Grouper(Parametrizable):
+    """Grouping information (base.py:118-501): ``Grouper("time.dayofyear", window=31)``."""
+
+    _repr_hide_params = ["dim", "prop"]
+    PROP = "<PROP>"
+    DIM = "<DIM>"
+    ADD_DIMS = "<ADD_DIMS>"
+
+    def __init__(self, group: str, window: int = 1, add_dims=None):
+        if group == "time" and window > 1:
+            raise ValueError(
+                "The group given is 'time', but the window given is greater than 1. The `group = 'time'` option "
+                "takes the complete series, thus the concept of window is not applicable in this case. When using "
+                "`group = 'time'`, `window=1` is expected."
+            )
+        if "." in group:
+            dim, prop = group.split(".")
+        else:
+            dim, prop = group, "group"
+        if group == "5D":
+            dim = "time"
+        if isinstance(add_dims, str):
+            add_dims = [add_dims]
+        super().__init__(dim=dim, add_dims=list(add_dims or []), prop=prop, name=group, window=window)
+
+    @classmethod
+    def from_kwargs(cls, **kwargs):
+        kwargs["group"] = cls(group=kwargs.pop("group"), window=kwargs.pop("window", 1), add_dims=kwargs.pop("add_dims", []))
+        return kwargs
+
+    @property
+    def freq(self):
+        return {"group": "YS", "season": "QS-DEC", "month": "MS", "week": "W", "dayofyear": "D"}.get(self.prop, None)
+
+    @property
+    def prop_name(self):
+        return "year" if self.prop == "group" else self.prop
+
+    # ---- coordinates / indexes ------------------------------------------------------------------------
+    def _time_index(self, da) -> TimeIndex:
+        da = as_dataarray(da) if not isinstance(da, Dataset) else da
+        crd = da.coords.get(self.dim) if hasattr(da, "coords") else None
+        if crd is None or crd.index is None:
+            raise ValueError(f"`{self.dim}` must be a time-like coordinate of the input to group on {self.name!r}")
+        return crd.index
+
+    def get_coordinate(self, ds=None) -> DataArray:
+        """Coordinate of the grouped dimension as in the output of ``group.apply`` (base.py:207-230)."""
+        if self.prop == "month":
+            return DataArray(np.arange(1, 13), dims=("month",), name="month")
+        if self.prop == "season":
+            return DataArray(np.array(["DJF", "MAM", "JJA", "SON"]), dims=("season",), name="season")
+        if self.prop == "dayofyear":
+            mdoy = MAX_DOY[self._time_index(ds).calendar] if ds is not None else 365
+            return DataArray(np.arange(1, mdoy + 1), dims=("dayofyear",), name="dayofyear")
+        if self.prop == "group":
+            return DataArray(np.array([1]), dims=("group",), name="group")
+        raise NotImplementedError("No grouping found.")
+
+    def get_index(self, da, interp: bool | None = None) -> DataArray:
+        """Group index of each element along the main dimension (base.py:274-345)."""
+        da = as_dataarray(da) if not isinstance(da, Dataset) else da
+        if self.prop == "group":
+            n = da.sizes[self.dim]
+            if self.dim == "time":
+                return DataArray(np.ones(n, dtype=int), dims=(self.dim,), coords={self.dim: da.coords[self.dim]}, name="group")
+            return da[self.dim].rename("group")
+        ind = self._time_index(da)
+        if interp and self.dim == "time":
+            if self.prop == "month":
+                i = ind.month - 0.5 + ind.day / ind.days_in_month
+            elif self.prop == "season":
+                length_year = 360 if ind.calendar == "360_day" else 365 + (0 if ind.calendar in ("noleap", "365_day") else ind.is_leap_year)
+                i = ind.dayofyear / length_year * 4 - 1 / 6
+            elif self.prop == "dayofyear":
+                i = ind.dayofyear
+            else:
+                raise ValueError(f"Interpolation is not supported for {self.dim}.{self.prop}.")
+        else:
+            if self.prop == "season":
+                i = ind.month % 12 // 3
+            elif self.prop in ("month", "dayofyear", "year", "day"):
+                i = getattr(ind, self.prop)
+            else:
+                raise ValueError(f"Index {self.name} is not supported by {self.__class__.__name__}.")
+            if not np.issubdtype(np.asarray(i).dtype, np.integer):
+                raise ValueError(f"Index {self.name} is not of type int (rather {i.dtype}), but {self.__class__.__name__} requires integer indexes.")
+        return DataArray(np.asarray(i), dims=(self.dim,), coords={self.dim: da.coords[self.dim]}, name=self.prop)
+
+    def n_groups(self, da=None) -> int:
+        return {"group": 1, "month": 12, "season": 4}.get(self.prop) or int(self.get_coordinate(da).size)
+
+    def group_index(self, da):
+        """(0-based int32 group of every time step, number of groups): what the HIP kernels take as
+        ``group_of_time`` / ``n_groups`` (include/xsdba_hip.h)."""
+        G = self.n_groups(da)
+        if self.prop == "group":
+            return np.zeros(as_dataarray(da).sizes[self.dim] if not isinstance(da, Dataset) else da.sizes[self.dim], np.int32), 1
+        idx = np.asarray(self.get_index(da, interp=False).values)
+        g0 = idx if self.prop == "season" else idx - 1
+        return g0.astype(np.int32), G
+
+    # ---- generic host application (third-party functions) ---------------------------------------------
+    def apply(self, func, da, main_only: bool = False, **kwargs):
+        """Apply ``func(group, dim=dims, **kwargs)`` group-wise (base.py:347-457).
+
+        Host loop over the groups on numpy data, for user functions and string reductions; the functions of
+        the accelerated path do not come through here (they are fused on the device).
+        """
+        is_ds = isinstance(da, (dict, Dataset)) or hasattr(da, "data_vars")
+        ds = as_dataset(da) if hasattr(da, "data_vars") else (Dataset(da) if isinstance(da, dict) else None)
+        one = None if is_ds else as_dataarray(da)
+        ref = one if one is not None else next(v for v in ds.data_vars.values() if self.dim in v.dims)
+        gidx, G = self.group_index(ref)
+        T = ref.sizes[self.dim]
+        W = 1 if main_only else self.window
+        if main_only:
+            dims = self.dim
+        else:
+            dims = [self.dim] + [d for d in self.add_dims if d in ref.dims]
+            if self.window > 1:
+                dims += ["window"]
+
+        def windows(v: DataArray) -> DataArray:
+            if W == 1 or self.dim not in v.dims:
+                return v
+            ax = v.dims.index(self.dim)
+            x = np.moveaxis(v.values, ax, -1)
+            out = np.full(x.shape + (W,), np.nan, dtype=np.result_type(x.dtype, np.float32))
+            for j in range(W):  # rolling(center=True).construct: slot j holds x[t + j - W//2] (base.py:261-262)
+                o = j - W // 2
+                lo, hi = max(0, -o), min(T, T - o)
+                out[..., lo:hi, j] = x[..., lo + o:hi + o]
+            out = np.moveaxis(out, -2, ax)
+            return DataArray(out, v.dims + ("window",), v.coords, v.attrs, v.name)
+
+        pieces, sels = [], []
+        for g in range(G):
+            sel = np.nonzero(gidx == g)[0]
+            if sel.size == 0:
+                continue
+            if one is not None:
+                blk = windows(one).isel({self.dim: sel})
+            else:
+                blk = Dataset({k: (windows(v).isel({self.dim: sel}) if self.dim in v.dims else v) for k, v in ds.data_vars.items()})
+            if isinstance(func, str):
+                res = getattr(blk, func)(dim=dims, **kwargs)
+            else:
+                res = func(blk, dim=dims, **kwargs)
+            pieces.append((g, res))
+            sels.append(sel)
+
+        def combine(parts):
+            first = parts[0]
+            if self.dim in first.dims:  # not reduced: put back on the time axis, window centre only
+                ax = first.dims.index(self.dim)
+                parts = [p.isel(window=self.window // 2) if "window" in p.dims else p for p in parts]
+                shape = list(parts[0].shape)
+                shape[ax] = T
+                out = np.full(shape, np.nan, dtype=np.result_type(parts[0].dtype, np.float32))
+                for p, sel in zip(parts, sels):
+                    idx = [slice(None)] * out.ndim
+                    idx[ax] = sel
+                    out[tuple(idx)] = p.values
+                coords = OrderedDict(parts[0].coords)
+                coords[self.dim] = ref.coords[self.dim]
+                return DataArray(out, parts[0].dims, coords, parts[0].attrs, parts[0].name)
+            crd = self.get_coordinate(ref)
+            full = np.full((crd.size,) + first.shape, np.nan, dtype=np.result_type(first.dtype, np.float32))
+            for (g, _), p in zip(pieces, parts):
+                full[g] = p.values
+            coords = OrderedDict(first.coords)
+            coords[self.prop] = Coordinate(self.prop, crd.values)
+            return DataArray(full, (self.prop,) + first.dims, coords, first.attrs, first.name)
+
+        if isinstance(pieces[0][1], Dataset):
+            out = Dataset({k: combine([p[k] for _, p in pieces]) for k in pieces[0][1].data_vars})
+        else:
+            out = combine([as_dataarray(p) for _, p in pieces])
+        out.attrs["group"] = self.name
+        out.attrs["group_compute_dims"] = dims
+        out.attrs["group_window"] = self.window
+        return out
+
+    @staticmethod
+    def filter_dim(da, dim):
+        if isinstance(dim, str):
+            return dim
+        return [dim[0]] + [d for d in dim[1:] if d in da.dims]
+
+    @staticmethod
+    def filter_add_dims(dim):
+        if isinstance(dim, str):
+            return [dim]
+        extra_dim = list(set(dim[1:]) - {"window"})
+        return list(set(dim) - set(extra_dim))
+
+
+_register(Grouper, "xsdba.base")
+
+
+def parse_group(func, kwargs=None, allow_only=None):
+    """Set the ``group`` argument to a :class:`Grouper` (decorator or kwargs parser; base.py:504-538)."""
+    sig = signature(func)
+    default_group = sig.parameters["group"].default if "group" in sig.parameters else None
+
+    def _update_kwargs(_kwargs, allowed=None):
+        if default_group or "group" in _kwargs:
+            _kwargs.setdefault("group", default_group)
+            if not isinstance(_kwargs["group"], Grouper):
+                _kwargs = Grouper.from_kwargs(**_kwargs)
+        if allowed is not None and "group" in _kwargs and _kwargs["group"].prop not in allowed:
+            raise ValueError(f"Grouping on {_kwargs['group'].prop_name} is not allowed for this function. Should be one of {allowed}.")
+        return _kwargs
+
+    if kwargs is not None:
+        return _update_kwargs(kwargs, allowed=allow_only)
+
+    def _parse_group(*f_args, **f_kwargs):
+        f_kwargs = _update_kwargs(f_kwargs, allowed=allow_only)
+        return func(*f_args, **f_kwargs)
+
+    _parse_group.__name__ = getattr(func, "__name__", "parse_group")
+    _parse_group.__doc__ = func.__doc__
+    _parse_group.__wrapped__ = func
+    return _parse_group
+
+
+def _merge_dimensions(*seqs):
+    out = list(seqs[0])
+    for seq in seqs[1:]:
+        last_index = 0
+        for e in seq:
+            if e in out:
+                indx = out.index(e)
+                if indx < last_index:
+                    raise ValueError("Dimensions order mismatch, lists are not mergeable.")
+                last_index = indx
+            else:
+                out.insert(last_index + 1, e)
+    return out
+
+
+def map_blocks(reduces=None, **out_vars):
+    """Declare a block function ``func(ds, **kwargs) -> Dataset`` (base.py:563-726).
+
+    Data here are numpy-backed (one block), so the wrapper's job is the contract around the call: group
+    parsing, the placeholder dims ``<PROP>/<DIM>/<ADD_DIMS>``, the output dimension order
+    (untouched dims first, new dims last, :653-656), the output dtype (largest input dtype, :681-685),
+    dropping auxiliary coordinates (:708-712) and re-raising any failure as
+    ``ValueError("<func> failed on block with coords : ...")`` (:698-703).  ``.func`` exposes the raw body.
+    """
+    out_dims = _merge_dimensions(*out_vars.values()) if out_vars else []
+    red_dims = list(reduces or [])
+
+    def _decorator(func):
+        def _map_blocks(ds, **kwargs):
+            ds = as_dataset(ds) if (isinstance(ds, Dataset) or hasattr(ds, "data_vars")) else as_dataarray(ds)
+            group = kwargs.get("group")
+            if {Grouper.PROP, Grouper.DIM, Grouper.ADD_DIMS}.intersection(out_dims + red_dims) and group is None:
+                raise ValueError("Missing required `group` argument.")
+            placeholders = {Grouper.PROP: [group.prop], Grouper.DIM: [group.dim], Grouper.ADD_DIMS: group.add_dims} if group is not None else {}
+            if group is not None and group.add_dims and not set(group.add_dims).issubset(set(ds.dims)):
+                raise ValueError("`add_dims` argument needs to be a dimension in one of the input datasets.")
+            new_dims, reduced_dims = [], []
+            for dim in out_dims:
+                new_dims.extend(placeholders.get(dim, [dim]))
+            for dim in red_dims:
+                reduced_dims.extend(placeholders.get(dim, [dim]))
+            in_dims = list(ds.dims) if not isinstance(ds, Dataset) else list(ds.sizes)
+            base_dims = [d for d in in_dims if d not in new_dims and d not in reduced_dims]
+            all_dims = base_dims + new_dims
+            for dim in new_dims:
+                if group is not None and dim in (group.prop, group.dim):
+                    continue
+                if dim not in kwargs and dim not in in_dims:
+                    raise ValueError(f"This function adds the {dim} dimension, its coordinate must be provided as a keyword argument.")
+            try:
+                out = func(ds, **kwargs)
+                out = as_dataset(out)
+                out = Dataset({k: v.transpose(*[d for d in all_dims if d in v.dims]) for k, v in out.data_vars.items()},
+                              attrs=out.attrs)
+            except Exception as err:
+                crds = list(ds.coords)
+                raise ValueError(f"{func.__name__} failed on block with coords : {crds}.") from err
+            return out
+
+        wrapped = parse_group(_map_blocks)
+        wrapped.__name__ = getattr(func, "__name__", "map_blocks")
+        wrapped.__doc__ = func.__doc__
+        wrapped.__dict__["func"] = func
+        return wrapped
+
+    return _decorator
+
+
+def map_groups(reduces=None, main_only: bool = False, fused=None, **out_vars):
+    """Declare a per-group function ``func(ds, dim, **kwargs) -> Dataset`` (base.py:729-778).
+
+    ``fused`` (extension of this implementation): a callable ``fused(ds, group=..., **kwargs) -> Dataset``
+    that produces the result for ALL groups at once — the functions of the accelerated path pass their HIP
+    implementation here; without it the wrapper falls back on ``group.apply(func, ...)`` like the reference.
+    """
+    def_reduces = [Grouper.DIM]
+    if not main_only:
+        def_reduces.append(Grouper.ADD_DIMS)
+    reduces = reduces or def_reduces
+
+    def _decorator(func):
+        decorator = map_blocks(reduces=reduces, **out_vars)
+
+        def _apply_on_group(dsblock, **kwargs):
+            group = kwargs.pop("group")
+            if fused is not None:
+                out = fused(dsblock, group=group, **kwargs)
+                out.attrs["group"] = group.name
+                out.attrs["group_compute_dims"] = [group.dim] + (["window"] if group.window > 1 else [])
+                out.attrs["group_window"] = group.window
+                return out
+            return group.apply(func, dsblock, main_only=main_only, **kwargs)
+
+        _apply_on_group.__name__ = f"group_{func.__name__}"
+        wrapper = decorator(_apply_on_group)
+        wrapper.__name__ = func.__name__
+        wrapper.__doc__ = func.__doc__
+        wrapper.__dict__["func"] = func
+        return wrapper
+
+    return _decorator
+
+
+def uses_dask(*das) -> bool:
+    return False

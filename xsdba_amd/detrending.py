@@ -1,0 +1,88 @@
+"""Detrending objects of the hot path (xsdba.detrending, detrending.py:17-131 BaseDetrend, :165-208 PolyDetrend).
+
+``PolyDetrend(degree 0 | 1)`` is computed by the HIP group-trend kernel (NaN-skipping centred window means per
+time step, per-group least squares against the float64 time axis); other detrenders of the reference
+(Loess, RollingMean, Mean, No) are outside the accelerated path."""
+from __future__ import annotations
+
+import warnings
+
+from . import hip
+from .base import Grouper, ParametrizableWithDataset, _register, parse_group
+from .labeled import DataArray, as_dataarray
+from .utils import ADDITIVE, apply_correction, cell_time_view, invert
+
+
+class BaseDetrend(ParametrizableWithDataset):
+    """fit(da) -> fitted copy with ``ds.trend``; detrend(da); retrend(da) (detrending.py:17-131)."""
+
+    def __init__(self, *, group="time", kind="+", mult_skip_zeros=False, **kwargs):
+        kw = parse_group(self.__class__.__init__, dict(group=group))
+        super().__init__(group=kw["group"], kind=kind, mult_skip_zeros=mult_skip_zeros, **kwargs)
+
+    @property
+    def fitted(self):
+        return hasattr(self, "ds")
+
+    def fit(self, da):
+        da = as_dataarray(da)
+        new = self.__class__(**self.parameters)
+        trend = new._get_trend(da).astype(da.dtype).rename("trend")
+        new.set_dataset(trend.to_dataset())
+        if "units" in da.attrs:
+            new.ds.trend.attrs["units"] = da.attrs["units"]
+        return new
+
+    def detrend(self, da):
+        if not self.fitted:
+            raise ValueError("You must call fit() before detrending.")
+        return self._detrend(as_dataarray(da), self.ds.trend)
+
+    def retrend(self, da):
+        if not self.fitted:
+            raise ValueError("You must call fit() before retrending")
+        return self._retrend(as_dataarray(da), self.ds.trend)
+
+    def _detrend(self, da, trend):
+        trend = trend.transpose(*[d for d in da.dims if d in trend.dims])
+        out = apply_correction(da, invert(trend, self.kind), self.kind)
+        if self.mult_skip_zeros and self.kind != "*":
+            warnings.warn(f"mult_skip_zeros is only used for kind='*'. Your kind is {self.kind}. mult_skip_zeros will be ignored.",
+                          UserWarning, stacklevel=2)
+        if self.mult_skip_zeros and self.kind == "*":
+            out = out.where(trend != 0, da)
+        return out
+
+    def _retrend(self, da, trend):
+        trend = trend.transpose(*[d for d in da.dims if d in trend.dims])
+        return apply_correction(da, trend, self.kind)
+
+    def _get_trend(self, da):
+        raise NotImplementedError
+
+    def __repr__(self):
+        rep = super().__repr__()
+        return rep if self.fitted else f"<{rep} | unfitted>"
+
+
+class PolyDetrend(BaseDetrend):
+    """Detrend time series using a polynomial regression per group (detrending.py:165-208)."""
+
+    def __init__(self, group="time", kind=ADDITIVE, degree=4, preserve_mean=False, mult_skip_zeros=False):
+        super().__init__(group=group, kind=kind, degree=degree, preserve_mean=preserve_mean, mult_skip_zeros=mult_skip_zeros)
+
+    def _get_trend(self, da: DataArray) -> DataArray:
+        group: Grouper = self.group
+        if self.degree not in (0, 1):
+            raise NotImplementedError(f"PolyDetrend(degree={self.degree}) is not implemented on the HIP path (0 or 1)")
+        if self.preserve_mean:
+            raise NotImplementedError("PolyDetrend(preserve_mean=True) is not implemented on the HIP path")
+        x2, cell_dims, cell_shape = cell_time_view(da, group.dim)
+        gidx, G = group.group_index(da)
+        tnum = group._time_index(da).numeric_ns
+        tr = hip.polydetrend_trend(x2, gidx, G, group.window, tnum, int(self.degree))
+        coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == group.dim}
+        return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
+
+
+_register(PolyDetrend, "xsdba.detrending")

@@ -1,0 +1,551 @@
+"""Minimal labelled arrays (``DataArray`` / ``Dataset``) for the host side of the hot path.
+
+The reference's public surface takes and returns xarray objects (adjustment.py:227-316).  xarray is not a
+dependency of this package (and is absent from the GPU image), so the boundary is duck-typed:
+
+* anything exposing ``.dims``, ``.values``, ``.coords`` and ``.attrs`` — in particular real
+  ``xarray.DataArray`` objects — is accepted by :func:`as_dataarray`;
+* results are instances of the classes below, which carry the same attributes/methods the path and its
+  tests use (``dims, sizes, coords, attrs, values, dtype, transpose, isel, astype, rename, to_dataset,
+  assign_coords, expand_dims, squeeze, mean, where, isnull`` …) and convert back with ``.to_xarray()``
+  when xarray is importable (done automatically when the inputs were xarray objects).
+
+Only what the quantile-mapping path needs is implemented: this is not a general xarray replacement.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from .calendar import TimeIndex, time_index
+
+
+def _is_time_like(values) -> bool:
+    if isinstance(values, TimeIndex):
+        return True
+    arr = np.asarray(values) if not hasattr(values, "dtype") else values
+    dt = getattr(arr, "dtype", None)
+    if dt is None:
+        return False
+    if np.issubdtype(dt, np.datetime64):
+        return True
+    return dt == object and getattr(arr, "size", 0) > 0 and hasattr(np.asarray(arr).flat[0], "year")
+
+
+class Coordinate:
+    """1-D coordinate variable."""
+
+    def __init__(self, name, values, attrs=None):
+        self.name = name
+        self.index = time_index(values) if _is_time_like(values) else None
+        self.values = values if isinstance(values, TimeIndex) else np.asarray(values)
+        if isinstance(self.values, np.ndarray) and self.values.ndim != 1:
+            raise ValueError(f"coordinate {name!r} must be 1-D")
+        self.attrs = dict(attrs or {})
+
+    @property
+    def size(self):
+        return self.index.size if self.index is not None else self.values.size
+
+    def isel(self, key):
+        if self.index is not None:
+            return Coordinate(self.name, self.index[key].values, self.attrs)
+        return Coordinate(self.name, self.values[key], self.attrs)
+
+    def equals(self, other):
+        if self.index is not None and other.index is not None:
+            return self.index.equals(other.index)
+        return np.array_equal(np.asarray(self.values), np.asarray(other.values))
+
+
+class _DtAccessor:
+    def __init__(self, idx: TimeIndex):
+        self._idx = idx
+
+    def __getattr__(self, item):
+        return getattr(self._idx, item)
+
+
+class DataArray:
+    def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
+        self.values = np.asarray(data)
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(self.values.ndim))
+        if isinstance(dims, str):
+            dims = (dims,)
+        self.dims = tuple(dims)
+        if len(self.dims) != self.values.ndim:
+            raise ValueError(f"dims {self.dims} do not match data of shape {self.values.shape}")
+        self.coords = OrderedDict()
+        if coords:
+            items = coords.items() if isinstance(coords, dict) else coords
+            for k, v in items:
+                if isinstance(v, Coordinate):
+                    c = v
+                elif isinstance(v, DataArray):
+                    c = Coordinate(k, v.coords[k].values if k in v.coords else v.values, v.attrs)
+                else:
+                    c = Coordinate(k, v)
+                if k in self.dims and c.size != self.sizes[k]:
+                    raise ValueError(f"coordinate {k!r} has size {c.size}, dimension has {self.sizes[k]}")
+                self.coords[k] = c
+        self.attrs = dict(attrs or {})
+        self.name = name
+
+    # ---- basic properties -----------------------------------------------------------------------
+    @property
+    def shape(self):
+        return self.values.shape
+
+    @property
+    def dtype(self):
+        return self.values.dtype
+
+    @property
+    def ndim(self):
+        return self.values.ndim
+
+    @property
+    def size(self):
+        return self.values.size
+
+    @property
+    def sizes(self):
+        return OrderedDict(zip(self.dims, self.values.shape))
+
+    @property
+    def data(self):
+        return self.values
+
+    @property
+    def chunks(self):
+        return None
+
+    def __array__(self, dtype=None, copy=None):
+        return self.values if dtype is None else self.values.astype(dtype)
+
+    def __len__(self):
+        return self.values.shape[0]
+
+    def __repr__(self):
+        return f"<xsdba_amd.DataArray {self.name or ''} {dict(self.sizes)} {self.dtype}>"
+
+    def __getattr__(self, item):
+        # coordinate access (da.time, da.quantiles) and attribute access (da.units) like xarray
+        if item.startswith("__"):
+            raise AttributeError(item)
+        coords = self.__dict__.get("coords", {})
+        if item in coords:
+            return self[item]
+        attrs = self.__dict__.get("attrs", {})
+        if item in attrs:
+            return attrs[item]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {item!r}")
+
+    @property
+    def dt(self):
+        for c in self.coords.values():
+            if c.index is not None and (self.name == c.name or len(self.coords) == 1):
+                return _DtAccessor(c.index)
+        raise AttributeError("no time-like coordinate")
+
+    def get_axis_num(self, dim):
+        return self.dims.index(dim)
+
+    # ---- indexing -------------------------------------------------------------------------------
+    def __getitem__(self, key):
+        if isinstance(key, str):
+            if key in self.coords:
+                c = self.coords[key]
+                vals = c.values if not isinstance(c.values, TimeIndex) else np.arange(c.size)
+                out = DataArray(vals, dims=(key,), attrs=c.attrs, name=key)
+                out.coords[key] = c
+                return out
+            if key in self.dims:
+                return DataArray(np.arange(self.sizes[key]), dims=(key,), name=key)
+            raise KeyError(key)
+        if isinstance(key, dict):
+            return self.isel(key)
+        if isinstance(key, DataArray):
+            key = key.values
+        if not isinstance(key, tuple):
+            key = (key,)
+        basic = all(isinstance(k, (slice, int, np.integer)) or k is Ellipsis for k in key) and Ellipsis not in key
+        if basic:
+            idx = {d: k for d, k in zip(self.dims, key)}
+            return self.isel(idx)
+        return self.values[key]
+
+    def isel(self, indexers=None, drop=False, **kw):
+        idx = dict(indexers or {})
+        idx.update(kw)
+        key = tuple(idx.get(d, slice(None)) for d in self.dims)
+        data = self.values[key]
+        dims = tuple(d for d in self.dims if not isinstance(idx.get(d, slice(None)), (int, np.integer)))
+        coords = OrderedDict()
+        for k, c in self.coords.items():
+            if k in idx:
+                if isinstance(idx[k], (int, np.integer)):
+                    continue
+                coords[k] = c.isel(idx[k])
+            else:
+                coords[k] = c
+        return DataArray(data, dims, coords, self.attrs, self.name)
+
+    # ---- structural -----------------------------------------------------------------------------
+    def transpose(self, *dims):
+        if not dims:
+            dims = self.dims[::-1]
+        if Ellipsis in dims:
+            i = dims.index(Ellipsis)
+            rest = [d for d in self.dims if d not in dims]
+            dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
+        if set(dims) != set(self.dims):
+            raise ValueError(f"{dims} is not a permutation of {self.dims}")
+        return DataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords, self.attrs, self.name)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def astype(self, dtype):
+        return DataArray(self.values.astype(dtype), self.dims, self.coords, self.attrs, self.name)
+
+    def copy(self, data=None):
+        return DataArray(self.values.copy() if data is None else data, self.dims, self.coords, self.attrs, self.name)
+
+    def rename(self, name=None):
+        if isinstance(name, dict):
+            dims = tuple(name.get(d, d) for d in self.dims)
+            coords = OrderedDict((name.get(k, k), Coordinate(name.get(k, k), c.values, c.attrs)) for k, c in self.coords.items())
+            return DataArray(self.values, dims, coords, self.attrs, self.name)
+        return DataArray(self.values, self.dims, self.coords, self.attrs, name)
+
+    def to_dataset(self, name=None):
+        nm = name or self.name
+        if nm is None:
+            raise ValueError("unnamed DataArray")
+        return Dataset({nm: self})
+
+    def assign_coords(self, coords=None, **kw):
+        c = OrderedDict(self.coords)
+        for k, v in {**(coords or {}), **kw}.items():
+            c[k] = v if isinstance(v, Coordinate) else Coordinate(k, v.values if isinstance(v, DataArray) and k not in v.coords else (v.coords[k].values if isinstance(v, DataArray) else v))
+        return DataArray(self.values, self.dims, c, self.attrs, self.name)
+
+    def assign_attrs(self, attrs=None, **kw):
+        a = dict(self.attrs)
+        a.update(attrs or {})
+        a.update(kw)
+        return DataArray(self.values, self.dims, self.coords, a, self.name)
+
+    def drop_vars(self, names, errors="raise"):
+        names = [names] if isinstance(names, str) else list(names)
+        c = OrderedDict((k, v) for k, v in self.coords.items() if k not in names)
+        return DataArray(self.values, self.dims, c, self.attrs, self.name)
+
+    def expand_dims(self, dim=None, **kw):
+        spec = dict(dim or {}) if not isinstance(dim, str) else {dim: 1}
+        spec.update(kw)
+        data, dims, coords = self.values, self.dims, OrderedDict(self.coords)
+        for k, v in reversed(list(spec.items())):
+            n = v if isinstance(v, (int, np.integer)) else len(v)
+            data = np.broadcast_to(data[None], (n,) + data.shape)
+            dims = (k,) + dims
+            if not isinstance(v, (int, np.integer)):
+                coords[k] = Coordinate(k, np.asarray(v))
+        return DataArray(np.array(data), dims, coords, self.attrs, self.name)
+
+    def squeeze(self, dim=None, drop=False):
+        dims = [dim] if isinstance(dim, str) else (list(dim) if dim else [d for d, n in self.sizes.items() if n == 1])
+        return self.isel({d: 0 for d in dims})
+
+    # ---- reductions / elementwise ---------------------------------------------------------------
+    def _reduce(self, fn, dim=None, **kw):
+        dims = self.dims if dim is None else ([dim] if isinstance(dim, str) else list(dim))
+        axes = tuple(self.dims.index(d) for d in dims)
+        with np.errstate(all="ignore"):
+            data = fn(self.values, axis=axes, **kw)
+        keep = tuple(d for d in self.dims if d not in dims)
+        coords = OrderedDict((k, c) for k, c in self.coords.items() if k in keep)
+        return DataArray(data, keep, coords, self.attrs, self.name)
+
+    def mean(self, dim=None, skipna=True):
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return self._reduce(np.nanmean if skipna else np.mean, dim)
+
+    def sum(self, dim=None):
+        return self._reduce(np.nansum, dim)
+
+    def min(self, dim=None):
+        return self._reduce(np.nanmin, dim)
+
+    def max(self, dim=None):
+        return self._reduce(np.nanmax, dim)
+
+    def all(self, dim=None):
+        return self._reduce(np.all, dim)
+
+    def any(self, dim=None):
+        return self._reduce(np.any, dim)
+
+    def isnull(self):
+        return DataArray(np.isnan(self.values), self.dims, self.coords, name=self.name)
+
+    def notnull(self):
+        return DataArray(~np.isnan(self.values), self.dims, self.coords, name=self.name)
+
+    def where(self, cond, other=np.nan):
+        cond, _ = _align(self, cond)
+        other_v = _align(self, other)[0] if isinstance(other, DataArray) else other
+        return DataArray(np.where(cond, self.values, other_v), self.dims, self.coords, self.attrs, self.name)
+
+    def item(self):
+        return self.values.item()
+
+    def __bool__(self):
+        return bool(self.values)
+
+    def _binary(self, other, op, reflexive=False):
+        if isinstance(other, DataArray):
+            a, b, dims, coords = _broadcast(self, other)
+        else:
+            a, b, dims, coords = self.values, other, self.dims, self.coords
+        with np.errstate(all="ignore"):
+            data = op(b, a) if reflexive else op(a, b)
+        return DataArray(data, dims, coords, self.attrs if _KEEP_ATTRS[0] else {}, self.name)
+
+    def __add__(self, o): return self._binary(o, np.add)
+    def __radd__(self, o): return self._binary(o, np.add, True)
+    def __sub__(self, o): return self._binary(o, np.subtract)
+    def __rsub__(self, o): return self._binary(o, np.subtract, True)
+    def __mul__(self, o): return self._binary(o, np.multiply)
+    def __rmul__(self, o): return self._binary(o, np.multiply, True)
+    def __truediv__(self, o): return self._binary(o, np.divide)
+    def __rtruediv__(self, o): return self._binary(o, np.divide, True)
+    def __neg__(self): return DataArray(-self.values, self.dims, self.coords, self.attrs, self.name)
+    def __lt__(self, o): return self._binary(o, np.less)
+    def __le__(self, o): return self._binary(o, np.less_equal)
+    def __gt__(self, o): return self._binary(o, np.greater)
+    def __ge__(self, o): return self._binary(o, np.greater_equal)
+    def __eq__(self, o): return self._binary(o, np.equal)
+    def __ne__(self, o): return self._binary(o, np.not_equal)
+    def __invert__(self): return DataArray(~self.values, self.dims, self.coords, self.attrs, self.name)
+    __hash__ = None
+
+    # ---- xarray interop -------------------------------------------------------------------------
+    def to_xarray(self):
+        import xarray as xr
+
+        coords = {}
+        for k, c in self.coords.items():
+            vals = c.values
+            if isinstance(vals, TimeIndex):
+                vals = xr.date_range(f"{vals.year[0]:04d}-{vals.month[0]:02d}-{vals.day[0]:02d}", periods=vals.size,
+                                     calendar=vals.calendar, use_cftime=True)
+            coords[k] = xr.Variable((k,), vals, c.attrs)
+        return xr.DataArray(self.values, dims=self.dims, coords=coords, attrs=self.attrs, name=self.name)
+
+
+_KEEP_ATTRS = [True]
+
+
+def _broadcast(a: DataArray, b: DataArray):
+    dims = list(a.dims) + [d for d in b.dims if d not in a.dims]
+
+    def expand(x):
+        v = x.values
+        order = [x.dims.index(d) for d in dims if d in x.dims]
+        v = v.transpose(order)
+        shape = [x.sizes[d] if d in x.dims else 1 for d in dims]
+        return v.reshape(shape)
+
+    coords = OrderedDict(a.coords)
+    for k, c in b.coords.items():
+        coords.setdefault(k, c)
+    return expand(a), expand(b), tuple(dims), coords
+
+
+def _align(a: DataArray, b):
+    if isinstance(b, DataArray):
+        _, bv, dims, _ = _broadcast(a, b)
+        if tuple(dims) != a.dims:
+            raise ValueError("condition adds dimensions")
+        return np.broadcast_to(bv, a.shape), dims
+    return np.asarray(b), a.dims
+
+
+class Dataset:
+    def __init__(self, data_vars=None, coords=None, attrs=None):
+        self.data_vars = OrderedDict()
+        self.coords = OrderedDict()
+        self.attrs = dict(attrs or {})
+        for k, c in (coords or {}).items():
+            self.coords[k] = c if isinstance(c, Coordinate) else Coordinate(k, c.coords[k].values if isinstance(c, DataArray) and k in c.coords else (c.values if isinstance(c, DataArray) else c))
+        for k, v in (data_vars or {}).items():
+            self[k] = v
+
+    def __setitem__(self, name, da):
+        da = as_dataarray(da)
+        for k, c in da.coords.items():
+            if k in self.coords and k in da.dims and self.coords[k].size != c.size:
+                raise ValueError(f"conflicting sizes for dimension {k!r}")
+            self.coords.setdefault(k, c)
+        self.data_vars[name] = da.rename(name)
+
+    def __getitem__(self, name):
+        if isinstance(name, (list, tuple)):
+            return Dataset({n: self.data_vars[n] for n in name}, attrs=self.attrs)
+        if name in self.data_vars:
+            da = self.data_vars[name]
+            for k, c in self.coords.items():
+                if k in da.dims:
+                    da.coords.setdefault(k, c)
+            return da
+        if name in self.coords:
+            c = self.coords[name]
+            out = DataArray(c.values if not isinstance(c.values, TimeIndex) else np.arange(c.size), dims=(name,), attrs=c.attrs, name=name)
+            out.coords[name] = c
+            return out
+        raise KeyError(name)
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        d = self.__dict__
+        if item in d.get("data_vars", {}) or item in d.get("coords", {}):
+            return self[item]
+        raise AttributeError(item)
+
+    def __contains__(self, name):
+        return name in self.data_vars or name in self.coords
+
+    def __iter__(self):
+        return iter(self.data_vars)
+
+    def keys(self):
+        return self.data_vars.keys()
+
+    def values(self):
+        return self.data_vars.values()
+
+    @property
+    def sizes(self):
+        s = OrderedDict()
+        for da in self.data_vars.values():
+            s.update(da.sizes)
+        for k, c in self.coords.items():
+            s.setdefault(k, c.size)
+        return s
+
+    @property
+    def dims(self):
+        return self.sizes
+
+    @property
+    def chunks(self):
+        return None
+
+    def assign(self, variables=None, **kw):
+        out = Dataset(self.data_vars, self.coords, self.attrs)
+        for k, v in {**(variables or {}), **kw}.items():
+            out[k] = v
+        return out
+
+    def assign_attrs(self, **kw):
+        out = Dataset(self.data_vars, self.coords, {**self.attrs, **kw})
+        return out
+
+    def drop_vars(self, names, errors="raise"):
+        names = [names] if isinstance(names, str) else list(names)
+        return Dataset({k: v for k, v in self.data_vars.items() if k not in names},
+                       {k: c for k, c in self.coords.items() if k not in names}, self.attrs)
+
+    def rename(self, mapping):
+        return Dataset({mapping.get(k, k): v for k, v in self.data_vars.items()}, self.coords, self.attrs)
+
+    def isel(self, indexers=None, **kw):
+        idx = {**(indexers or {}), **kw}
+        return Dataset({k: v.isel({d: i for d, i in idx.items() if d in v.dims}) for k, v in self.data_vars.items()}, attrs=self.attrs)
+
+    def transpose(self, *dims):
+        def tr(v):
+            want = [d for d in dims if d in v.dims or d is Ellipsis]
+            rest = [d for d in v.dims if d not in want]
+            if Ellipsis in want:
+                return v.transpose(*want)
+            return v.transpose(*(rest + want)) if rest else v.transpose(*want)
+
+        return Dataset({k: tr(v) for k, v in self.data_vars.items()}, self.coords, self.attrs)
+
+    def __repr__(self):
+        vs = ", ".join(f"{k}{tuple(v.dims)}" for k, v in self.data_vars.items())
+        return f"<xsdba_amd.Dataset {vs}>"
+
+    def to_xarray(self):
+        import xarray as xr
+
+        ds = xr.Dataset({k: self[k].to_xarray() for k in self.data_vars})
+        ds.attrs.update(self.attrs)
+        return ds
+
+
+def is_xarray(obj) -> bool:
+    mod = type(obj).__module__ or ""
+    return mod.startswith("xarray")
+
+
+def as_dataarray(obj, name=None) -> DataArray:
+    """Accept our DataArray, an xarray.DataArray (duck-typed) or a bare array."""
+    if isinstance(obj, DataArray):
+        return obj
+    if hasattr(obj, "dims") and hasattr(obj, "values") and hasattr(obj, "coords"):
+        coords = OrderedDict()
+        for k in obj.coords:
+            c = obj.coords[k]
+            cdims = tuple(getattr(c, "dims", (k,)))
+            if cdims != (k,):
+                continue  # auxiliary coordinates are dropped (base.py:708-712 does the same around the call)
+            vals = c.values
+            if _is_time_like(vals):
+                cal = None
+                try:
+                    cal = c.dt.calendar
+                except Exception:
+                    pass
+                try:
+                    vals = time_index(c.to_index(), cal)
+                except Exception:
+                    vals = time_index(vals, cal)
+            coords[k] = Coordinate(k, vals, dict(getattr(c, "attrs", {})))
+        return DataArray(np.asarray(obj.values), tuple(obj.dims), coords, dict(obj.attrs), getattr(obj, "name", name))
+    arr = np.asarray(obj)
+    return DataArray(arr, name=name)
+
+
+def as_dataset(obj) -> Dataset:
+    if isinstance(obj, Dataset):
+        return obj
+    if hasattr(obj, "data_vars"):
+        return Dataset({k: as_dataarray(obj[k]) for k in obj.data_vars}, attrs=dict(obj.attrs))
+    raise TypeError(f"cannot interpret {type(obj)} as a Dataset")
+
+
+def full_like(da: DataArray, fill, dtype=None) -> DataArray:
+    return DataArray(np.full(da.shape, fill, dtype or da.dtype), da.dims, da.coords, da.attrs, da.name)
+
+
+class set_keep_attrs:
+    def __init__(self, keep=True):
+        self.keep = keep
+
+    def __enter__(self):
+        self.old = _KEEP_ATTRS[0]
+        _KEEP_ATTRS[0] = self.keep
+
+    def __exit__(self, *a):
+        _KEEP_ATTRS[0] = self.old

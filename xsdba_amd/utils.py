@@ -1,0 +1,194 @@
+"""Array helpers of the hot path with the reference's names (xsdba.utils, utils.py:31-32, 130-177,
+251-281, 284-314, 408-513, 573-638).  Numerics run in the HIP library; these wrappers only shape the
+labelled inputs/outputs."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hip
+from .base import Grouper, parse_group
+from .labeled import Coordinate, DataArray, as_dataarray
+
+MULTIPLICATIVE = "*"
+ADDITIVE = "+"
+
+
+def equally_spaced_nodes(n: int, eps: float | None = None) -> np.ndarray:
+    """Nodes with `n` equally spaced points within [0, 1], optionally with two end-points (utils.py:251-281)."""
+    dq = 1 / n / 2
+    q = np.linspace(dq, 1 - dq, n)
+    if eps is None:
+        return q
+    return np.insert(np.append(q, 1 - eps), 0, eps)
+
+
+def get_correction(x, y, kind: str):
+    """Additive or multiplicative correction factors (utils.py:130-143)."""
+    if kind == ADDITIVE:
+        out = y - x
+    elif kind == MULTIPLICATIVE:
+        out = y / x
+    else:
+        raise ValueError("kind must be + or *.")
+    if isinstance(out, DataArray):
+        out.attrs["kind"] = kind
+    return out
+
+
+def apply_correction(x, factor, kind: str | None = None):
+    """Apply correction factors (utils.py:146-162)."""
+    kind = kind or getattr(factor, "attrs", {}).get("kind", None)
+    if kind == ADDITIVE:
+        return x + factor
+    if kind == MULTIPLICATIVE:
+        return x * factor
+    raise ValueError("kind must be `+` or `*`.")
+
+
+def invert(x, kind: str | None = None):
+    """-x or 1/x (utils.py:165-177)."""
+    kind = kind or getattr(x, "attrs", {}).get("kind", None)
+    if kind == ADDITIVE:
+        return -x
+    if kind == MULTIPLICATIVE:
+        return 1 / x
+    raise ValueError
+
+
+def add_cyclic_bounds(da, att: str, cyclic_coords: bool = True):
+    """Prepend the last slice and append the first along `att` (utils.py:284-314)."""
+    da = as_dataarray(da)
+    ax = da.dims.index(att)
+    v = da.values
+    data = np.concatenate([np.take(v, [-1], axis=ax), v, np.take(v, [0], axis=ax)], axis=ax)
+    crd = np.asarray(da.coords[att].values)
+    if cyclic_coords:
+        vals = np.concatenate([crd[-1:], crd, crd[:1]])
+    else:
+        vals = np.concatenate([[crd[0] - (crd[1] - crd[0])], crd, [crd[-1] + (crd[-1] - crd[-2])]])
+    coords = dict(da.coords)
+    coords[att] = Coordinate(att, vals, da.coords[att].attrs)
+    return DataArray(data, da.dims, coords, da.attrs, da.name)
+
+
+# ---- [cell, time] views of labelled arrays ------------------------------------------------------------
+def cell_time_view(da: DataArray, dim: str = "time"):
+    """Logical ``[cell, time]`` 2-D view of `da` (no copy for C-ordered (time, cells...) or (cells..., time)
+    arrays: the library reads both layouts), with the cell dims and their shape to fold results back."""
+    ax = da.dims.index(dim)
+    v = np.moveaxis(da.values, ax, -1)
+    cell_dims = tuple(d for d in da.dims if d != dim)
+    cell_shape = v.shape[:-1]
+    return v.reshape(-1, v.shape[-1]), cell_dims, cell_shape
+
+
+def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantiles"):
+    """[cell, group(, quantile)] contiguous view of a trained table with the cells ordered like `cell_dims`."""
+    tail = [prop] + ([last] if last else [])
+    missing = [d for d in cell_dims if d not in tab.dims]
+    if missing:
+        raise ValueError(f"trained table lacks dimension(s) {missing} present on the data")
+    t = tab.transpose(*cell_dims, *tail)
+    return np.ascontiguousarray(t.values).reshape((-1,) + t.shape[len(cell_dims):])
+
+
+@parse_group
+def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: str = "linear",
+                        extrapolation: str = "constant"):
+    """Interpolate values of yq on new values of x (utils.py:408-513).
+
+    Ungrouped: 1-D scipy-interp1d semantics ('nearest' | 'linear').  Grouped: the reference's 2-D griddata
+    path; only ``method="nearest"`` (true 2-D nearest neighbour) is implemented on the device — 'linear' /
+    'cubic' go through a Qhull triangulation in the reference and raise NotImplementedError here.
+    """
+    newx, xq, yq = as_dataarray(newx), as_dataarray(xq), as_dataarray(yq)
+    dim, prop = group.dim, group.prop
+    if method not in ("nearest", "linear"):
+        raise NotImplementedError(f"interp_on_quantiles(method={method!r}) is not implemented on the HIP path")
+    x2, cell_dims, cell_shape = cell_time_view(newx, dim)
+    if prop == "group":
+        if "group" in xq.dims:
+            xq = xq.squeeze("group")
+        if "group" in yq.dims:
+            yq = yq.squeeze("group")
+        xt = table_view(xq.expand_dims(group=[1]), cell_dims, "group")
+        yt = table_view(yq.expand_dims(group=[1]), cell_dims, "group")
+        gidx = None
+    else:
+        if method != "nearest":
+            raise NotImplementedError("grouped interp_on_quantiles is implemented for method='nearest' only "
+                                      "(the reference's 'linear'/'cubic' use scipy.griddata's Qhull triangulation)")
+        crd = group.get_coordinate(newx)
+        if prop not in xq.dims:
+            xq = xq.expand_dims({prop: crd.values})
+        if prop not in yq.dims:
+            yq = yq.expand_dims({prop: crd.values})
+        for d in cell_dims:
+            if d not in xq.dims:
+                xq = xq.expand_dims({d: newx.sizes[d]})
+            if d not in yq.dims:
+                yq = yq.expand_dims({d: newx.sizes[d]})
+        xt, yt = table_view(xq, cell_dims, prop), table_view(yq, cell_dims, prop)
+        gidx, _ = group.group_index(newx)
+    dt = np.result_type(yt.dtype, np.float32)
+    out = hip.qm_adjust(x2.astype(dt, copy=False), yt.astype(dt, copy=False), xt.astype(dt, copy=False), gidx, method,
+                        extrapolation, kind=None)
+    coords = {k: c for k, c in newx.coords.items() if k in cell_dims or k == dim}
+    return DataArray(out.reshape(cell_shape + (out.shape[-1],)), cell_dims + (dim,), coords)
+
+
+@parse_group
+def broadcast(grouped, x, *, group: str | Grouper = "time", interp: str = "nearest", sel=None):
+    """Broadcast a grouped array back to the shape of `x` along time (utils.py:180-248), nearest selection."""
+    grouped, x = as_dataarray(grouped), as_dataarray(x)
+    if interp != "nearest" and group.prop != "group":
+        raise NotImplementedError("broadcast(interp != 'nearest') is not implemented")
+    if group.prop == "group":
+        return grouped.squeeze("group") if "group" in grouped.dims else grouped
+    gidx, _ = group.group_index(x)
+    ax = grouped.dims.index(group.prop)
+    data = np.take(grouped.values, gidx, axis=ax)
+    dims = tuple(group.dim if d == group.prop else d for d in grouped.dims)
+    coords = {k: c for k, c in grouped.coords.items() if k != group.prop}
+    coords[group.dim] = x.coords[group.dim]
+    return DataArray(data, dims, coords, grouped.attrs, grouped.name)
+
+
+def rank(da, dim: str | list = "time", pct: bool = False, use_random_tiebreak: bool = False):
+    """Rank data along a dimension (utils.py:573-638): average ties, NaN stay NaN; ``pct=True`` rescales to [0, 1].
+
+    Computed by the HIP rank kernel (percent ranks); integer ranks are recovered from them exactly when
+    the extremes are untied, otherwise through the count of valid values.
+    """
+    if use_random_tiebreak:
+        raise NotImplementedError("use_random_tiebreak is not implemented on the HIP path")
+    da = as_dataarray(da)
+    dims = dim if isinstance(dim, list) else [dim]
+    if len(dims) > 1:
+        raise NotImplementedError("multi-dimensional rank is reached through qdm_adjust(rank_window=True) on the HIP path")
+    x2, cell_dims, cell_shape = cell_time_view(da, dims[0])
+    x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
+    T = x2.shape[1]
+    pr = hip.rank_groups(x2, None, 1, 1, False)
+    if not pct:
+        # pr = pmax*(p-pmin)/(pmax-pmin) with p = r/N: invert with the extreme average ranks of each row
+        valid = ~np.isnan(x2)
+        N = valid.sum(axis=1, keepdims=True).astype(np.float64)
+        with np.errstate(all="ignore"):
+            mn = np.nanmin(np.where(valid, x2, np.nan), axis=1, keepdims=True)
+            mx = np.nanmax(np.where(valid, x2, np.nan), axis=1, keepdims=True)
+        nmin = (x2 == mn).sum(axis=1, keepdims=True)
+        nmax = (x2 == mx).sum(axis=1, keepdims=True)
+        rmin, rmax = (nmin + 1) / 2.0, (N - nmax) + (nmax + 1) / 2.0
+        with np.errstate(all="ignore"):
+            # p = pr*(pmax-pmin)/pmax + pmin with pmax = rmax/N, pmin = rmin/N ; r = p*N
+            r = (pr * ((rmax - rmin) / N) / (rmax / N) + rmin / N) * N
+        r = np.where((rmax == rmin) & valid, rmin, r)
+        pr = np.rint(r * 2) / 2
+    coords = {k: c for k, c in da.coords.items()}
+    out = DataArray(pr.reshape(cell_shape + (T,)), cell_dims + (dims[0],), coords, da.attrs, da.name)
+    return out.transpose(*da.dims)
+
+
+__all__ = ["ADDITIVE", "MULTIPLICATIVE", "add_cyclic_bounds", "apply_correction", "broadcast", "equally_spaced_nodes",
+           "get_correction", "interp_on_quantiles", "invert", "rank"]
