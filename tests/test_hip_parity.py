@@ -345,3 +345,22 @@ def test_errors(hip):
         hip.qm_adjust(x, np.zeros((2, 4, 5), np.float32), np.zeros((2, 4, 5), np.float32), np.zeros(100, np.int32), "linear")
     with pytest.raises(TypeError):
         hip.quantile_groups(x.astype(np.int32), None, 1, 1, q)
+
+
+def test_table_larger_than_lds(hip):
+    """float64 tables with 50 quantiles x 365 groups (288 KB) do not fit the 160 KB LDS: the adjust kernels then
+    keep the compacted table in a global scratch slice per block — same numbers as the oracle."""
+    rng = np.random.default_rng(31)
+    T, C = 3650, 3
+    gidx, G, W = GROUPINGS["doy31"](T)
+    ref, hist, sim = _synth(rng, C, T, "+", np.float64, nan_frac=0.01)
+    q = _nodes(50, np.float64)
+    af, hq = oracle.eqm_train(ref, hist, gidx, G, W, q, "+")
+    got, node = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", "+", return_nodes=True)
+    exp, enode = oracle.qm_adjust(sim, af, hq, gidx, "nearest", "constant", "+", return_nodes=True)
+    assert_close(got, exp, rtol=0.0, what="scen (global table)")
+    np.testing.assert_array_equal(node, enode)
+    scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, True, "nearest", "constant", "+")
+    escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, True, "nearest", "constant", "+")
+    assert_close(sim_q, esim_q, rtol=0.0, what="sim_q")
+    assert_close(scen, escen, rtol=0.0, what="qdm scen (global table)")

@@ -64,7 +64,7 @@ struct xsdba_hip_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<std::unique_ptr<Plan>> plans;
-    DevBuf scratch[12];
+    DevBuf scratch[16];
     std::vector<void *> user_allocs;
     bool profiling = false;
     std::vector<ProfEntry> prof;
@@ -75,7 +75,7 @@ struct xsdba_hip_ctx {
 
 namespace {
 
-enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC };
+enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_NSLOTS };
 
 int ensure(xsdba_hip_ctx *ctx, int slot, size_t bytes, void **out)
 {
@@ -391,12 +391,24 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
                      const int *d_gidx, int interp, int extrap, char kind, R *scen_cm, int *node, const R *scaling,
                      const R *trend_cm)
 {
-    size_t lds = xs::tab_lds_bytes<R>(G, Q);
+    const size_t tab = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
     int rc;
-    if ((rc = set_lds(xs::k_qm_adjust<R>, lds, ctx, "the factor table"))) return rc;
-    LaunchScope ls(ctx, scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust");
-    hipLaunchKernelGGL(xs::k_qm_adjust<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
-                       af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node, scaling, trend_cm);
+    const char *name = scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust";
+    if (tab <= (size_t)ctx->lds_limit) {
+        if ((rc = set_lds(xs::k_qm_adjust<R, true>, tab, ctx, "the factor table"))) return rc;
+        LaunchScope ls(ctx, name);
+        hipLaunchKernelGGL((xs::k_qm_adjust<R, true>), dim3((unsigned)C), dim3(256), tab, ctx->stream, (const R *)s.dev, T, C,
+                           s.st, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node,
+                           scaling, trend_cm, (unsigned char *)nullptr, (size_t)0);
+    } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
+        const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
+        void *scratch;
+        if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
+        LaunchScope ls(ctx, name);
+        hipLaunchKernelGGL((xs::k_qm_adjust<R, false>), dim3(nblk), dim3(256), 0, ctx->stream, (const R *)s.dev, T, C, s.st,
+                           s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node, scaling,
+                           trend_cm, (unsigned char *)scratch, tab);
+    }
     return check_launch("k_qm_adjust");
 }
 
@@ -511,16 +523,27 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     SeriesOut o, oq;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     if ((rc = series_out_begin<double>(ctx, S_OUT1, S_CM2, sim_q, T, C, ost, osc, &oq))) return rc;
-    size_t lds = (ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15)) +
-                 ((sizeof(int) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
-    if ((rc = set_lds(xs::k_qdm_adjust<R>, lds, ctx, "the ranking series + factor table"))) return rc;
+    const size_t tab = ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15);
+    const size_t base = ((sizeof(int) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
     const bool rw = rank_window && W > 1;
-    {
+    const int *gp = rw ? pl->d_row_ptr : pl->d_mem_ptr, *gi = rw ? pl->d_row_idx : pl->d_mem_idx;
+    if (base + tab <= (size_t)ctx->lds_limit) {
+        if ((rc = set_lds(xs::k_qdm_adjust<R, true>, base + tab, ctx, "the ranking series + factor table"))) return rc;
         LaunchScope ls(ctx, "k_qdm_adjust");
-        hipLaunchKernelGGL(xs::k_qdm_adjust<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
-                           (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, rw ? pl->d_row_ptr : pl->d_mem_ptr,
-                           rw ? pl->d_row_idx : pl->d_mem_idx, interp, extrap, (int)kind, (R *)o.kernel_dst,
-                           (double *)oq.kernel_dst, (int64_t)1, T);
+        hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3((unsigned)C), dim3(256), base + tab, ctx->stream, (const R *)s.dev,
+                           T, C, s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap,
+                           (int)kind, (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)nullptr,
+                           (size_t)0);
+        if ((rc = check_launch("k_qdm_adjust"))) return rc;
+    } else {
+        if ((rc = set_lds(xs::k_qdm_adjust<R, false>, base, ctx, "the ranking series"))) return rc;
+        const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
+        void *scratch;
+        if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
+        LaunchScope ls(ctx, "k_qdm_adjust");
+        hipLaunchKernelGGL((xs::k_qdm_adjust<R, false>), dim3(nblk), dim3(256), base, ctx->stream, (const R *)s.dev, T, C, s.st,
+                           s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap, (int)kind,
+                           (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)scratch, tab);
         if ((rc = check_launch("k_qdm_adjust"))) return rc;
     }
     if ((rc = series_out_end<R>(ctx, &o, T, C)) || (rc = series_out_end<double>(ctx, &oq, T, C))) return rc;

@@ -212,35 +212,42 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
 // series.  scaling/trend non-null -> DQM: x = (sim (+|*) scaling[g]) detrended by trend[t]
 // (detrending.py:102-120), mapped, retrended.  trend is cell-major contiguous [cell][time].
 // ---------------------------------------------------------------------------------------------
-template <typename R>
-__global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc, const R *__restrict__ af,
-                            const R *__restrict__ hist_q, int G, int Q, const int *__restrict__ gidx, int interp,
-                            int extrap, int kind, R *__restrict__ scen, int64_t ost, int64_t osc,
-                            int *__restrict__ node, const R *__restrict__ scaling, const R *__restrict__ trend)
+// TAB_LDS: the compacted table lives in LDS (the normal case); otherwise (tables larger than the LDS, e.g.
+// float64 with 50 quantiles x 366 groups) each block compacts it into its own slice of a global scratch
+// buffer (L2-resident) and the block walks the cells grid-stride.
+template <typename R, bool TAB_LDS>
+__global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
+                            const R *__restrict__ af, const R *__restrict__ hist_q, int G, int Q,
+                            const int *__restrict__ gidx, int interp, int extrap, int kind, R *__restrict__ scen,
+                            int64_t ost, int64_t osc, int *__restrict__ node, const R *__restrict__ scaling,
+                            const R *__restrict__ trend, unsigned char *__restrict__ gscratch, size_t gstride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int64_t c = blockIdx.x;
-    TabLds<R> tl = tab_carve<R>(smem, G, Q);
-    CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
-    const R *x = sim + c * sc;
-    R *o = scen + c * osc;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-        R v = x[t * st];
-        int g0 = G > 1 ? gidx[t] : 0;
-        R tr = (R)0;
-        if (scaling) {
-            int gs = gidx[t];
-            R s = gs >= 0 ? scaling[(size_t)c * G + gs] : nan_of<R>();
-            v = apply_corr<R>(v, s, kind);
-            tr = trend[(size_t)c * T + t];
-            v = apply_corr<R>(v, invert<R>(tr, kind), kind);
+    unsigned char *tabmem = TAB_LDS ? smem : gscratch + (size_t)blockIdx.x * gstride;
+    TabLds<R> tl = tab_carve<R>(tabmem, G, Q);
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
+        const R *x = sim + c * sc;
+        R *o = scen + c * osc;
+        for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+            R v = x[t * st];
+            int g0 = G > 1 ? gidx[t] : 0;
+            R tr = (R)0;
+            if (scaling) {
+                int gs = gidx[t];
+                R s = gs >= 0 ? scaling[(size_t)c * G + gs] : nan_of<R>();
+                v = apply_corr<R>(v, s, kind);
+                tr = trend[(size_t)c * T + t];
+                v = apply_corr<R>(v, invert<R>(tr, kind), kind);
+            }
+            int nd;
+            R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, node ? &nd : nullptr);
+            R y = kind ? apply_corr<R>(v, a, kind) : a;
+            if (scaling) y = apply_corr<R>(y, tr, kind);
+            o[t * ost] = y;
+            if (node) node[(size_t)c * T + t] = nd;
         }
-        int nd;
-        R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, node ? &nd : nullptr);
-        R y = kind ? apply_corr<R>(v, a, kind) : a;
-        if (scaling) y = apply_corr<R>(y, tr, kind);
-        o[t * ost] = y;
-        if (node) node[(size_t)c * T + t] = nd;
+        __syncthreads();  // everyone is done with the table before the next cell overwrites it
     }
 }
 
@@ -315,24 +322,27 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 // axis + apply.  af == nullptr -> ranks only (utils.rank through Grouper.apply).
 // One block per cell; dynamic LDS: [table (if af)][gstat: 4*G ints][xs: T * sizeof(R)]
 // ---------------------------------------------------------------------------------------------
-template <typename R>
-__global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc, const R *__restrict__ af,
-                             const R *__restrict__ quantiles, int G, int Q, const int *__restrict__ gidx,
-                             const int *__restrict__ grp_ptr, const int *__restrict__ grp_idx, int interp, int extrap,
-                             int kind, R *__restrict__ scen, double *__restrict__ sim_q, int64_t ost, int64_t osc)
+template <typename R, bool TAB_LDS>
+__global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
+                             const R *__restrict__ af, const R *__restrict__ quantiles, int G, int Q,
+                             const int *__restrict__ gidx, const int *__restrict__ grp_ptr,
+                             const int *__restrict__ grp_idx, int interp, int extrap, int kind, R *__restrict__ scen,
+                             double *__restrict__ sim_q, int64_t ost, int64_t osc, unsigned char *__restrict__ gscratch,
+                             size_t gstride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int64_t c = blockIdx.x;
     unsigned char *p = smem;
-    CellTab<R> ct;
+    TabLds<R> tl;
     if (af) {
-        TabLds<R> tl = tab_carve<R>(p, G, Q);
-        ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
-        p += (tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
+        tl = tab_carve<R>(TAB_LDS ? p : gscratch + (size_t)blockIdx.x * gstride, G, Q);
+        if (TAB_LDS) p += (tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
     }
     int *gstat = reinterpret_cast<int *>(p);  // per group: N valid, #==min, #==max
     p += ((sizeof(int) * 3 * (size_t)G) + 15) & ~(size_t)15;
     R *xs = reinterpret_cast<R *>(p);
+  for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+    CellTab<R> ct;
+    if (af) ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
     const R *x = sim + c * sc;
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t * st];
     __syncthreads();
@@ -371,6 +381,8 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t st, i
             scen[c * osc + t * ost] = apply_corr<R>(v, a, kind);
         }
     }
+    __syncthreads();  // series / table are reused by the next cell
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
