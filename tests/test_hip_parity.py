@@ -30,6 +30,17 @@ def hip():
     return h
 
 
+@pytest.fixture(autouse=True, params=["cell", "rows"])
+def train_kernel(request, monkeypatch):
+    """every test runs twice: with the per-cell fast train kernel (k_train_cell, where eligible) and with the
+    generic per-(cell, group) row kernel pinned (XSDBA_HIP_TRAIN=rows)"""
+    if request.param == "rows":
+        monkeypatch.setenv("XSDBA_HIP_TRAIN", "rows")
+    else:
+        monkeypatch.delenv("XSDBA_HIP_TRAIN", raising=False)
+    return request.param
+
+
 def _doy_month(T, start=0):
     d0 = (np.arange(T) + start) % 365
     cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
@@ -364,3 +375,28 @@ def test_table_larger_than_lds(hip):
     escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, True, "nearest", "constant", "+")
     assert_close(sim_q, esim_q, rtol=0.0, what="sim_q")
     assert_close(scen, escen, rtol=0.0, what="qdm scen (global table)")
+
+
+def test_fast_train_fallback_cells(hip, train_kernel):
+    """cells that break the shortcut assumptions of k_train_cell (inf - inf in the interpolation, non-positive
+    multiplicative group means, infinite means) are flagged and redone by the generic kernel: same results"""
+    rng = np.random.default_rng(37)
+    T, C = 3650, 6
+    gidx, G, W = GROUPINGS["doy31"](T)
+    ref, hist, _ = _synth(rng, C, T, "*", np.float32)
+    ref[1, 100:140] = np.inf      # +inf runs -> lerp between inf and inf
+    hist[2] = -hist[2]            # negative means for the multiplicative DQM normalisation
+    hist[3, ::7] = 0.0            # ties at zero
+    ref[4, 5] = -np.inf
+    q = _nodes(20)
+    with np.errstate(all="ignore"):
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, "*")
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, "*")
+        assert_close(hq, ehq, rtol=0.0, what="eqm hist_q")
+        assert_close(af, eaf, rtol=0.0, what="eqm af")
+        for kind in ("+", "*"):
+            af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind)
+            eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+            assert_close(sc, esc, rtol=5e-7, atol=1e-4, what=f"dqm scaling {kind}")
+            assert_close(hq, ehq, rtol=5e-7, atol=1e-4, what=f"dqm hist_q {kind}")
+            assert_close(af, eaf, rtol=2e-6, atol=2e-4, what=f"dqm af {kind}")

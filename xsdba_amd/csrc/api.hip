@@ -8,10 +8,14 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
+#include <iterator>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/xsdba_hip.h"
 #include "kernels.hpp"
+#include "train_cell.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -49,6 +53,9 @@ struct Plan {
     int max_row = 0, max_mem = 0;
     std::vector<int> row_ptr, row_idx, mem_ptr, mem_idx;
     int *d_gidx = nullptr, *d_row_ptr = nullptr, *d_row_idx = nullptr, *d_mem_ptr = nullptr, *d_mem_idx = nullptr;
+    // fast train path (train_cell.hpp): rows as sorted sets, toggle lists between consecutive groups
+    bool simple = false;  // no time index occurs twice in one group row
+    int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
 };
 
 struct ProfEntry {
@@ -75,7 +82,7 @@ struct xsdba_hip_ctx {
 
 namespace {
 
-enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_NSLOTS };
+enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_FLAGS, S_NSLOTS };
 
 int ensure(xsdba_hip_ctx *ctx, int slot, size_t bytes, void **out)
 {
@@ -237,7 +244,26 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
             if (tt >= 0 && tt < T) pl->row_idx[(size_t)rp[gg]++] = (int)tt;
         }
     }
+    // rows as sorted sets + symmetric differences of consecutive rows (the XOR lists of k_train_cell)
+    std::vector<int> row_sorted(pl->row_idx), tog_ptr((size_t)G, 0), tog_idx;
+    pl->simple = true;
+    for (int i = 0; i < G; i++) {
+        auto b = row_sorted.begin() + pl->row_ptr[i], e = row_sorted.begin() + pl->row_ptr[i + 1];
+        std::sort(b, e);
+        if (std::adjacent_find(b, e) != e) pl->simple = false;
+    }
+    if (pl->simple) {
+        for (int i = 0; i + 1 < G; i++) {
+            std::set_symmetric_difference(row_sorted.begin() + pl->row_ptr[i], row_sorted.begin() + pl->row_ptr[i + 1],
+                                          row_sorted.begin() + pl->row_ptr[i + 1], row_sorted.begin() + pl->row_ptr[i + 2],
+                                          std::back_inserter(tog_idx));
+            tog_ptr[(size_t)i + 1] = (int)tog_idx.size();
+        }
+    }
     int rc;
+    if ((rc = upload_ints(ctx, row_sorted, &pl->d_row_sorted))) return rc;
+    if ((rc = upload_ints(ctx, tog_ptr, &pl->d_tog_ptr))) return rc;
+    if ((rc = upload_ints(ctx, tog_idx, &pl->d_tog_idx))) return rc;
     if ((rc = upload_ints(ctx, g, &pl->d_gidx))) return rc;
     if ((rc = upload_ints(ctx, pl->row_ptr, &pl->d_row_ptr))) return rc;
     if ((rc = upload_ints(ctx, pl->row_idx, &pl->d_row_idx))) return rc;
@@ -253,6 +279,7 @@ void free_plan(Plan *p)
 {
     (void)hipFree(p->d_gidx); (void)hipFree(p->d_row_ptr); (void)hipFree(p->d_row_idx);
     (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
+    (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
 }
 
 // ---- series staging: any (host|device, strides) -> cell-major contiguous device view ---------------
@@ -369,18 +396,52 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     if ((rc = stage_out(ctx, S_TAB1, hq, tab, &ohq))) return rc;
     if ((rc = stage_out(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &osc))) return rc;
 
-    int P = 2;
-    while (P < pl->max_row) P <<= 1;
-    int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
-    size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * sizeof(U) + (size_t)Q * sizeof(R);
-    if ((rc = set_lds(xs::k_train_rows<R>, lds, ctx, "the row sort"))) return rc;
-    {
+    // generic (cell, group)-row kernel; `cells` (device list of n_list cell ids) restricts it to a subset
+    auto launch_rows = [&](const int *cells, int64_t n_list) -> int {
+        int P = 2;
+        while (P < pl->max_row) P <<= 1;
+        int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+        size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * sizeof(U) + (size_t)Q * sizeof(R);
+        int rc2;
+        if ((rc2 = set_lds(xs::k_train_rows<R>, lds, ctx, "the row sort"))) return rc2;
         LaunchScope ls(ctx, "k_train_rows");
-        hipLaunchKernelGGL(xs::k_train_rows<R>, dim3((unsigned)((int64_t)C * G)), dim3(NT), lds, ctx->stream,
+        hipLaunchKernelGGL(xs::k_train_rows<R>, dim3((unsigned)(n_list * G)), dim3(NT), lds, ctx->stream,
                            (const R *)s0.dev, (const R *)s1.dev, s0.st, s0.sc, pl->d_row_ptr, pl->d_row_idx, G,
-                           (const R *)dq, Q, (int)kind, mode, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, P);
-        if ((rc = check_launch("k_train_rows"))) return rc;
+                           (const R *)dq, Q, (int)kind, mode, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, P, cells);
+        return check_launch("k_train_rows");
+    };
+    bool fast = false;
+    if constexpr (std::is_same<R, float>::value) {
+        const char *force = getenv("XSDBA_HIP_TRAIN");  // "rows" pins the generic kernel (A/B runs, tests)
+        fast = pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
+        if (fast) {
+            void *flags;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
+            auto go = [&](auto cfg) -> int {
+                constexpr int EPT = decltype(cfg)::value;
+                size_t lds = xs::CellCfg<EPT>::lds_bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_cell<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
+                LaunchScope ls(ctx, "k_train_cell");
+                hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3((unsigned)C), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
+                                   pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
+                                   (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list);
+                return check_launch("k_train_cell");
+            };
+            rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})
+                                                                          : go(std::integral_constant<int, 11>{});
+            if (rc) return rc;
+            int nflag = 0;  // cells whose shortcut assumptions failed (rare) are redone by the generic kernel
+            HIP_TRY(hipMemcpyAsync(&nflag, flag_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (nflag > 0 && (rc = launch_rows(flag_list, nflag))) return rc;
+        }
     }
+    if (!fast && (rc = launch_rows(nullptr, C))) return rc;
     if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
     return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
 }

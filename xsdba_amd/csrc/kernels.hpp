@@ -76,7 +76,8 @@ template <typename R>
 __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1, int64_t st, int64_t sc,
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, int G,
                              const R *__restrict__ q, int Q, int kind, int mode, R *__restrict__ af,
-                             R *__restrict__ out_hq, R *__restrict__ scaling, int P_max)
+                             R *__restrict__ out_hq, R *__restrict__ scaling, int P_max,
+                             const int *__restrict__ cell_list)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -87,8 +88,9 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
     R *rq = reinterpret_cast<R *>(keys + P_max);
 
     const int64_t b = blockIdx.x;
-    const int64_t c = b / G;
-    const int g = (int)(b - c * G);
+    const int64_t ci = b / G;
+    const int g = (int)(b - ci * G);
+    const int64_t c = cell_list ? (int64_t)cell_list[ci] : ci;  // subset mode: redo the cells k_train_cell flagged
     const int r0 = row_ptr[g], L = row_ptr[g + 1] - r0;
     int P = 2;
     while (P < L) P <<= 1;
