@@ -103,22 +103,32 @@ def main():
     sim = ctx.synth((C, T), np.float32, gen, 2, seed, cell0, time_major=args.time_major)
     ctx.synchronize()
 
+    # output buffers are allocated once and reused by every step (a production pipeline does the same; a fresh
+    # multi-GB hipMalloc per step costs milliseconds of driver page clearing inside the step)
+    f32 = np.float32
+    o_af, o_hq = ctx.empty((C, G, Q), f32), ctx.empty((C, G, Q), f32)
+    o_scen = ctx.empty((C, T), f32)
+    o_sc = ctx.empty((C, G), f32) if method == "dqm" else None
+    o_trend = ctx.empty((C, T), f32) if method == "dqm" else None
+    ctx.synchronize()
+
     def step():
         """one pass of the hot path over this rank's cells; returns the device outputs"""
         if method == "dqm":
-            af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx)
-            scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind, ctx=ctx)
+            af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx, out=(o_af, o_hq, o_sc))
+            scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind, ctx=ctx,
+                                         out=(o_scen, o_trend))
             return [af, hq, sc, scen, trend]
-        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx)
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx, out=(o_af, o_hq))
         if method == "qdm":
-            scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, False, "nearest", "constant", kind, want_sim_q=False, ctx=ctx)
+            scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, False, "nearest", "constant", kind, want_sim_q=False, ctx=ctx,
+                                     out=o_scen)
         else:
-            scen = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind, ctx=ctx)
+            scen = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind, ctx=ctx, out=o_scen)
         return [af, hq, scen]
 
     def free(outs):
-        for o in outs:
-            o.free()
+        pass
 
     def barrier():
         ctx.synchronize()

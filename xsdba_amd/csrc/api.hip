@@ -429,7 +429,8 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3((unsigned)C), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
                                    pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
-                                   (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list);
+                                   (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list,
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
                 return check_launch("k_train_cell");
             };
             rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})

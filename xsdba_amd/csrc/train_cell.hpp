@@ -25,14 +25,16 @@
 
 namespace xs {
 
+// Inclusive wave64 prefix sum on the DPP cross-lane path (no LDS traffic): Hillis-Steele inside each row of 16
+// lanes (row_shr 1,2,4,8; lanes without a source read 0), then row_bcast:15 / row_bcast:31 carry the row totals.
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int u = __shfl_up(v, o, 64);
-        if (lane >= o) v += u;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
     const float *__restrict__ q, int Q, int kind, int mode, float *af, float *__restrict__ out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list)
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW, BS = Cfg::BS;
@@ -94,10 +96,22 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         // ---------------- A. load, keys, range ----------------
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (int i = tid; i < TPAD; i += NT) {
-            uint32_t k = i < T ? to_key(x[i]) : 0xFFFFFFFFu;
-            keys[i] = k;
-            if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
+        if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
+            for (int i = 2 * tid; i < TPAD; i += 2 * NT) {
+                float2 v2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+                if (i + 1 < T) v2 = *reinterpret_cast<const float2 *>(x + i);
+                else if (i < T) v2.x = x[i];
+                uint32_t k0 = to_key(v2.x), k1 = to_key(v2.y);
+                *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
+                if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
+                if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
+            }
+        } else {
+            for (int i = tid; i < TPAD; i += NT) {
+                uint32_t k = i < T ? to_key(x[i]) : 0xFFFFFFFFu;
+                keys[i] = k;
+                if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
+            }
         }
 #pragma unroll
         for (int e = 0; e < EPT; e++) idx0[tid * EPT + e] = (uint16_t)(tid * EPT + e);
@@ -117,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         const int npass = max(1, ((range + 1u == 0u ? 32 : nbits) + 3) / 4);
         __syncthreads();
 
+        if (debug_phase == 1) continue;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         // ---------------- B. LSD radix sort of the time indexes ----------------
         int cur = 0;
         for (int p = 0; p < npass; p++) {
@@ -180,6 +195,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             cur ^= 1;
         }
         const uint16_t *sorted = cur ? idx1 : idx0;
+        if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
         for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
         __syncthreads();
 
@@ -190,20 +206,40 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         for (int i = lane; i < BITW; i += 64) bits[i] = 0u;
         lds_wave_fence();
         double gsum = 0.0;
+        // software prefetch of the next group's toggle list (first 64 entries): its L2 latency hides under the
+        // current group's select
+        int pre_t = -1, pre_len = 0, pre_base = 0;
+        if (g_begin + 1 < g_end) {
+            pre_base = tog_ptr[g_begin];
+            pre_len = tog_ptr[g_begin + 1] - pre_base;
+            pre_t = lane < pre_len ? tog_idx[pre_base + lane] : -1;
+        }
+        // quantile-index math is a function of (n, k) only: cached while n does not change between groups
+        int n_prev = -1, c_case = 3, c_lo = 0;
+        float c_gamma = 0.f;
         for (int g = g_begin; g < g_end; g++) {
-            const int *list;
-            int len;
-            if (g == g_begin) { list = row_sorted + row_ptr[g]; len = row_ptr[g + 1] - row_ptr[g]; }
-            else { list = tog_idx + tog_ptr[g - 1]; len = tog_ptr[g] - tog_ptr[g - 1]; }
             double dloc = 0.0;
-            for (int i = lane; i < len; i += 64) {
-                int t = list[i];
+            auto toggle = [&](int t) {
                 int r = rank[t];
                 if (r < nvalid) {
                     uint32_t m = 1u << (r & 31);
                     uint32_t old = atomicXor(&bits[r >> 5], m);
                     if (mode == 2) { float v = from_key(keys[t]); dloc += (old & m) ? -(double)v : (double)v; }
                 }
+            };
+            if (g == g_begin) {
+                const int *list = row_sorted + row_ptr[g];
+                const int len = row_ptr[g + 1] - row_ptr[g];
+                for (int i = lane; i < len; i += 64) toggle(list[i]);
+            } else {
+                const int t0 = pre_t, len = pre_len, lbase = pre_base;
+                if (g + 1 < g_end) {
+                    pre_base = tog_ptr[g];
+                    pre_len = tog_ptr[g + 1] - pre_base;
+                    pre_t = lane < pre_len ? tog_idx[pre_base + lane] : -1;
+                }
+                if (t0 >= 0) toggle(t0);
+                for (int i = lane + 64; i < len; i += 64) toggle(tog_idx[lbase + i]);
             }
             lds_wave_fence();
             int cl = 0;
@@ -211,7 +247,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             for (int j = 0; j < WPL; j++) cl += __popc(bits[lane * WPL + j]);
             const int incl = wave_incl_scan(cl);
             const int excl = incl - cl;
-            const int n = __shfl(incl, 63, 64);
+            const int n = __builtin_amdgcn_readlane(incl, 63);
             float mu = 0.f, inv = 0.f;
             if (mode == 2) {
                 gsum += wave_sum(dloc);
@@ -225,16 +261,21 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 const int k = kb + (lane & 31);
                 const bool act = k < Q;
                 const bool hi_lane = lane >= 32;
-                const double qk = (double)q[act ? k : 0];
-                const double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
-                int casek;  // 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
-                int lo = 0;
-                if (n == 0) casek = 3;
-                else if (vi != vi || vi >= (double)(n - 1)) { casek = 1; lo = n - 1; }
-                else if (vi < 0.0) { casek = 2; lo = 0; }
-                else { casek = 0; lo = (int)floor(vi); }
-                int j = (casek == 0 && hi_lane) ? lo + 1 : lo;
-                // ---- select(j): owner lane, word, bit ----
+                int casek, lo;  // casek 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
+                float gamma;
+                if (kb == 0 && n == n_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
+                else {
+                    const double qk = (double)q[act ? k : 0];
+                    const double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
+                    lo = 0; gamma = 0.f;
+                    if (n == 0) casek = 3;
+                    else if (vi != vi || vi >= (double)(n - 1)) { casek = 1; lo = n - 1; }
+                    else if (vi < 0.0) { casek = 2; lo = 0; }
+                    else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
+                    if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
+                }
+                const int j = (casek == 0 && hi_lane) ? lo + 1 : lo;
+                // ---- select(j): owner lane (binary search over the lane prefix counts) ----
                 int L = 0, eL = 0;
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) {
@@ -245,25 +286,33 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     eL = ok ? e : eL;
                 }
                 int rem = j - eL;
+                // ---- word inside the owner's WPL words: all loads first, then a branch-free prefix compare ----
                 const uint32_t *wp = bits + L * WPL;
-                uint32_t wsel = 0u;
-                int wi = 0;
-                bool done = false;
+                uint32_t wv[WPL];
 #pragma unroll
-                for (int i = 0; i < WPL; i++) {
-                    uint32_t w = wp[i];
-                    int cw = __popc(w);
-                    if (!done) {
-                        if (rem >= cw && i < WPL - 1) rem -= cw;
-                        else { wsel = w; wi = i; done = true; }
-                    }
+                for (int i = 0; i < WPL; i++) wv[i] = wp[i];
+                int wi = 0, sub = 0, run = 0;
+#pragma unroll
+                for (int i = 0; i < WPL - 1; i++) {
+                    int ci = __popc(wv[i]);
+                    run += ci;
+                    bool ge = rem >= run;
+                    wi += ge ? 1 : 0;
+                    sub += ge ? ci : 0;
                 }
+                rem -= sub;
+                uint32_t w = wv[0];
+#pragma unroll
+                for (int i = 1; i < WPL; i++) w = (wi == i) ? wv[i] : w;
+                // ---- bit inside the word ----
                 int pos = 0;
-                uint32_t w = wsel;
 #pragma unroll
                 for (int s = 16; s > 0; s >>= 1) {
                     int cw = __popc(w & ((1u << s) - 1u));
-                    if (rem >= cw) { rem -= cw; w >>= s; pos += s; }
+                    bool ge = rem >= cw;
+                    rem -= ge ? cw : 0;
+                    w = ge ? (w >> s) : w;
+                    pos += ge ? s : 0;
                 }
                 int rsel = min((L * WPL + wi) * 32 + pos, TPAD - 1);
                 int id = min((int)sorted[rsel], TPAD - 1);
@@ -275,7 +324,6 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 else if (casek != 0) res = v;
                 else {
                     float left = v, right = vhi;
-                    float gamma = (float)(vi - (double)lo);
                     float diff = right - left;
                     if (gamma >= 0.5f) res = (float)((double)right - (double)diff * (1.0 - (double)gamma));
                     else res = left + diff * gamma;
@@ -290,6 +338,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     }
                 }
             }
+            n_prev = n;
             if (mode == 2 && lane == 0) {
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;
                 else scaling[(size_t)c * G + g] = get_corr<float>(mu, scaling[(size_t)c * G + g], kind);

@@ -101,7 +101,7 @@ def quantile_groups(x, gidx, G, W, q, ctx: Context | None = None):
     return out
 
 
-def _train(fn, name, ref, hist, gidx, G, W, q, kind, with_scaling, ctx):
+def _train(fn, name, ref, hist, gidx, G, W, q, kind, with_scaling, ctx, out=None):
     ctx = ctx or default_context()
     r = _Series(ref)
     h = _Series(hist, r.dtype)
@@ -114,30 +114,30 @@ def _train(fn, name, ref, hist, gidx, G, W, q, kind, with_scaling, ctx):
         h = _Series(np.ascontiguousarray(h.arr))
     q = np.ascontiguousarray(q, r.dtype)
     g = _gidx(gidx, r.T, G)
-    af = _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
-    hq = _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
+    af = out[0] if out else _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
+    hq = out[1] if out else _out(ctx, r.dev, (r.C, G, q.size), r.dtype)
     args = [ctx.handle, r.ptr, h.ptr, dtype_code(r.dtype), _i64(r.T), _i64(r.C), _i64(r.st), _i64(r.sc), _vp(g),
             C.c_int(G), C.c_int(W), _vp(q), C.c_int(q.size), C.c_char(kind.encode()), _vp(af), _vp(hq)]
     if with_scaling:
-        sc = _out(ctx, r.dev, (r.C, G), r.dtype)
+        sc = out[2] if out else _out(ctx, r.dev, (r.C, G), r.dtype)
         check(fn(*args, _vp(sc)), name)
         return af, hq, sc
     check(fn(*args), name)
     return af, hq
 
 
-def eqm_train(ref, hist, gidx, G, W, q, kind, ctx=None):
-    """_adjustment.eqm_train -> (af, hist_q) each [C, G, Q]"""
-    return _train(load().xsdba_hip_eqm_train, "eqm_train", ref, hist, gidx, G, W, q, kind, False, ctx)
+def eqm_train(ref, hist, gidx, G, W, q, kind, ctx=None, out=None):
+    """_adjustment.eqm_train -> (af, hist_q) each [C, G, Q]; ``out=(af, hist_q)`` reuses buffers"""
+    return _train(load().xsdba_hip_eqm_train, "eqm_train", ref, hist, gidx, G, W, q, kind, False, ctx, out)
 
 
-def dqm_train(ref, hist, gidx, G, W, q, kind, ctx=None):
-    """_adjustment.dqm_train -> (af, hist_q, scaling)"""
-    return _train(load().xsdba_hip_dqm_train, "dqm_train", ref, hist, gidx, G, W, q, kind, True, ctx)
+def dqm_train(ref, hist, gidx, G, W, q, kind, ctx=None, out=None):
+    """_adjustment.dqm_train -> (af, hist_q, scaling); ``out=(af, hist_q, scaling)`` reuses buffers"""
+    return _train(load().xsdba_hip_dqm_train, "dqm_train", ref, hist, gidx, G, W, q, kind, True, ctx, out)
 
 
 def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="+", return_nodes=False, ctx=None,
-              out_time_major=False):
+              out_time_major=False, out=None):
     """_adjustment.qm_adjust -> scen [C, T]; ``kind=None`` returns the interpolated factors
     (utils.interp_on_quantiles)."""
     ctx = ctx or default_context()
@@ -146,7 +146,7 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
     af = _table(af, s.dtype, (s.C, G, Q))
     hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
     g = _gidx(gidx, s.T, G)
-    scen = _out(ctx, s.dev, (s.T, s.C) if out_time_major else (s.C, s.T), s.dtype)
+    scen = out if out is not None else _out(ctx, s.dev, (s.T, s.C) if out_time_major else (s.C, s.T), s.dtype)
     ost, osc = (s.C, 1) if out_time_major else (1, s.T)
     node = np.empty((s.C, s.T), np.int32) if return_nodes else None
     k = C.c_char(kind.encode()) if kind else C.c_char(b"\0")
@@ -159,7 +159,7 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
 
 
 def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
-               ctx=None):
+               ctx=None, out=None):
     """_adjustment.dqm_adjust -> (scen, trend) each [C, T]"""
     ctx = ctx or default_context()
     s = _Series(sim)
@@ -169,8 +169,8 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
     scaling = _table(scaling, s.dtype, (s.C, G))
     g = _gidx(gidx, s.T, G)
     tn = np.ascontiguousarray(time_num, np.float64)
-    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
-    trend = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    scen = out[0] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_dqm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
                                       _vp(af), _vp(hist_q), _vp(scaling), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
                                       _vp(tn), C.c_int(degree), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),
@@ -179,7 +179,7 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
 
 
 def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest", extrap="constant", kind="+",
-               want_sim_q=True, ctx=None):
+               want_sim_q=True, ctx=None, out=None):
     """_adjustment.qdm_adjust -> (scen, sim_q)"""
     ctx = ctx or default_context()
     s = _Series(sim)
@@ -187,7 +187,7 @@ def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest",
     af = _table(af, s.dtype, (s.C, G, Q))
     quantiles = np.ascontiguousarray(quantiles, s.dtype)
     g = _gidx(gidx, s.T, G)
-    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    scen = out if out is not None else _out(ctx, s.dev, (s.C, s.T), s.dtype)
     sim_q = _out(ctx, s.dev, (s.C, s.T), np.float64) if want_sim_q else None
     check(load().xsdba_hip_qdm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
                                       _vp(af), _vp(quantiles), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
