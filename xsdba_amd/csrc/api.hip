@@ -397,7 +397,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     if ((rc = stage_out(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &osc))) return rc;
 
     // generic (cell, group)-row kernel; `cells` (device list of n_list cell ids) restricts it to a subset
-    auto launch_rows = [&](const int *cells, int64_t n_list) -> int {
+    auto launch_rows = [&](const int *cells, const int *n_cells_dev, int64_t n_blocks_or_cells) -> int {
         int P = 2;
         while (P < pl->max_row) P <<= 1;
         int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
@@ -405,9 +405,10 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         int rc2;
         if ((rc2 = set_lds(xs::k_train_rows<R>, lds, ctx, "the row sort"))) return rc2;
         LaunchScope ls(ctx, "k_train_rows");
-        hipLaunchKernelGGL(xs::k_train_rows<R>, dim3((unsigned)(n_list * G)), dim3(NT), lds, ctx->stream,
+        const int64_t grid = cells ? n_blocks_or_cells : n_blocks_or_cells * G;
+        hipLaunchKernelGGL(xs::k_train_rows<R>, dim3((unsigned)grid), dim3(NT), lds, ctx->stream,
                            (const R *)s0.dev, (const R *)s1.dev, s0.st, s0.sc, pl->d_row_ptr, pl->d_row_idx, G,
-                           (const R *)dq, Q, (int)kind, mode, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, P, cells);
+                           (const R *)dq, Q, (int)kind, mode, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, P, cells, n_cells_dev);
         return check_launch("k_train_rows");
     };
     bool fast = false;
@@ -436,13 +437,12 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})
                                                                           : go(std::integral_constant<int, 11>{});
             if (rc) return rc;
-            int nflag = 0;  // cells whose shortcut assumptions failed (rare) are redone by the generic kernel
-            HIP_TRY(hipMemcpyAsync(&nflag, flag_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            if (nflag > 0 && (rc = launch_rows(flag_list, nflag))) return rc;
+            // cells whose shortcut assumptions failed (rare) are redone by the generic kernel: a small fixed grid
+            // walks the flagged rows, reading the count on the device (no host round trip, the call stays async)
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
         }
     }
-    if (!fast && (rc = launch_rows(nullptr, C))) return rc;
+    if (!fast && (rc = launch_rows(nullptr, nullptr, C))) return rc;
     if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
     return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
 }

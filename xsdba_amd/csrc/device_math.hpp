@@ -96,9 +96,9 @@ __device__ __forceinline__ int ext_row(int rr, int G) { return rr == 0 ? G - 1 :
 // (slope in the table dtype; evaluation in float64 when the abscissa is float64, the QDM path).
 template <typename R>
 __device__ __forceinline__ R interp1d_eval(double x, bool x_is_double, const R *xs, const R *ys, int n, R yfirst,
-                                           R ylast, int interp, int extrap, int *node)
+                                           R ylast, int interp, int extrap, int &node)
 {
-    if (node) *node = -1;
+    node = -1;
     if (x != x || n == 0) return nan_of<R>();
     if (x < (double)xs[0]) return extrap == 0 ? yfirst : nan_of<R>();
     if (x > (double)xs[n - 1]) return extrap == 0 ? ylast : nan_of<R>();
@@ -109,7 +109,7 @@ __device__ __forceinline__ R interp1d_eval(double x, bool x_is_double, const R *
             R b = xs[mid] / (R)2.0 + xs[mid + 1] / (R)2.0;
             if ((double)b < x) lo = mid + 1; else hi = mid;
         }
-        if (node) *node = lo;
+        node = lo;
         return ys[lo];
     }
     if (n == 1) return nan_of<R>();
@@ -139,9 +139,9 @@ template <typename R> __device__ __forceinline__ double row_nearest(double x, co
 // Rows are visited outward (r, r-1, r+1, r-2, ...) while dr^2 < best; exact distance ties keep the
 // first visited node (cKDTree's choice at ties is implementation-defined).
 template <typename R>
-__device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R> &ct, int extrap, int *node)
+__device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R> &ct, int extrap, int &node)
 {
-    if (node) *node = -1;
+    node = -1;
     if (x != x || !ct.any_valid) return nan_of<R>();
     const int G = ct.G, Q = ct.Q, r = g0 + 1;
     if (x < ct.xfirst[g0]) return extrap == 0 ? ct.yfirst[g0] : nan_of<R>();
@@ -159,7 +159,7 @@ __device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R>
             if (n == 0) continue;
             int w;
             double d2 = row_nearest<R>(x, ct.xs + (size_t)g * Q, n, &w) + d2r;
-            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; if (node) *node = rr * Q + w; }
+            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
         }
     }
     return val;
@@ -167,11 +167,11 @@ __device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R>
 
 template <typename R>
 __device__ __forceinline__ R celltab_eval(const CellTab<R> &ct, double x, bool x_is_double, int g0, int interp,
-                                          int extrap, int *node)
+                                          int extrap, int &node)
 {
     if (ct.G == 1)
         return interp1d_eval<R>(x, x_is_double, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, node);
-    if (g0 < 0) { if (node) *node = -1; return nan_of<R>(); }
+    if (g0 < 0) { node = -1; return nan_of<R>(); }
     return interp2d_nearest<R>(x, g0, ct, extrap, node);
 }
 

@@ -77,7 +77,7 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, int G,
                              const R *__restrict__ q, int Q, int kind, int mode, R *__restrict__ af,
                              R *__restrict__ out_hq, R *__restrict__ scaling, int P_max,
-                             const int *__restrict__ cell_list)
+                             const int *__restrict__ cell_list, const int *__restrict__ n_list_dev)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -87,7 +87,10 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
     R *vals = reinterpret_cast<R *>(keys);
     R *rq = reinterpret_cast<R *>(keys + P_max);
 
-    const int64_t b = blockIdx.x;
+    // full mode: one (cell, group) row per block.  subset mode (cell_list): the rows of the *n_list_dev flagged
+    // cells are walked grid-stride, the count being read on the device so that the host never has to wait for it
+    const int64_t total = n_list_dev ? (int64_t)(*n_list_dev) * G : (int64_t)gridDim.x;
+    for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
     const int64_t ci = b / G;
     const int g = (int)(b - ci * G);
     const int64_t c = cell_list ? (int64_t)cell_list[ci] : ci;  // subset mode: redo the cells k_train_cell flagged
@@ -138,6 +141,8 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
         __syncthreads();
     }
     if (mode == 2 && threadIdx.x == 0) scaling[(size_t)c * G + g] = get_corr<R>(mu[1], mu[0], kind);
+    __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -243,7 +248,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                 v = apply_corr<R>(v, invert<R>(tr, kind), kind);
             }
             int nd;
-            R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, node ? &nd : nullptr);
+            R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, nd);
             R y = kind ? apply_corr<R>(v, a, kind) : a;
             if (scaling) y = apply_corr<R>(y, tr, kind);
             o[t * ost] = y;
@@ -379,7 +384,8 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         }
         if (sim_q) sim_q[c * osc + t * ost] = sq;
         if (af) {
-            R a = celltab_eval<R>(ct, sq, true, G > 1 ? g : 0, interp, extrap, nullptr);
+            int nd_unused;
+            R a = celltab_eval<R>(ct, sq, true, G > 1 ? g : 0, interp, extrap, nd_unused);
             scen[c * osc + t * ost] = apply_corr<R>(v, a, kind);
         }
     }
