@@ -61,7 +61,7 @@ template <int EPT> struct CellCfg {
     // select view of the union
     static constexpr size_t off_rank = off_union;
     static constexpr size_t off_bits = off_rank + (size_t)TPAD * 2;
-    static constexpr size_t sel_end = off_bits + (size_t)NWAVE * BITW * 4;
+    static constexpr size_t sel_end = off_bits + (size_t)2 * NWAVE * BITW * 4;  // two group streams per wave
     static constexpr size_t off_misc = ((sort_end > sel_end ? sort_end : sel_end) + 15) & ~(size_t)15;
     static constexpr size_t lds_bytes = off_misc + 64 * 8;  // reduction scratch
 };
@@ -198,28 +198,35 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
         for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
         __syncthreads();
+        if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
 
-        // ---------------- C. per-wave group chunks: membership bit-vector + select ----------------
-        const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
-        const int g_begin = wid * gpw, g_end = min(G, g_begin + gpw);
-        uint32_t *bits = bits_all + wid * BITW;
-        for (int i = lane; i < BITW; i += 64) bits[i] = 0u;
+        // ---------------- C. membership bit-vectors in rank space + select ----------------
+        // The groups are cut into 2*NWAVE contiguous chunks; every wave walks TWO chunks in lock-step, one per
+        // half-wave (lanes 0-31: chunk A, lanes 32-63: chunk B), each with its own bit-vector.  Lane k of a half
+        // serves quantile k: it selects the lower neighbour, then finds the upper one as the next set bit.
+        constexpr int NCH = 2 * Cfg::NWAVE;
+        const int gpc = (G + NCH - 1) / NCH;
+        const int half = lane >> 5;
+        const int gA0 = min(G, (2 * wid) * gpc), gA1 = min(G, gA0 + gpc);
+        const int gB0 = min(G, (2 * wid + 1) * gpc), gB1 = min(G, gB0 + gpc);
+        uint32_t *bitsA = bits_all + (2 * wid) * BITW, *bitsB = bitsA + BITW;
+        for (int i = lane; i < 2 * BITW; i += 64) bitsA[i] = 0u;
         lds_wave_fence();
-        double gsum = 0.0;
-        // software prefetch of the next group's toggle list (first 64 entries): its L2 latency hides under the
-        // current group's select
-        int pre_t = -1, pre_len = 0, pre_base = 0;
-        if (g_begin + 1 < g_end) {
-            pre_base = tog_ptr[g_begin];
-            pre_len = tog_ptr[g_begin + 1] - pre_base;
-            pre_t = lane < pre_len ? tog_idx[pre_base + lane] : -1;
-        }
-        // quantile-index math is a function of (n, k) only: cached while n does not change between groups
-        int n_prev = -1, c_case = 3, c_lo = 0;
+        const uint32_t *bits_h = half ? bitsB : bitsA;
+        double gsumA = 0.0, gsumB = 0.0;
+        // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select
+        int preA = -1, preA_len = 0, preA_base = 0, preB = -1, preB_len = 0, preB_base = 0;
+        if (gA0 + 1 < gA1) { preA_base = tog_ptr[gA0]; preA_len = tog_ptr[gA0 + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
+        if (gB0 + 1 < gB1) { preB_base = tog_ptr[gB0]; preB_len = tog_ptr[gB0 + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
+        // quantile-index math depends on (n, k) only: cached while both halves keep their n
+        int nA_prev = -1, nB_prev = -1, c_case = 3, c_lo = 0;
         float c_gamma = 0.f;
-        for (int g = g_begin; g < g_end; g++) {
-            double dloc = 0.0;
-            auto toggle = [&](int t) {
+        const int n_iter = max(gA1 - gA0, gB1 - gB0);
+        for (int it = 0; it < n_iter; it++) {
+            const int gA = gA0 + it, gB = gB0 + it;
+            const bool vA = gA < gA1, vB = gB < gB1;
+            double dlocA = 0.0, dlocB = 0.0;
+            auto toggle = [&](uint32_t *bits, int t, double &dloc) {
                 int r = rank[t];
                 if (r < nvalid) {
                     uint32_t m = 1u << (r & 31);
@@ -227,71 +234,78 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     if (mode == 2) { float v = from_key(keys[t]); dloc += (old & m) ? -(double)v : (double)v; }
                 }
             };
-            if (g == g_begin) {
-                const int *list = row_sorted + row_ptr[g];
-                const int len = row_ptr[g + 1] - row_ptr[g];
-                for (int i = lane; i < len; i += 64) toggle(list[i]);
-            } else {
-                const int t0 = pre_t, len = pre_len, lbase = pre_base;
-                if (g + 1 < g_end) {
-                    pre_base = tog_ptr[g];
-                    pre_len = tog_ptr[g + 1] - pre_base;
-                    pre_t = lane < pre_len ? tog_idx[pre_base + lane] : -1;
+            if (it == 0) {
+                // initial build of both vectors from their row lists: the index loads of 8 rounds are issued
+                // together so that one L2 latency covers 512 entries
+                auto build = [&](uint32_t *bits, int g, double &dloc) {
+                    const int *l = row_sorted + row_ptr[g];
+                    const int len = row_ptr[g + 1] - row_ptr[g];
+                    for (int i0 = 0; i0 < len; i0 += 512) {
+                        int ts[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (ts[u] >= 0) toggle(bits, ts[u], dloc);
+                    }
+                };
+                if (vA) build(bitsA, gA, dlocA);
+                if (vB) build(bitsB, gB, dlocB);
+            } else if (debug_phase != 4) {
+                if (vA) {
+                    const int t0 = preA, len = preA_len, lb = preA_base;
+                    if (gA + 1 < gA1) { preA_base = tog_ptr[gA]; preA_len = tog_ptr[gA + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
+                    if (t0 >= 0) toggle(bitsA, t0, dlocA);
+                    for (int i = lane + 64; i < len; i += 64) toggle(bitsA, tog_idx[lb + i], dlocA);
                 }
-                if (t0 >= 0) toggle(t0);
-                for (int i = lane + 64; i < len; i += 64) toggle(tog_idx[lbase + i]);
+                if (vB) {
+                    const int t0 = preB, len = preB_len, lb = preB_base;
+                    if (gB + 1 < gB1) { preB_base = tog_ptr[gB]; preB_len = tog_ptr[gB + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
+                    if (t0 >= 0) toggle(bitsB, t0, dlocB);
+                    for (int i = lane + 64; i < len; i += 64) toggle(bitsB, tog_idx[lb + i], dlocB);
+                }
             }
             lds_wave_fence();
-            int cl = 0;
+            if (debug_phase == 6) { if (lane == 0 && bitsA[3] == 12345u) out_hq[0] = 1.f; break; }
+            // per-lane member counts of both vectors, packed (A low 16 bits, B high 16 bits): ONE prefix scan
+            int clp = 0;
 #pragma unroll
-            for (int j = 0; j < WPL; j++) cl += __popc(bits[lane * WPL + j]);
-            const int incl = wave_incl_scan(cl);
-            const int excl = incl - cl;
-            const int n = __builtin_amdgcn_readlane(incl, 63);
+            for (int j = 0; j < WPL; j++) clp += __popc(bitsA[lane * WPL + j]) + (__popc(bitsB[lane * WPL + j]) << 16);
+            const int inclp = wave_incl_scan(clp);
+            const int exclp = inclp - clp;
+            const int totp = __builtin_amdgcn_readlane(inclp, 63);
+            const int nA = totp & 0xFFFF, nB = (int)((unsigned)totp >> 16);
+            const int n = half ? nB : nA;
+            const int g = half ? gB : gA;
+            const bool vh = half ? vB : vA;
             float mu = 0.f, inv = 0.f;
             if (mode == 2) {
-                gsum += wave_sum(dloc);
-                gsum = __shfl(gsum, 0, 64);
-                mu = n ? (float)(gsum / (double)n) : __builtin_nanf("");
+                gsumA += wave_sum(dlocA); gsumA = __shfl(gsumA, 0, 64);
+                gsumB += wave_sum(dlocB); gsumB = __shfl(gsumB, 0, 64);
+                const double gs = half ? gsumB : gsumA;
+                mu = n ? (float)(gs / (double)n) : __builtin_nanf("");
                 inv = invert<float>(mu, kind);
-                if (n && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
+                if (vh && n && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
             }
-            const size_t obase = ((size_t)c * G + g) * (size_t)Q;
-            for (int kb = 0; kb < Q; kb += 32) {
-                const int k = kb + (lane & 31);
-                const bool act = k < Q;
-                const bool hi_lane = lane >= 32;
-                int casek, lo;  // casek 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
-                float gamma;
-                if (kb == 0 && n == n_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
-                else {
-                    const double qk = (double)q[act ? k : 0];
-                    const double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
-                    lo = 0; gamma = 0.f;
-                    if (n == 0) casek = 3;
-                    else if (vi != vi || vi >= (double)(n - 1)) { casek = 1; lo = n - 1; }
-                    else if (vi < 0.0) { casek = 2; lo = 0; }
-                    else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
-                    if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
-                }
-                const int j = (casek == 0 && hi_lane) ? lo + 1 : lo;
-                // ---- select(j): owner lane (binary search over the lane prefix counts) ----
-                int L = 0, eL = 0;
+            const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
+            // rank-space position of the j-th member of this half's vector
+            auto select_rank = [&](int j, int &L, int &wi, int &pos, uint32_t (&wv)[WPL]) {
+                L = 0;
+                int eL = 0;
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) {
                     int cand = L + s;
-                    int e = __shfl(excl, cand & 63, 64);
+                    int ep = __shfl(exclp, cand & 63, 64);
+                    int e = half ? (int)((unsigned)ep >> 16) : (ep & 0xFFFF);
                     bool ok = cand < 64 && e <= j;
                     L = ok ? cand : L;
                     eL = ok ? e : eL;
                 }
                 int rem = j - eL;
-                // ---- word inside the owner's WPL words: all loads first, then a branch-free prefix compare ----
-                const uint32_t *wp = bits + L * WPL;
-                uint32_t wv[WPL];
+                const uint32_t *wp = bits_h + L * WPL;
 #pragma unroll
                 for (int i = 0; i < WPL; i++) wv[i] = wp[i];
-                int wi = 0, sub = 0, run = 0;
+                int sub = 0, run = 0;
+                wi = 0;
 #pragma unroll
                 for (int i = 0; i < WPL - 1; i++) {
                     int ci = __popc(wv[i]);
@@ -304,8 +318,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 uint32_t w = wv[0];
 #pragma unroll
                 for (int i = 1; i < WPL; i++) w = (wi == i) ? wv[i] : w;
-                // ---- bit inside the word ----
-                int pos = 0;
+                pos = 0;
 #pragma unroll
                 for (int s = 16; s > 0; s >>= 1) {
                     int cw = __popc(w & ((1u << s) - 1u));
@@ -314,11 +327,57 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     w = ge ? (w >> s) : w;
                     pos += ge ? s : 0;
                 }
+            };
+            auto value_at = [&](int L, int wi, int pos) {
                 int rsel = min((L * WPL + wi) * 32 + pos, TPAD - 1);
                 int id = min((int)sorted[rsel], TPAD - 1);
-                float v = from_key(keys[id]);
-                if (mode == 2) v = apply_corr<float>(v, inv, kind);
-                const float vhi = __shfl(v, (lane & 31) + 32, 64);
+                return from_key(keys[id]);
+            };
+            if (debug_phase == 3 || debug_phase == 4) { if (n == 12345 && lane == 0) out_hq[obase] = (float)exclp; continue; }
+            for (int kb = 0; kb < Q; kb += 32) {
+                const int k = kb + (lane & 31);
+                const bool act = vh && k < Q;
+                int casek, lo;  // casek 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
+                float gamma;
+                if (kb == 0 && nA == nA_prev && nB == nB_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
+                else {
+                    const double qk = (double)q[k < Q ? k : 0];
+                    const double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
+                    lo = 0; gamma = 0.f;
+                    if (n == 0) casek = 3;
+                    else if (vi != vi || vi >= (double)(n - 1)) { casek = 1; lo = n - 1; }
+                    else if (vi < 0.0) { casek = 2; lo = 0; }
+                    else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
+                    if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
+                }
+                int L, wi, pos;
+                uint32_t wv[WPL];
+                select_rank(lo, L, wi, pos, wv);
+                float v = value_at(L, wi, pos);
+                // upper neighbour = next set bit: same word, then the owner lane's following words
+                uint32_t wfull = wv[0];
+#pragma unroll
+                for (int i = 1; i < WPL; i++) wfull = (wi == i) ? wv[i] : wfull;
+                uint32_t rest = pos < 31 ? (wfull >> (pos + 1)) : 0u;
+                bool found = rest != 0u;
+                int hwi = wi, hpos = pos + 1 + (found ? __ffs((int)rest) - 1 : 0);
+#pragma unroll
+                for (int i = 1; i < WPL; i++) {
+                    bool take = !found && i > wi && wv[i] != 0u;
+                    hwi = take ? i : hwi;
+                    hpos = take ? __ffs((int)wv[i]) - 1 : hpos;
+                    found = found || take;
+                }
+                int hL = L;
+                const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words (rare)
+                if (__any(need_slow)) {
+                    int L2, wi2, pos2;
+                    uint32_t wv2[WPL];
+                    select_rank(lo + 1, L2, wi2, pos2, wv2);
+                    if (need_slow) { hL = L2; hwi = wi2; hpos = pos2; }
+                }
+                float vhi = casek == 0 ? value_at(hL, hwi, hpos) : v;
+                if (mode == 2) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
                 float res;
                 if (casek == 3) res = __builtin_nanf("");
                 else if (casek != 0) res = v;
@@ -327,9 +386,9 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     float diff = right - left;
                     if (gamma >= 0.5f) res = (float)((double)right - (double)diff * (1.0 - (double)gamma));
                     else res = left + diff * gamma;
-                    if (res != res) flag_cell = true;  // inf - inf: needs a[n-1]; the generic kernel redoes the cell
+                    if (res != res && act) flag_cell = true;  // inf - inf: needs a[n-1]; the generic kernel redoes the cell
                 }
-                if (act && !hi_lane) {
+                if (act) {
                     if (mode == 0) out_hq[obase + k] = res;
                     else if (arr == 0) af[obase + k] = res;  // ref_q parked in the af buffer until the hist pass
                     else {
@@ -338,8 +397,8 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     }
                 }
             }
-            n_prev = n;
-            if (mode == 2 && lane == 0) {
+            nA_prev = nA; nB_prev = nB;
+            if (mode == 2 && vh && (lane & 31) == 0) {
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;
                 else scaling[(size_t)c * G + g] = get_corr<float>(mu, scaling[(size_t)c * G + g], kind);
             }
