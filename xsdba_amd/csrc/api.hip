@@ -78,11 +78,12 @@ struct xsdba_hip_ctx {
     std::vector<hipEvent_t> event_pool;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int lds_limit = 160 * 1024;
+    int n_cu = 256;
 };
 
 namespace {
 
-enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_FLAGS, S_NSLOTS };
+enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_FLAGS, S_PARK, S_NSLOTS };
 
 int ensure(xsdba_hip_ctx *ctx, int slot, size_t bytes, void **out)
 {
@@ -426,12 +427,17 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 size_t lds = xs::CellCfg<EPT>::lds_bytes;
                 int rc2;
                 if ((rc2 = set_lds(xs::k_train_cell<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
+                // one resident block per CU (LDS-bound) x 4 for dynamic balance; each block owns a slice of `park`
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
+                void *park;
+                if ((rc2 = ensure(ctx, S_PARK, sizeof(float) * (size_t)nblk * ((size_t)G * Q + G), &park))) return rc2;
                 LaunchScope ls(ctx, "k_train_cell");
-                hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3((unsigned)C), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
                                    pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
                                    (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list,
-                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0, C,
+                                   (float *)park);
                 return check_launch("k_train_cell");
             };
             rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})
@@ -448,6 +454,27 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
 }
 
 // ---- adjust -----------------------------------------------------------------------------------------
+// threads per block of the adjust kernels (XSDBA_HIP_ADJ_THREADS overrides, for tuning runs)
+inline unsigned adj_threads()
+{
+    const char *e = getenv("XSDBA_HIP_ADJ_THREADS");
+    int v = e ? atoi(e) : 512;  // 512: measured best on MI355X (5.8 ms vs 10.6 at 256 / 6.5 at 1024, 64800 cells doy tables)
+    return (unsigned)(v >= 64 && v <= 1024 ? (v / 64) * 64 : 512);
+}
+
+inline unsigned qdm_threads()
+{
+    const char *e = getenv("XSDBA_HIP_QDM_THREADS");
+    int v = e ? atoi(e) : 1024;
+    return (unsigned)(v >= 64 && v <= 1024 ? (v / 64) * 64 : 1024);
+}
+inline unsigned trend_threads()
+{
+    const char *e = getenv("XSDBA_HIP_TREND_THREADS");
+    int v = e ? atoi(e) : 512;
+    return (unsigned)(v >= 64 && v <= 1024 ? (v / 64) * 64 : 512);
+}
+
 template <typename R>
 int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *af, const R *hq, int G, int Q,
                      const int *d_gidx, int interp, int extrap, char kind, R *scen_cm, int *node, const R *scaling,
@@ -459,7 +486,7 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
     if (tab <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_qm_adjust<R, true>, tab, ctx, "the factor table"))) return rc;
         LaunchScope ls(ctx, name);
-        hipLaunchKernelGGL((xs::k_qm_adjust<R, true>), dim3((unsigned)C), dim3(256), tab, ctx->stream, (const R *)s.dev, T, C,
+        hipLaunchKernelGGL((xs::k_qm_adjust<R, true>), dim3((unsigned)C), dim3(adj_threads()), tab, ctx->stream, (const R *)s.dev, T, C,
                            s.st, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node,
                            scaling, trend_cm, (unsigned char *)nullptr, (size_t)0);
     } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
@@ -508,7 +535,7 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     int rc;
     if ((rc = set_lds(xs::k_group_trend<R>, lds, ctx, "the detrending series"))) return rc;
     LaunchScope ls(ctx, "k_group_trend");
-    hipLaunchKernelGGL(xs::k_group_trend<R>, dim3((unsigned)C), dim3(256), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
+    hipLaunchKernelGGL(xs::k_group_trend<R>, dim3((unsigned)C), dim3(trend_threads()), lds, ctx->stream, (const R *)s.dev, T, s.st, s.sc,
                        scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr, pl->d_mem_idx, d_tnum, degree, trend_cm);
     return check_launch("k_group_trend");
 }
@@ -592,7 +619,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     if (base + tab <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_qdm_adjust<R, true>, base + tab, ctx, "the ranking series + factor table"))) return rc;
         LaunchScope ls(ctx, "k_qdm_adjust");
-        hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3((unsigned)C), dim3(256), base + tab, ctx->stream, (const R *)s.dev,
+        hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3((unsigned)C), dim3(qdm_threads()), base + tab, ctx->stream, (const R *)s.dev,
                            T, C, s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap,
                            (int)kind, (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)nullptr,
                            (size_t)0);
@@ -603,7 +630,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         void *scratch;
         if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
         LaunchScope ls(ctx, "k_qdm_adjust");
-        hipLaunchKernelGGL((xs::k_qdm_adjust<R, false>), dim3(nblk), dim3(256), base, ctx->stream, (const R *)s.dev, T, C, s.st,
+        hipLaunchKernelGGL((xs::k_qdm_adjust<R, false>), dim3(nblk), dim3(qdm_threads()), base, ctx->stream, (const R *)s.dev, T, C, s.st,
                            s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap, (int)kind,
                            (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)scratch, tab);
         if ((rc = check_launch("k_qdm_adjust"))) return rc;
@@ -659,6 +686,7 @@ API int xsdba_hip_create(int device, xsdba_hip_ctx **out)
     if (!ctx) return fail(XSDBA_E_NOMEM, "out of host memory");
     ctx->device = device;
     ctx->lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor > 0 ? (int)std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, 160 * 1024) : 64 * 1024;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ctx; return fail((int)e, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     (void)hipEventCreate(&ctx->t0);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
     const float *__restrict__ q, int Q, int kind, int mode, float *af, float *__restrict__ out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase)
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C, float *park)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW, BS = Cfg::BS;
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int64_t c = blockIdx.x;
+    // persistent-style grid: each block walks its cells grid-stride; `park` gives every block a private slice
+    // ([G][Q] ref_q + [G] mean) that stays L2-resident, so the ref pass results never travel to HBM
+    float *park_q = park + (size_t)blockIdx.x * ((size_t)G * Q + G), *park_mu = park_q + (size_t)G * Q;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
     const int npass_arr = mode == 0 ? 1 : 2;
     bool flag_cell = false;
 
@@ -390,17 +393,17 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 }
                 if (act) {
                     if (mode == 0) out_hq[obase + k] = res;
-                    else if (arr == 0) af[obase + k] = res;  // ref_q parked in the af buffer until the hist pass
+                    else if (arr == 0) park_q[(size_t)g * Q + k] = res;  // ref_q parked until the hist pass
                     else {
                         out_hq[obase + k] = res;
-                        af[obase + k] = get_corr<float>(res, af[obase + k], kind);
+                        af[obase + k] = get_corr<float>(res, park_q[(size_t)g * Q + k], kind);
                     }
                 }
             }
             nA_prev = nA; nB_prev = nB;
             if (mode == 2 && vh && (lane & 31) == 0) {
-                if (arr == 0) scaling[(size_t)c * G + g] = mu;
-                else scaling[(size_t)c * G + g] = get_corr<float>(mu, scaling[(size_t)c * G + g], kind);
+                if (arr == 0) park_mu[g] = mu;
+                else scaling[(size_t)c * G + g] = get_corr<float>(mu, park_mu[g], kind);
             }
         }
         __syncthreads();  // all waves are done with keys / sorted / rank before the next array reuses them
@@ -411,6 +414,8 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         int slot = atomicAdd(flag_count, 1);
         flag_list[slot] = (int)c;
     }
+    flag_cell = false;
+    }  // cell loop
 }
 
 }  // namespace xs
