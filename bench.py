@@ -199,7 +199,7 @@ def main():
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9
         roof = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, C, T, dom),
             "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
             "kernels": {k: {"count": v["count"], "avg_ms": round(v["total_ms"] / v["count"], 4)} for k, v in kern.items()},
         }
@@ -225,6 +225,22 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(workload, cells, days, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very configuration
+    (profiles/*traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None when
+    no PMC run matches the workload being benchmarked."""
+    for f in sorted((ROOT / "profiles").glob("*traffic*.json"), reverse=True):
+        try:
+            d = json.loads(f.read_text())
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("cells") == cells and d.get("days") == days:
+            k = d.get("kernels", {}).get(kernel.split("(")[0])
+            if k:
+                return k["traffic_bytes"]
+    return None
 
 
 def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major):

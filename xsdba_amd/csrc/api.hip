@@ -427,17 +427,13 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 size_t lds = xs::CellCfg<EPT>::lds_bytes;
                 int rc2;
                 if ((rc2 = set_lds(xs::k_train_cell<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
-                // one resident block per CU (LDS-bound) x 4 for dynamic balance; each block owns a slice of `park`
-                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
-                void *park;
-                if ((rc2 = ensure(ctx, S_PARK, sizeof(float) * (size_t)nblk * ((size_t)G * Q + G), &park))) return rc2;
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);  // blocks walk the cells grid-stride
                 LaunchScope ls(ctx, "k_train_cell");
                 hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
                                    pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
                                    (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list,
-                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0, C,
-                                   (float *)park);
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0, C);
                 return check_launch("k_train_cell");
             };
             rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})

@@ -70,8 +70,8 @@ template <int EPT>
 __global__ __launch_bounds__(1024) void k_train_cell(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
-    const float *__restrict__ q, int Q, int kind, int mode, float *af, float *__restrict__ out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C, float *park)
+    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW, BS = Cfg::BS;
@@ -87,15 +87,15 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // persistent-style grid: each block walks its cells grid-stride; `park` gives every block a private slice
-    // ([G][Q] ref_q + [G] mean) that stays L2-resident, so the ref pass results never travel to HBM
-    float *park_q = park + (size_t)blockIdx.x * ((size_t)G * Q + G), *park_mu = park_q + (size_t)G * Q;
+    // persistent-style grid: each block walks its cells grid-stride
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
     const int npass_arr = mode == 0 ? 1 : 2;
     bool flag_cell = false;
 
     for (int arr = 0; arr < npass_arr; arr++) {
-        const float *x = (arr == 0 ? x0 : x1) + c * sc;
+        // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
+        // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
+        const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
         // ---------------- A. load, keys, range ----------------
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -393,17 +393,14 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 }
                 if (act) {
                     if (mode == 0) out_hq[obase + k] = res;
-                    else if (arr == 0) park_q[(size_t)g * Q + k] = res;  // ref_q parked until the hist pass
-                    else {
-                        out_hq[obase + k] = res;
-                        af[obase + k] = get_corr<float>(res, park_q[(size_t)g * Q + k], kind);
-                    }
+                    else if (arr == 0) out_hq[obase + k] = res;  // hist_q
+                    else af[obase + k] = get_corr<float>(out_hq[obase + k], res, kind);  // res = ref_q
                 }
             }
             nA_prev = nA; nB_prev = nB;
             if (mode == 2 && vh && (lane & 31) == 0) {
-                if (arr == 0) park_mu[g] = mu;
-                else scaling[(size_t)c * G + g] = get_corr<float>(mu, park_mu[g], kind);
+                if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced below
+                else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
             }
         }
         __syncthreads();  // all waves are done with keys / sorted / rank before the next array reuses them
