@@ -81,16 +81,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = None
+    backend = os.environ.get("XSDBA_BENCH_BACKEND", "nccl")  # "gloo": code-path check of N>1 on a 1-GPU box
+    from xsdba_amd import _lib as xlib
+
+    ndev = max(xlib.device_count(), 1)
+    device = local_rank % ndev
     if world > 1:
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend)
+    tdev = "cuda" if backend == "nccl" else "cpu"
 
     from xsdba_amd import hip
 
-    ctx = hip.Context(local_rank)
+    ctx = hip.Context(device)
     method, group, W, kind, gen = WORKLOADS[args.workload]
     C, T, Q = args.cells, args.days, args.nquantiles
     gidx, G = group_index(group, T)
@@ -135,7 +144,8 @@ def main():
         if dist is not None:
             import torch
 
-            torch.cuda.synchronize()
+            if tdev == "cuda":
+                torch.cuda.synchronize()
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -150,7 +160,7 @@ def main():
             free(outs)
         outs = step()
     ctx.synchronize()
-    if dist is not None:
+    if dist is not None and tdev == "cuda":
         import torch
 
         torch.cuda.synchronize()
@@ -160,30 +170,33 @@ def main():
     if dist is not None:
         import torch
 
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     gather_ms = None
     if dist is not None and args.gather:
-        import torch
-
-        scen_dev = outs[-1] if method != "dqm" else outs[3]
-        scen_t = torch.empty((C, T), dtype=torch.float32, device="cuda")
-        # device-to-device copy of the library's buffer into a torch tensor, then one RCCL gather over xGMI
+        # the one collective of the path: the final gather of the per-rank scen blocks to rank 0 (RCCL over xGMI
+        # with backend nccl); timed separately, never part of `value`
         import ctypes
 
-        from xsdba_amd._lib import check, load
+        import torch
 
+        from xsdba_amd._lib import check, load
+        from xsdba_amd.sharding import gather_cells
+
+        scen_dev = outs[-1] if method != "dqm" else outs[3]
+        scen_t = torch.empty((C, T), dtype=torch.float32, device=tdev)
         check(load().xsdba_hip_memcpy_d2h(ctx.handle, ctypes.c_void_p(scen_t.data_ptr()), ctypes.c_void_p(scen_dev.ptr),
-                                          ctypes.c_size_t(scen_dev.nbytes)), "d2d copy")
-        torch.cuda.synchronize()
-        dist.barrier()
+                                          ctypes.c_size_t(scen_dev.nbytes)), "copy of scen into the collective's buffer")
+        barrier()
         g0 = time.perf_counter()
-        gl = [torch.empty_like(scen_t) for _ in range(world)] if rank == 0 else None
-        dist.gather(scen_t, gl, dst=0)
-        torch.cuda.synchronize()
+        full = gather_cells(scen_t, C * world, dst=0)
+        if tdev == "cuda":
+            torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert tuple(full.shape) == (C * world, T)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
