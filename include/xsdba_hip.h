@@ -90,6 +90,12 @@ int xsdba_hip_quantile_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int6
                               int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
                               int32_t window, const void *q, int32_t nq, void *out);
 
+/* ---- a5: nbutils.vecquantiles / _vecquantiles (nbutils.py:151-195): a different quantile for every row:
+ * out[c] = np.nanquantile(x[c, :], rnk[c]) as numba evaluates it (float64 linear interpolation between the
+ * closest ranks); NaN rnk or no valid value -> NaN.  Used by adapt_freq (_processing.py:107). */
+int xsdba_hip_vecquantiles(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
+                           int64_t stride_t, int64_t stride_c, const void *rnk, void *out);
+
 /* ---- a9: _adjustment.eqm_train (_adjustment.py:193-286), called by EmpiricalQuantileMapping._train and
  * QuantileDeltaMapping (adjustment.py:485-495, 674).  af = ref_q - hist_q or ref_q / hist_q. */
 int xsdba_hip_eqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t n_time,

@@ -195,3 +195,14 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1):
                                                 C.c_int(G), C.c_int(W), _p(tn), C.c_int(degree), _p(out), _i64(1),
                                                 _i64(T)), "polydetrend_trend")
     return out
+
+
+def vecquantiles(x, rnk):
+    x = np.asarray(x)
+    Cn, T = x.shape
+    r = np.ascontiguousarray(rnk, x.dtype).reshape(-1)
+    out = np.empty(Cn, x.dtype)
+    st, sc = _strides(x)
+    _check(lib().xsdba_oracle_vecquantiles(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(r), _p(out)),
+           "vecquantiles")
+    return out

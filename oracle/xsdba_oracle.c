@@ -271,3 +271,45 @@ API int xsdba_oracle_polydetrend_trend(const void *x, int dtype, int64_t T, int6
     plan_free(&pl);
     return 0;
 }
+
+/* nbutils._vecquantiles (nbutils.py:151-161): np.nanquantile(row, rnk) per row as numba evaluates it
+ * (numba/np/arraymath.py _collect_percentiles_inner; numba is not importable here, so this row is restated from
+ * numba's published algorithm: PARITY UNPINNED against the reference for this function; it is checked against
+ * numpy's nanquantile, which agrees to float64 rounding). */
+static double vecq_sorted(const double *a, int64_t n, double q)
+{
+    if (isnan(q) || n == 0) return NAN;
+    if (n == 1) return a[0];
+    double p = q * 100.0;
+    if (p == 100.0) return a[n - 1];
+    if (p == 0.0) return a[0];
+    double rank = 1.0 + (double)(n - 1) * (p / 100.0);
+    double f = floor(rank), m = rank - f;
+    int64_t lo = (int64_t)f - 1;
+    if (lo < 0) lo = 0;
+    if (lo > n - 2) lo = n - 2;
+    return a[lo] * (1.0 - m) + a[lo + 1] * m;
+}
+
+API int xsdba_oracle_vecquantiles(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                  const void *rnk, void *out)
+{
+#pragma omp parallel
+    {
+        double *buf = (double *)malloc(sizeof(double) * (size_t)(T > 0 ? T : 1));
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t c = 0; c < C; c++) {
+            int64_t n = 0;
+            for (int64_t t = 0; t < T; t++) {
+                double v = dtype == 0 ? (double)((const float *)x)[c * sc + t * st] : ((const double *)x)[c * sc + t * st];
+                if (!isnan(v)) buf[n++] = v;
+            }
+            quick_sort_f64(buf, n);
+            double q = dtype == 0 ? (double)((const float *)rnk)[c] : ((const double *)rnk)[c];
+            double r = vecq_sorted(buf, n, q);
+            if (dtype == 0) ((float *)out)[c] = (float)r; else ((double *)out)[c] = r;
+        }
+        free(buf);
+    }
+    return 0;
+}

@@ -400,3 +400,19 @@ def test_fast_train_fallback_cells(hip, train_kernel):
             assert_close(sc, esc, rtol=5e-7, atol=1e-4, what=f"dqm scaling {kind}")
             assert_close(hq, ehq, rtol=5e-7, atol=1e-4, what=f"dqm hist_q {kind}")
             assert_close(af, eaf, rtol=2e-6, atol=2e-4, what=f"dqm af {kind}")
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_vecquantiles_vs_oracle(hip, dtype):
+    """nbutils.vecquantiles (a5): one quantile per row; NaN q, no valid value, a single value, q = 0 and 1"""
+    rng = np.random.default_rng(41)
+    x = rng.gamma(2.0, 3.0, (300, 930)).astype(dtype)
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[3] = np.nan
+    x[4, 1:] = np.nan
+    q = rng.random(300).astype(dtype)
+    q[7], q[8], q[9] = np.nan, 0.0, 1.0
+    got = hip.vecquantiles(x, q)
+    assert_close(got, oracle.vecquantiles(x, q), rtol=0.0, what="vecquantiles")
+    assert np.isnan(got[3]) and np.isnan(got[7]) and got[4] == x[4, 0]
+    assert got[8] == np.nanmin(x[8]) and got[9] == np.nanmax(x[9])

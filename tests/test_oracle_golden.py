@@ -200,3 +200,21 @@ def test_known_answer_qm(golden):
         assert_close(p, d[f"eqm_p_linear_{tag}"], rtol=1e-15, what="p vs reference kernel")
         middle = (d["u"] > 1e-2) & (d["u"] < 0.99)
         np.testing.assert_array_almost_equal(p[0][middle], y[middle], 1)
+
+
+def test_vecquantiles_matches_numpy():
+    # a5 (nbutils.py:151-161): numba's np.nanquantile == numpy's to float64 rounding (numba itself cannot run here)
+    import warnings
+
+    rng = np.random.default_rng(2)
+    x = rng.gamma(2, 3, (60, 777))
+    x[rng.random(x.shape) < 0.1] = np.nan
+    x[3] = np.nan
+    x[4, 1:] = np.nan
+    q = rng.random(60)
+    q[7], q[8], q[9] = np.nan, 0.0, 1.0
+    got = oracle.vecquantiles(x, q)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        exp = np.array([np.nanquantile(x[i], q[i]) if not np.isnan(q[i]) else np.nan for i in range(60)])
+    assert_close(got, exp, rtol=1e-13, what="vecquantiles vs numpy")

@@ -381,17 +381,17 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                void *scaling)
 {
     using U = typename xs::KeyOf<R>::U;
-    if (C <= 0 || Q <= 0 || !q || !hq || (mode && (!x1 || !af)) || (mode == 2 && !scaling)) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (C <= 0 || Q <= 0 || !q || !hq || ((mode == 1 || mode == 2) && (!x1 || !af)) || (mode == 2 && !scaling)) return fail(XSDBA_E_ARG, "null/empty argument");
     if ((int64_t)C * G > (1ll << 31) - 1) return fail(XSDBA_E_ARG, "n_cell * n_groups exceeds 2^31");
     int rc;
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
     SeriesIn s0, s1;
     if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x0, T, C, st, sc, &s0))) return rc;
-    if (mode && (rc = series_in<R>(ctx, S_IN1, S_CM1, x1, T, C, st, sc, &s1))) return rc;
+    if ((mode == 1 || mode == 2) && (rc = series_in<R>(ctx, S_IN1, S_CM1, x1, T, C, st, sc, &s1))) return rc;
     const void *dq;
-    if ((rc = stage_in(ctx, S_Q, q, (size_t)Q * sizeof(R), &dq))) return rc;
-    size_t tab = (size_t)C * G * Q * sizeof(R);
+    if ((rc = stage_in(ctx, S_Q, q, (size_t)(mode == 3 ? C : Q) * sizeof(R), &dq))) return rc;
+    size_t tab = (mode == 3 ? (size_t)C : (size_t)C * G * Q) * sizeof(R);
     OutStage oaf, ohq, osc;
     if ((rc = stage_out(ctx, S_TAB0, af, tab, &oaf))) return rc;
     if ((rc = stage_out(ctx, S_TAB1, hq, tab, &ohq))) return rc;
@@ -415,7 +415,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     bool fast = false;
     if constexpr (std::is_same<R, float>::value) {
         const char *force = getenv("XSDBA_HIP_TRAIN");  // "rows" pins the generic kernel (A/B runs, tests)
-        fast = pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
+        fast = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
         if (fast) {
             void *flags;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -922,4 +922,13 @@ API int xsdba_hip_synth_series(xsdba_hip_ctx *ctx, void *dst, int dtype, int64_t
                            array_id, seed, cell_offset, nan_cell_frac, nan_iid_frac);
     else return fail(XSDBA_E_ARG, "bad dtype");
     return check_launch("k_synth");
+}
+
+API int xsdba_hip_vecquantiles(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                               const void *rnk, void *out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (train_impl<float>(ctx, 3, x, nullptr, T, C, st, sc, nullptr, 1, 1, rnk, 1, '+', nullptr, out, nullptr)),
+                    (train_impl<double>(ctx, 3, x, nullptr, T, C, st, sc, nullptr, 1, 1, rnk, 1, '+', nullptr, out, nullptr)));
 }

@@ -75,6 +75,25 @@ template <typename R, typename Load> __device__ __forceinline__ R quantile_sorte
     return res;
 }
 
+// nbutils._vecquantiles (nbutils.py:151-161): `np.nanquantile(arr, rnk)` as numba implements it
+// (numba/np/arraymath.py, _collect_percentiles_inner): everything in float64; p = q*100; rank = 1 + (n-1)*(p/100);
+// f = floor(rank); m = rank - f; val = a[f-1]*(1-m) + a[f]*m; q = 0 / 1 -> min / max; one value -> that value;
+// no valid value or NaN q -> NaN.  The float64 result is stored in the data dtype.
+template <typename R, typename Load> __device__ __forceinline__ R vecquantile_sorted(Load a, int n, R q)
+{
+    if (q != q || n == 0) return nan_of<R>();
+    if (n == 1) return a(0);
+    double p = (double)q * 100.0;
+    if (p == 100.0) return a(n - 1);
+    if (p == 0.0) return a(0);
+    double rank = 1.0 + (double)(n - 1) * (p / 100.0);
+    double f = floor(rank);
+    double m = rank - f;
+    int lo = (int)f - 1;
+    lo = lo < 0 ? 0 : (lo > n - 2 ? n - 2 : lo);
+    return (R)((double)a(lo) * (1.0 - m) + (double)a(lo + 1) * m);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Interpolation of the trained factors on quantiles.  A cell's table lives in LDS as G rows of
 // compacted (x, y) pairs (NaN pairs removed in place, order kept) + per-row metadata; the cyclic

@@ -69,6 +69,7 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort(U *keys
 //   mode 1: EQM train: hist_q, af = corr(hist_q, ref_q)                   (_adjustment.py:253-286)
 //   mode 2: DQM train: rows normalised by their NaN-skipping mean first,  (_adjustment.py:150-190)
 //           scaling = corr(mean(hist), mean(ref))
+//   mode 3: out_hq[c] = np.nanquantile(row c, q[c])  (nbutils._vecquantiles :151-161; G must be 1)
 // grid.x = n_cell * n_groups (block b -> cell b / G, group b % G); dynamic LDS:
 //   [red: 2*(NT/64)+2 doubles][keys: P_max * sizeof(U)][rq: Q * sizeof(R)]
 // ---------------------------------------------------------------------------------------------
@@ -100,7 +101,7 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
     const size_t obase = ((size_t)c * G + g) * (size_t)Q;
 
     R mu[2] = {nan_of<R>(), nan_of<R>()};
-    const int npass = mode == 0 ? 1 : 2;
+    const int npass = (mode == 0 || mode == 3) ? 1 : 2;
     for (int pass = 0; pass < npass; pass++) {
         const R *x = (pass == 0 ? x0 : x1) + c * sc;
         R inv = (R)0;
@@ -129,6 +130,11 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
         block_sum_count(dummy, nvalid, red);  // also the barrier between key writes and the sort
         block_bitonic_sort<U>(keys, P);
         auto load = [&](int i) { return from_key(keys[i]); };
+        if (mode == 3) {  // nbutils._vecquantiles: one quantile per row, q[c] (NaN q -> NaN)
+            if (threadIdx.x == 0) out_hq[c] = vecquantile_sorted<R>(load, nvalid, q[c]);
+            __syncthreads();
+            continue;
+        }
         for (int k = threadIdx.x; k < Q; k += blockDim.x) {
             R v = quantile_sorted<R>(load, nvalid, q[k]);
             if (mode == 0) out_hq[obase + k] = v;

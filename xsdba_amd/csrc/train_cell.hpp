@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             const int shift = 4 * p;
             uint64_t cnt = 0;
             uint16_t ids[EPT];
-            uint64_t dgs = 0;
+            uint64_t dgs = 0, lrs = 0;
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 uint16_t id = src[tid * EPT + e];
@@ -152,6 +152,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 uint32_t d = (r >> shift) & 15u;
                 ids[e] = id;
                 dgs |= (uint64_t)d << (4 * e);
+                lrs |= ((cnt >> (4 * d)) & 15ull) << (4 * e);  // rank among this thread's earlier equal digits
                 cnt += 1ull << (4 * d);
             }
             const int pi = tid + (tid >> 4);
@@ -189,8 +190,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
                     int d = (int)((dgs >> (4 * e)) & 15u);
-                    uint16_t pos = base[d * BS + pb];
-                    base[d * BS + pb] = (uint16_t)(pos + 1);
+                    int pos = (int)base[d * BS + pb] + (int)((lrs >> (4 * e)) & 15u);  // no read-modify-write chain
                     dst[pos] = ids[e];
                 }
             }

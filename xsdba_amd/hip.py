@@ -101,6 +101,19 @@ def quantile_groups(x, gidx, G, W, q, ctx: Context | None = None):
     return out
 
 
+def vecquantiles(x, rnk, ctx: Context | None = None):
+    """nbutils.vecquantiles: out[c] = nanquantile(x[c, :], rnk[c]) -> [C]"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    r = np.ascontiguousarray(rnk, s.dtype).reshape(-1)
+    if r.size != s.C:
+        raise ValueError(f"rnk must hold one quantile per row ({s.C}), got {r.size}")
+    out = _out(ctx, s.dev, (s.C,), s.dtype)
+    check(load().xsdba_hip_vecquantiles(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                        _vp(r), _vp(out)), "vecquantiles")
+    return out
+
+
 def _train(fn, name, ref, hist, gidx, G, W, q, kind, with_scaling, ctx, out=None):
     ctx = ctx or default_context()
     r = _Series(ref)
@@ -221,5 +234,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]

@@ -35,3 +35,15 @@ def _quantile(arr, q, nreduce=None):
     x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
     out = hip.quantile_groups(x2, None, 1, 1, np.asarray(q, x2.dtype))[:, 0, :]
     return out.reshape(tuple(lead) + (len(q),)) if lead else out[0]
+
+
+def vecquantiles(da, rnk, dim):
+    """For when the quantile (rnk) is different for each point (nbutils.py:164-195): `da` and `rnk` share all
+    dimensions but `dim`; returns an array shaped like `rnk`."""
+    da, rnk = as_dataarray(da), as_dataarray(rnk)
+    dims = [dim] if isinstance(dim, str) else list(dim)
+    v = da.transpose(*rnk.dims, *dims).values
+    x2 = v.reshape((int(np.prod(v.shape[: rnk.ndim], dtype=np.int64)), -1))
+    x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
+    out = hip.vecquantiles(x2, rnk.values.reshape(-1).astype(x2.dtype))
+    return DataArray(out.reshape(rnk.shape).astype(da.dtype), rnk.dims, rnk.coords, da.attrs)
