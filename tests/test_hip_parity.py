@@ -227,7 +227,8 @@ def test_polydetrend_ramp(hip):
     tnum = np.arange(T, dtype=np.float64) * 86400e9 + 9.6e17
     trend = hip.polydetrend_trend(x, None, 1, 1, tnum, 1)
     np.testing.assert_array_almost_equal(x - trend, 0)
-    assert_close(trend, oracle.polydetrend_trend(x, np.zeros(T, np.int32), 1, 1, tnum, 1), rtol=1e-12, what="trend")
+    # float64 reduction order differs (half-wave xor-shuffles vs sequential): 1e-12 of the data scale
+    assert_close(trend, oracle.polydetrend_trend(x, np.zeros(T, np.int32), 1, 1, tnum, 1), rtol=1e-12, atol=1e-12 * T, what="trend")
 
 
 # ------------------------------------------------------------------------------------------------

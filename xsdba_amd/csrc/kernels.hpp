@@ -271,7 +271,9 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
 // are parked in the trend buffer itself between the two phases.
 // dynamic LDS: [coef: 3*G doubles][xs: T * sizeof(R)]
 // ---------------------------------------------------------------------------------------------
-template <typename R>
+// M_LDS: the window means live in a second LDS array (T * sizeof(R) more) instead of the trend buffer — the
+// normal case for float32; float64 series that do not fit keep them in global memory.
+template <typename R, bool M_LDS>
 __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
@@ -279,10 +281,13 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *coef = reinterpret_cast<double *>(smem);
-    R *xs = reinterpret_cast<R *>(coef + 3 * (size_t)G);
+    double *rcp = coef + 3 * (size_t)G;  // [W+1] correctly rounded reciprocals of the possible window counts
+    R *xs = reinterpret_cast<R *>(rcp + W + 1);
     const int64_t c = blockIdx.x;
     const R *x = sim + c * sc;
-    R *m = trend_cm + (size_t)c * T;
+    R *tr_out = trend_cm + (size_t)c * T;
+    for (int i = threadIdx.x; i <= W; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
+    R *m = M_LDS ? xs + T : tr_out;
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
         R v = x[t * st];
         if (scaling) {
@@ -293,39 +298,95 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     }
     __syncthreads();
     const int h = W / 2;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-        R mv;
-        if (W == 1) mv = xs[t];
-        else {
-            double s = 0; int n = 0;
+    // Window means.  Every thread owns a contiguous chunk of time steps and slides the window: one full window sum,
+    // then one value in / one value out per step (float64 accumulation; exact for float32 data whose values within
+    // a window span < 2^24, so it equals a fresh sum); s / n through a reciprocal table + one FMA residual
+    // correction (Markstein) instead of the long IEEE division sequence.  When the series fits CH values per
+    // thread the means are held in registers and written back over the series in place (no second array, no
+    // global round trip); longer series park them in the trend buffer.
+    constexpr int CH = 24;
+    const bool inplace = !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
+    auto mean_of = [&](double s, int n) {
+        double mv = __builtin_nan("");
+        if (n) {
+            const double dn = (double)n, rc = rcp[n];
+            double q0 = s * rc;
+            double r0 = __builtin_fma(-q0, dn, s);
+            mv = __builtin_fma(r0, rc, q0);
+        }
+        return (R)mv;
+    };
+    auto slide = [&](int64_t t, bool first, double &s, int &n) {
+        if (first) {
             for (int j = 0; j < W; j++) {
                 int64_t tt = t + j - h;
                 if (tt >= 0 && tt < T) { R v = xs[tt]; if (v == v) { s += (double)v; n++; } }
             }
-            mv = n ? (R)(s / n) : nan_of<R>();
+        } else {
+            int64_t tin = t + W - 1 - h, tout = t - 1 - h;
+            if (tin < T) { R v = xs[tin]; if (v == v) { s += (double)v; n++; } }
+            if (tout >= 0) { R v = xs[tout]; if (v == v) { s -= (double)v; n--; } }
         }
-        m[t] = mv;
+    };
+    if (W == 1) {
+        m = xs;  // the "window mean" is the series itself
+    } else if (inplace) {
+        const int64_t t0 = (int64_t)threadIdx.x * CH;
+        R mreg[CH];
+        double s = 0; int n = 0;
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+            mreg[k] = nan_of<R>();
+            if (t0 + k < T) { slide(t0 + k, k == 0, s, n); mreg[k] = mean_of(s, n); }
+        }
+        __syncthreads();  // every window has been read: the series can be overwritten by its window means
+#pragma unroll
+        for (int k = 0; k < CH; k++) if (t0 + k < T) xs[t0 + k] = mreg[k];
+        m = xs;
+    } else {
+        const int64_t chunk = (T + blockDim.x - 1) / blockDim.x;
+        const int64_t t0 = (int64_t)threadIdx.x * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+        double s = 0; int n = 0;
+        for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n); m[t] = mean_of(s, n); }
     }
     __syncthreads();
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
-        int n = 0; double sx = 0, sy = 0;
-        for (int p = p0; p < p1; p++) { int t = mem_idx[p]; R v = m[t]; if (v == v) { sx += tnum[t]; sy += (double)v; n++; } }
-        double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan(""), slope = 0.0;
-        if (degree >= 1 && n >= 2) {
-            double sxx = 0, sxy = 0;
-            for (int p = p0; p < p1; p++) {
-                int t = mem_idx[p]; R v = m[t];
-                if (v == v) { double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+    // per-group least squares: one half-wave (32 lanes) per group, members loaded in parallel, sums by xor-shuffles
+    {
+        const int hw = threadIdx.x >> 5, nhw = blockDim.x >> 5, hl = threadIdx.x & 31;
+        auto hsum = [](double v) {
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+            return v;
+        };
+        for (int g = hw; g < G; g += nhw) {
+            const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
+            double sx = 0, sy = 0, cn = 0;
+            for (int p = p0 + hl; p < p1; p += 32) {
+                int t = mem_idx[p];
+                R v = m[t];
+                if (v == v) { sx += tnum[t]; sy += (double)v; cn += 1.0; }
             }
-            slope = sxx > 0 ? sxy / sxx : 0.0;
+            sx = hsum(sx); sy = hsum(sy); cn = hsum(cn);
+            const int n = (int)cn;
+            const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
+            double slope = 0.0;
+            if (degree >= 1 && n >= 2) {
+                double sxx = 0, sxy = 0;
+                for (int p = p0 + hl; p < p1; p += 32) {
+                    int t = mem_idx[p];
+                    R v = m[t];
+                    if (v == v) { double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                }
+                sxx = hsum(sxx); sxy = hsum(sxy);
+                slope = sxx > 0 ? sxy / sxx : 0.0;
+            }
+            if (hl == 0) { coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope; }
         }
-        coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
     }
     __syncthreads();
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
         int g = gidx[t];
-        m[t] = g >= 0 ? (R)(coef[3 * g + 1] + coef[3 * g + 2] * (tnum[t] - coef[3 * g])) : nan_of<R>();
+        tr_out[t] = g >= 0 ? (R)(coef[3 * g + 1] + coef[3 * g + 2] * (tnum[t] - coef[3 * g])) : nan_of<R>();
     }
 }
 
