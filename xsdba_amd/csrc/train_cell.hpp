@@ -117,8 +117,6 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             }
         }
 #pragma unroll
-        for (int e = 0; e < EPT; e++) idx0[tid * EPT + e] = (uint16_t)(tid * EPT + e);
-#pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             nv += __shfl_down(nv, o, 64);
             kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, o, 64));
@@ -131,16 +129,64 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         const int nvalid = nv;
         const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
         const int nbits = 32 - __clz((int)(range + 1u) | 0) ;
-        const int npass = max(1, ((range + 1u == 0u ? 32 : nbits) + 3) / 4);
         __syncthreads();
 
         if (debug_phase == 1) continue;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         // ---------------- B. LSD radix sort of the time indexes ----------------
-        int cur = 0;
-        for (int p = 0; p < npass; p++) {
+        // Pass 1 takes the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no
+        // information), so it is a counting sort with LDS atomics: 16384 u16 bins packed two per dword, histogram by
+        // ds_add, exclusive scan (16 bins per thread), slots by returning ds_add.  It replaces 3.5 nibble passes.
+        constexpr int D1 = 14, NB1 = 1 << D1;
+        {
+            uint32_t *hist = cntlo;  // NB1/2 dwords = 32 KB inside the sort scratch (cntlo/cnthi/base region)
+            for (int i = tid; i < NB1 / 2; i += NT) hist[i] = 0u;
+            __syncthreads();
+            uint32_t dg[EPT];
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                uint32_t k = keys[tid * EPT + e];
+                uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
+                dg[e] = r & (NB1 - 1);
+                atomicAdd(&hist[dg[e] >> 1], 1u << (16 * (dg[e] & 1)));
+            }
+            __syncthreads();
+            {
+                constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
+                uint32_t wv[BPT / 2];
+#pragma unroll
+                for (int i = 0; i < BPT / 2; i++) wv[i] = hist[tid * (BPT / 2) + i];
+                int run = 0;
+                uint32_t ex[BPT / 2];
+#pragma unroll
+                for (int i = 0; i < BPT / 2; i++) {
+                    int c0 = (int)(wv[i] & 0xFFFFu), c1 = (int)(wv[i] >> 16);
+                    ex[i] = (uint32_t)run | ((uint32_t)(run + c0) << 16);
+                    run += c0 + c1;
+                }
+                int incl = wave_incl_scan(run);
+                if (lane == 63) red[wid] = (uint32_t)incl;
+                __syncthreads();
+                int woff = 0;
+                for (int w = 0; w < wid; w++) woff += (int)red[w];
+                const uint32_t off = (uint32_t)(woff + incl - run);
+#pragma unroll
+                for (int i = 0; i < BPT / 2; i++) hist[tid * (BPT / 2) + i] = ex[i] + off * 0x00010001u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int sh = 16 * (dg[e] & 1);
+                uint32_t old = atomicAdd(&hist[dg[e] >> 1], 1u << sh);
+                idx1[(old >> sh) & 0xFFFFu] = (uint16_t)(tid * EPT + e);
+            }
+            __syncthreads();
+        }
+        int cur = 1;
+        const int npass_rest = nbits > D1 ? (nbits - D1 + 3) / 4 : 0;
+        for (int p = 0; p < npass_rest; p++) {
             const uint16_t *src = cur ? idx1 : idx0;
             uint16_t *dst = cur ? idx0 : idx1;
-            const int shift = 4 * p;
+            const int shift = D1 + 4 * p;
             uint64_t cnt = 0;
             uint16_t ids[EPT];
             uint64_t dgs = 0, lrs = 0;
@@ -331,8 +377,8 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     pos += ge ? s : 0;
                 }
             };
-            auto value_at = [&](int L, int wi, int pos) {
-                int rsel = min((L * WPL + wi) * 32 + pos, TPAD - 1);
+            auto value_at = [&](int rpos) {
+                int rsel = min(rpos, TPAD - 1);
                 int id = min((int)sorted[rsel], TPAD - 1);
                 return from_key(keys[id]);
             };
@@ -356,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 int L, wi, pos;
                 uint32_t wv[WPL];
                 select_rank(lo, L, wi, pos, wv);
-                float v = value_at(L, wi, pos);
+                float v = value_at((L * WPL + wi) * 32 + pos);
                 // upper neighbour = next set bit: same word, then the owner lane's following words
                 uint32_t wfull = wv[0];
 #pragma unroll
@@ -371,15 +417,15 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     hpos = take ? __ffs((int)wv[i]) - 1 : hpos;
                     found = found || take;
                 }
-                int hL = L;
-                const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words (rare)
+                int hrank = (L * WPL + hwi) * 32 + hpos;
+                const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words
                 if (__any(need_slow)) {
                     int L2, wi2, pos2;
                     uint32_t wv2[WPL];
                     select_rank(lo + 1, L2, wi2, pos2, wv2);
-                    if (need_slow) { hL = L2; hwi = wi2; hpos = pos2; }
+                    if (need_slow) hrank = (L2 * WPL + wi2) * 32 + pos2;
                 }
-                float vhi = casek == 0 ? value_at(hL, hwi, hpos) : v;
+                float vhi = casek == 0 ? value_at(hrank) : v;
                 if (mode == 2) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
                 float res;
                 if (casek == 3) res = __builtin_nanf("");
