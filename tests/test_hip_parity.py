@@ -417,3 +417,31 @@ def test_vecquantiles_vs_oracle(hip, dtype):
     assert_close(got, oracle.vecquantiles(x, q), rtol=0.0, what="vecquantiles")
     assert np.isnan(got[3]) and np.isnan(got[7]) and got[4] == x[4, 0]
     assert got[8] == np.nanmin(x[8]) and got[9] == np.nanmax(x[9])
+
+
+def test_nan_mask_large(hip, train_kernel):
+    """cfg5-style NaN mask at the 30-year length: 30 % all-NaN ('ocean') cells + 1 % i.i.d. NaN elsewhere, DQM
+    doy/31 train + adjust: the all-NaN cells give NaN tables/scen without errors, a cell subsample equals the oracle"""
+    rng = np.random.default_rng(43)
+    C, T = 96, 10950
+    gidx, G, W = GROUPINGS["doy31"](T)
+    ref, hist, sim = _synth(rng, C, T, "+", np.float32, nan_frac=0.01)
+    ocean = rng.random(C) < 0.3
+    ocean[:4] = [True, False, True, False]
+    for a in (ref, hist, sim):
+        a[ocean] = np.nan
+    q = _nodes(20)
+    tnum = (np.arange(T, dtype=np.float64) + 10957) * 86400e9
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "+")
+    scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", "+")
+    assert np.isnan(af[ocean]).all() and np.isnan(hq[ocean]).all() and np.isnan(sc[ocean]).all() and np.isnan(scen[ocean]).all()
+    assert np.isfinite(af[~ocean]).all() and np.isfinite(sc[~ocean]).all()
+    sub = slice(0, 8)
+    eaf, ehq, esc = oracle.dqm_train(ref[sub], hist[sub], gidx, G, W, q, "+")
+    scale = float(np.nanmax(np.abs(ref)))
+    assert_close(sc[sub], esc, rtol=2.4e-7, atol=2.4e-7 * scale, what="scaling")
+    assert_close(hq[sub], ehq, rtol=2.4e-7, atol=2.4e-7 * scale, what="hist_q")
+    eqaf, eqhq = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
+    oaf, ohq = oracle.eqm_train(ref[sub], hist[sub], gidx, G, W, q, "+")
+    assert_close(eqhq[sub], ohq, rtol=0.0, what="eqm hist_q with NaN mask")
+    assert_close(eqaf[sub], oaf, rtol=0.0, what="eqm af with NaN mask")

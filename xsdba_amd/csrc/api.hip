@@ -56,6 +56,7 @@ struct Plan {
     // fast train path (train_cell.hpp): rows as sorted sets, toggle lists between consecutive groups
     bool simple = false;  // no time index occurs twice in one group row
     int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
+    int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
 };
 
 struct ProfEntry {
@@ -262,6 +263,16 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
         }
     }
     int rc;
+    if (pl->simple && G > 1) {
+        int maxlen = 0;
+        for (int i = 0; i + 1 < G; i++) maxlen = std::max(maxlen, tog_ptr[(size_t)i + 1] - tog_ptr[(size_t)i]);
+        if (maxlen <= 64) {
+            std::vector<int> t64((size_t)G * 64, -1);
+            for (int i = 0; i + 1 < G; i++)
+                std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t64.begin() + (size_t)(i + 1) * 64);
+            if ((rc = upload_ints(ctx, t64, &pl->d_tog64))) return rc;
+        }
+    }
     if ((rc = upload_ints(ctx, row_sorted, &pl->d_row_sorted))) return rc;
     if ((rc = upload_ints(ctx, tog_ptr, &pl->d_tog_ptr))) return rc;
     if ((rc = upload_ints(ctx, tog_idx, &pl->d_tog_idx))) return rc;
@@ -281,6 +292,7 @@ void free_plan(Plan *p)
     (void)hipFree(p->d_gidx); (void)hipFree(p->d_row_ptr); (void)hipFree(p->d_row_idx);
     (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
     (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
+    if (p->d_tog64) (void)hipFree(p->d_tog64);
 }
 
 // ---- series staging: any (host|device, strides) -> cell-major contiguous device view ---------------
@@ -422,22 +434,26 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
-            auto go = [&](auto cfg) -> int {
+            const int dbg = getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0;
+            auto go = [&](auto cfg, auto diag) -> int {
                 constexpr int EPT = decltype(cfg)::value;
+                constexpr bool DIAG = decltype(diag)::value;
                 size_t lds = xs::CellCfg<EPT>::lds_bytes;
                 int rc2;
-                if ((rc2 = set_lds(xs::k_train_cell<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_cell<EPT, DIAG>, lds, ctx, "the per-cell sort"))) return rc2;
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);  // blocks walk the cells grid-stride
                 LaunchScope ls(ctx, "k_train_cell");
-                hipLaunchKernelGGL(xs::k_train_cell<EPT>, dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_cell<EPT, DIAG>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
                                    pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
-                                   (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list,
-                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0, C);
+                                   (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, dbg, C, pl->d_tog64);
                 return check_launch("k_train_cell");
             };
-            rc = ept == 4 ? go(std::integral_constant<int, 4>{}) : ept == 8 ? go(std::integral_constant<int, 8>{})
-                                                                          : go(std::integral_constant<int, 11>{});
+            using std::integral_constant;
+            if (dbg == 9 && ept == 11) rc = go(integral_constant<int, 11>{}, std::true_type{});  // cycle-share diagnostic build
+            else rc = ept == 4 ? go(integral_constant<int, 4>{}, std::false_type{})
+                 : ept == 8 ? go(integral_constant<int, 8>{}, std::false_type{})
+                            : go(integral_constant<int, 11>{}, std::false_type{});
             if (rc) return rc;
             // cells whose shortcut assumptions failed (rare) are redone by the generic kernel: a small fixed grid
             // walks the flagged rows, reading the count on the device (no host round trip, the call stays async)

@@ -66,12 +66,13 @@ template <int EPT> struct CellCfg {
     static constexpr size_t lds_bytes = off_misc + 64 * 8;  // reduction scratch
 };
 
-template <int EPT>
+template <int EPT, bool DIAG = false>
 __global__ __launch_bounds__(1024) void k_train_cell(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
     const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C)
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C,
+    const int *__restrict__ tog64)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW, BS = Cfg::BS;
@@ -88,6 +89,9 @@ __global__ __launch_bounds__(1024) void k_train_cell(
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // persistent-style grid: each block walks its cells grid-stride
+    // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
+    unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
+    auto stamp = [&](int seg) { if constexpr (DIAG) { unsigned long long now = __builtin_readcyclecounter(); if (seg >= 0) tacc[seg] += now - tlast; tlast = now; } };
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
     const int npass_arr = mode == 0 ? 1 : 2;
     bool flag_cell = false;
@@ -141,42 +145,41 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             uint32_t *hist = cntlo;  // NB1/2 dwords = 32 KB inside the sort scratch (cntlo/cnthi/base region)
             for (int i = tid; i < NB1 / 2; i += NT) hist[i] = 0u;
             __syncthreads();
-            uint32_t dg[EPT];
+            uint32_t dgp[(EPT + 1) / 2];  // the 14-bit digits of this thread's elements, two per register
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 uint32_t k = keys[tid * EPT + e];
                 uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
-                dg[e] = r & (NB1 - 1);
-                atomicAdd(&hist[dg[e] >> 1], 1u << (16 * (dg[e] & 1)));
+                uint32_t d = r & (NB1 - 1);
+                if (e & 1) dgp[e >> 1] |= d << 16; else dgp[e >> 1] = d;
+                atomicAdd(&hist[d >> 1], 1u << (16 * (d & 1)));
             }
             __syncthreads();
             {
                 constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
                 uint32_t wv[BPT / 2];
-#pragma unroll
-                for (int i = 0; i < BPT / 2; i++) wv[i] = hist[tid * (BPT / 2) + i];
                 int run = 0;
-                uint32_t ex[BPT / 2];
 #pragma unroll
-                for (int i = 0; i < BPT / 2; i++) {
-                    int c0 = (int)(wv[i] & 0xFFFFu), c1 = (int)(wv[i] >> 16);
-                    ex[i] = (uint32_t)run | ((uint32_t)(run + c0) << 16);
-                    run += c0 + c1;
-                }
+                for (int i = 0; i < BPT / 2; i++) { wv[i] = hist[tid * (BPT / 2) + i]; run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16); }
                 int incl = wave_incl_scan(run);
                 if (lane == 63) red[wid] = (uint32_t)incl;
                 __syncthreads();
                 int woff = 0;
                 for (int w = 0; w < wid; w++) woff += (int)red[w];
-                const uint32_t off = (uint32_t)(woff + incl - run);
+                int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
 #pragma unroll
-                for (int i = 0; i < BPT / 2; i++) hist[tid * (BPT / 2) + i] = ex[i] + off * 0x00010001u;
+                for (int i = 0; i < BPT / 2; i++) {
+                    int c0 = (int)(wv[i] & 0xFFFFu), c1 = (int)(wv[i] >> 16);
+                    hist[tid * (BPT / 2) + i] = (uint32_t)pre | ((uint32_t)(pre + c0) << 16);
+                    pre += c0 + c1;
+                }
             }
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
-                const int sh = 16 * (dg[e] & 1);
-                uint32_t old = atomicAdd(&hist[dg[e] >> 1], 1u << sh);
+                const uint32_t d = (e & 1) ? (dgp[e >> 1] >> 16) : (dgp[e >> 1] & 0xFFFFu);
+                const int sh = 16 * (d & 1);
+                uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
                 idx1[(old >> sh) & 0xFFFFu] = (uint16_t)(tid * EPT + e);
             }
             __syncthreads();
@@ -265,8 +268,15 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         double gsumA = 0.0, gsumB = 0.0;
         // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select
         int preA = -1, preA_len = 0, preA_base = 0, preB = -1, preB_len = 0, preB_base = 0;
-        if (gA0 + 1 < gA1) { preA_base = tog_ptr[gA0]; preA_len = tog_ptr[gA0 + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
-        if (gB0 + 1 < gB1) { preB_base = tog_ptr[gB0]; preB_len = tog_ptr[gB0 + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
+        // tog64 (when every toggle list has <= 64 entries, e.g. doy windows): row g of a [G][64] table padded with -1
+        // holds the list g-1 -> g, so the prefetch is one independent vector load (no pointer chase through SMEM)
+        if (tog64) {
+            if (gA0 + 1 < gA1) preA = tog64[(size_t)(gA0 + 1) * 64 + lane];
+            if (gB0 + 1 < gB1) preB = tog64[(size_t)(gB0 + 1) * 64 + lane];
+        } else {
+            if (gA0 + 1 < gA1) { preA_base = tog_ptr[gA0]; preA_len = tog_ptr[gA0 + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
+            if (gB0 + 1 < gB1) { preB_base = tog_ptr[gB0]; preB_len = tog_ptr[gB0 + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
+        }
         // quantile-index math depends on (n, k) only: cached while both halves keep their n
         int nA_prev = -1, nB_prev = -1, c_case = 3, c_lo = 0;
         float c_gamma = 0.f;
@@ -274,46 +284,63 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         for (int it = 0; it < n_iter; it++) {
             const int gA = gA0 + it, gB = gB0 + it;
             const bool vA = gA < gA1, vB = gB < gB1;
+            stamp(-1);
             double dlocA = 0.0, dlocB = 0.0;
-            auto toggle = [&](uint32_t *bits, int t, double &dloc) {
-                int r = rank[t];
-                if (r < nvalid) {
-                    uint32_t m = 1u << (r & 31);
-                    uint32_t old = atomicXor(&bits[r >> 5], m);
-                    if (mode == 2) { float v = from_key(keys[t]); dloc += (old & m) ? -(double)v : (double)v; }
+            // Toggles are issued in two waves of LDS traffic — all the rank reads, then all the XORs — because the
+            // compiler must otherwise order every rank read behind the previous atomic (both live in the same LDS
+            // array): one LDS round trip per batch instead of two per element.  Only DQM needs the old bit back.
+            auto flip = [&](uint32_t *bits, int t, int r, double &dloc) {
+                if (t >= 0 && r < nvalid) {
+                    const uint32_t m = 1u << (r & 31);
+                    if (mode == 2) {
+                        uint32_t old = atomicXor(&bits[r >> 5], m);
+                        float v = from_key(keys[t]);
+                        dloc += (old & m) ? -(double)v : (double)v;
+                    } else {
+                        (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             };
             if (it == 0) {
-                // initial build of both vectors from their row lists: the index loads of 8 rounds are issued
-                // together so that one L2 latency covers 512 entries
+                // initial build of both vectors from their row lists, 8 rounds (512 entries) at a time
                 auto build = [&](uint32_t *bits, int g, double &dloc) {
                     const int *l = row_sorted + row_ptr[g];
                     const int len = row_ptr[g + 1] - row_ptr[g];
                     for (int i0 = 0; i0 < len; i0 += 512) {
-                        int ts[8];
+                        int ts[8], rs[8];
 #pragma unroll
                         for (int u = 0; u < 8; u++) { int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (ts[u] >= 0) toggle(bits, ts[u], dloc);
+                        for (int u = 0; u < 8; u++) rs[u] = ts[u] >= 0 ? (int)rank[ts[u]] : 0x7FFFFFFF;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) flip(bits, ts[u], rs[u], dloc);
                     }
                 };
                 if (vA) build(bitsA, gA, dlocA);
                 if (vB) build(bitsB, gB, dlocB);
             } else if (debug_phase != 4) {
+                // consume the lists prefetched during the previous group FIRST, then issue the next prefetch: the
+                // wait for tA/tB then never covers the loads just issued
+                const int tA = vA ? preA : -1, tB = vB ? preB : -1;
+                const int lenA = vA ? preA_len : 0, lenB = vB ? preB_len : 0, lbA = preA_base, lbB = preB_base;
+                const int rA = tA >= 0 ? (int)rank[tA] : 0x7FFFFFFF, rB = tB >= 0 ? (int)rank[tB] : 0x7FFFFFFF;
+                flip(bitsA, tA, rA, dlocA);
+                flip(bitsB, tB, rB, dlocB);
                 if (vA) {
-                    const int t0 = preA, len = preA_len, lb = preA_base;
-                    if (gA + 1 < gA1) { preA_base = tog_ptr[gA]; preA_len = tog_ptr[gA + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
-                    if (t0 >= 0) toggle(bitsA, t0, dlocA);
-                    for (int i = lane + 64; i < len; i += 64) toggle(bitsA, tog_idx[lb + i], dlocA);
+                    if (tog64) { if (gA + 1 < gA1) preA = tog64[(size_t)(gA + 1) * 64 + lane]; }
+                    else if (gA + 1 < gA1) { preA_base = tog_ptr[gA]; preA_len = tog_ptr[gA + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
                 }
                 if (vB) {
-                    const int t0 = preB, len = preB_len, lb = preB_base;
-                    if (gB + 1 < gB1) { preB_base = tog_ptr[gB]; preB_len = tog_ptr[gB + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
-                    if (t0 >= 0) toggle(bitsB, t0, dlocB);
-                    for (int i = lane + 64; i < len; i += 64) toggle(bitsB, tog_idx[lb + i], dlocB);
+                    if (tog64) { if (gB + 1 < gB1) preB = tog64[(size_t)(gB + 1) * 64 + lane]; }
+                    else if (gB + 1 < gB1) { preB_base = tog_ptr[gB]; preB_len = tog_ptr[gB + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
+                }
+                if (!tog64) {  // lists longer than 64 entries (coarse groups)
+                    for (int i = lane + 64; i < lenA; i += 64) { int t = tog_idx[lbA + i]; flip(bitsA, t, (int)rank[t], dlocA); }
+                    for (int i = lane + 64; i < lenB; i += 64) { int t = tog_idx[lbB + i]; flip(bitsB, t, (int)rank[t], dlocB); }
                 }
             }
             lds_wave_fence();
+            stamp(it == 0 ? 7 : 0);  // toggles (seg 0) / initial builds (seg 7)
             if (debug_phase == 6) { if (lane == 0 && bitsA[3] == 12345u) out_hq[0] = 1.f; break; }
             // per-lane member counts of both vectors, packed (A low 16 bits, B high 16 bits): ONE prefix scan
             int clp = 0;
@@ -323,6 +350,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             const int exclp = inclp - clp;
             const int totp = __builtin_amdgcn_readlane(inclp, 63);
             const int nA = totp & 0xFFFF, nB = (int)((unsigned)totp >> 16);
+            stamp(1);  // popcount + scan
             const int n = half ? nB : nA;
             const int g = half ? gB : gA;
             const bool vh = half ? vB : vA;
@@ -377,11 +405,6 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     pos += ge ? s : 0;
                 }
             };
-            auto value_at = [&](int rpos) {
-                int rsel = min(rpos, TPAD - 1);
-                int id = min((int)sorted[rsel], TPAD - 1);
-                return from_key(keys[id]);
-            };
             if (debug_phase == 3 || debug_phase == 4) { if (n == 12345 && lane == 0) out_hq[obase] = (float)exclp; continue; }
             for (int kb = 0; kb < Q; kb += 32) {
                 const int k = kb + (lane & 31);
@@ -399,10 +422,12 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
                     if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
                 }
+                stamp(2);  // DQM mean, quantile index math
                 int L, wi, pos;
                 uint32_t wv[WPL];
                 select_rank(lo, L, wi, pos, wv);
-                float v = value_at((L * WPL + wi) * 32 + pos);
+                stamp(3);  // select(lo)
+                const int lrank = (L * WPL + wi) * 32 + pos;
                 // upper neighbour = next set bit: same word, then the owner lane's following words
                 uint32_t wfull = wv[0];
 #pragma unroll
@@ -421,11 +446,15 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words
                 if (__any(need_slow)) {
                     int L2, wi2, pos2;
-                    uint32_t wv2[WPL];
-                    select_rank(lo + 1, L2, wi2, pos2, wv2);
+                    select_rank(lo + 1, L2, wi2, pos2, wv);  // wv is dead by now: reuse its registers
                     if (need_slow) hrank = (L2 * WPL + wi2) * 32 + pos2;
                 }
-                float vhi = casek == 0 ? value_at(hrank) : v;
+                stamp(5);  // next set bit (+ second select)
+                // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
+                const int rs0 = min(lrank, TPAD - 1), rs1 = min(casek == 0 ? hrank : lrank, TPAD - 1);
+                const int id0 = min((int)sorted[rs0], TPAD - 1), id1 = min((int)sorted[rs1], TPAD - 1);
+                float v = from_key(keys[id0]), vhi = from_key(keys[id1]);
+                stamp(4);  // value lookups
                 if (mode == 2) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
                 float res;
                 if (casek == 3) res = __builtin_nanf("");
@@ -443,6 +472,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     else af[obase + k] = get_corr<float>(out_hq[obase + k], res, kind);  // res = ref_q
                 }
             }
+            stamp(6);  // upper value, interpolation, stores
             nA_prev = nA; nB_prev = nB;
             if (mode == 2 && vh && (lane & 31) == 0) {
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced below
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     }
     flag_cell = false;
     }  // cell loop
+    if constexpr (DIAG) { if (blockIdx.x == 0 && tid == 0) for (int i = 0; i < 8; i++) out_hq[i] = (float)((double)tacc[i] * 1e-3); }
 }
 
 }  // namespace xs
