@@ -104,14 +104,26 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
         if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
-            for (int i = 2 * tid; i < TPAD; i += 2 * NT) {
-                float2 v2 = make_float2(__builtin_nanf(""), __builtin_nanf(""));
-                if (i + 1 < T) v2 = *reinterpret_cast<const float2 *>(x + i);
-                else if (i < T) v2.x = x[i];
-                uint32_t k0 = to_key(v2.x), k1 = to_key(v2.y);
-                *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
-                if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
-                if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
+            // all the loads of the series are issued before the first one is consumed (one HBM latency per array
+            // instead of one per 2048 elements)
+            constexpr int NL = (EPT + 1) / 2;
+            float2 v2[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int i = 2 * tid + j * 2 * NT;
+                v2[j] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+                if (i + 1 < T) v2[j] = *reinterpret_cast<const float2 *>(x + i);
+                else if (i < T) v2[j].x = x[i];
+            }
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int i = 2 * tid + j * 2 * NT;
+                if (i < TPAD) {
+                    uint32_t k0 = to_key(v2[j].x), k1 = to_key(v2[j].y);
+                    *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
+                    if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
+                    if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
+                }
             }
         } else {
             for (int i = tid; i < TPAD; i += NT) {
@@ -252,6 +264,19 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         __syncthreads();
         if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
 
+        // ---------------- C0. a single group holding every time step (group="time"): the sorted order IS the row
+        if (G == 1 && mode != 2 && row_ptr[1] - row_ptr[0] == (int)T) {
+            const int n = nvalid;
+            for (int k = tid; k < Q; k += NT) {
+                auto load = [&](int i) { return from_key(keys[sorted[i]]); };
+                float res = n ? quantile_sorted<float>(load, n, q[k]) : __builtin_nanf("");
+                const size_t o = (size_t)c * Q + k;
+                if (mode == 0 || arr == 0) out_hq[o] = res;
+                else af[o] = get_corr<float>(out_hq[o], res, kind);
+            }
+            __syncthreads();
+            continue;
+        }
         // ---------------- C. membership bit-vectors in rank space + select ----------------
         // The groups are cut into 2*NWAVE contiguous chunks; every wave walks TWO chunks in lock-step, one per
         // half-wave (lanes 0-31: chunk A, lanes 32-63: chunk B), each with its own bit-vector.  Lane k of a half
