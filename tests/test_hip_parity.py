@@ -32,12 +32,14 @@ def hip():
 
 @pytest.fixture(autouse=True, params=["cell", "rows"])
 def train_kernel(request, monkeypatch):
-    """every test runs twice: with the per-cell fast train kernel (k_train_cell, where eligible) and with the
-    generic per-(cell, group) row kernel pinned (XSDBA_HIP_TRAIN=rows)"""
+    """every test runs twice: with the per-cell sort kernels (k_train_cell / k_qdm_cell, where eligible) and with the
+    generic kernels pinned (XSDBA_HIP_TRAIN=rows: per-(cell, group) row sort; XSDBA_HIP_QDM=count: ranks by counting)"""
     if request.param == "rows":
         monkeypatch.setenv("XSDBA_HIP_TRAIN", "rows")
+        monkeypatch.setenv("XSDBA_HIP_QDM", "count")
     else:
         monkeypatch.delenv("XSDBA_HIP_TRAIN", raising=False)
+        monkeypatch.delenv("XSDBA_HIP_QDM", raising=False)
     return request.param
 
 
@@ -218,6 +220,61 @@ def test_qdm_adjust_bit_exact_vs_oracle(hip, gname, rank_window):
     assert_close(scen, escen, rtol=0.0, what="scen")
     r = hip.rank_groups(sim, gidx, G, W, rank_window)
     assert_close(r, esim_q, rtol=0.0, what="rank_groups")
+
+
+@pytest.mark.parametrize("T", [700, 4500, 10950])
+@pytest.mark.parametrize("gname", ["time", "doy31", "month", "month5", "doy30_even", "season", "time_gaps"])
+def test_qdm_long_series_ties_and_gaps(hip, gname, T):
+    """the three LDS configurations of k_qdm_cell (T <= 4096 / 8192 / 11264), heavy ties incl. -0.0 == +0.0, an
+    all-NaN cell, time steps without a group, both kinds, 1-D linear interpolation, NaN extrapolation"""
+    rng = np.random.default_rng(T + len(gname))
+    C = 4
+    if gname == "season":
+        gidx, G, W = ((_doy_month(T)[1] + 1) % 12 // 3).astype(np.int32), 4, 1
+    elif gname == "time_gaps":
+        gidx, G, W = np.zeros(T, np.int32), 1, 1
+        gidx[rng.random(T) < 0.1] = -1
+    else:
+        gidx, G, W = GROUPINGS[gname](T)
+    if gname == "month5":
+        gidx = gidx.copy()
+        gidx[5::97] = -1
+    q = _nodes(15)
+    for kind in "+*":
+        ref, hist, sim = _synth(rng, C, T, kind, np.float32, nan_frac=0.02)
+        sim[0] = np.round(sim[0] / 4) * 4             # a handful of distinct values
+        sim[1, ::3] = 0.0
+        sim[1, 1::6] = -0.0                           # equal to +0.0 for ranking purposes
+        sim[2] = np.nan
+        af, _ = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+        for rank_window in (False, True):
+            for interp, extrap in (("nearest", "constant"), ("linear", "nan")) if G == 1 else (("nearest", "constant"), ("nearest", "nan")):
+                scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, rank_window, interp, extrap, kind)
+                escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, rank_window, interp, extrap, kind)
+                assert_close(sim_q, esim_q, rtol=0.0, what=f"sim_q {kind} rw={rank_window}")
+                assert_close(scen, escen, rtol=0.0, what=f"scen {kind} rw={rank_window} {interp}/{extrap}")
+        r = hip.rank_groups(sim, gidx, G, W, True)
+        assert_close(r, oracle.rank_groups(sim, gidx, G, W, True), rtol=0.0, what="rank_groups")
+
+
+def test_qdm_nan_factors_fall_back(hip):
+    """NaN factors break the own-row shortcut of k_qdm_cell: those cells are redone by the generic kernel (2-D nearest
+    neighbour across group rows), the others keep the fast result"""
+    rng = np.random.default_rng(5)
+    T, C, kind = 3650, 6, "+"
+    gidx, G, W = GROUPINGS["doy31"](T)
+    ref, hist, sim = _synth(rng, C, T, kind)
+    q = _nodes(12)
+    af, _ = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    af[1, 40, :] = np.nan          # a whole row: the neighbours' nodes win
+    af[3, :, 0] = np.nan           # first node everywhere: yfirst moves
+    af[4, 100:103, 5:9] = np.nan   # holes inside rows
+    af[5] = np.nan                 # nothing valid at all
+    for extrap in ("constant", "nan"):
+        scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, True, "nearest", extrap, kind)
+        escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, True, "nearest", extrap, kind)
+        assert_close(sim_q, esim_q, rtol=0.0, what="sim_q")
+        assert_close(scen, escen, rtol=0.0, what=f"scen ({extrap})")
 
 
 def test_polydetrend_ramp(hip):

@@ -402,7 +402,7 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
                              const int *__restrict__ gidx, const int *__restrict__ grp_ptr,
                              const int *__restrict__ grp_idx, int interp, int extrap, int kind, R *__restrict__ scen,
                              double *__restrict__ sim_q, int64_t ost, int64_t osc, unsigned char *__restrict__ gscratch,
-                             size_t gstride)
+                             size_t gstride, const int *__restrict__ cell_list, const int *__restrict__ n_list_dev)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
@@ -414,7 +414,10 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
     int *gstat = reinterpret_cast<int *>(p);  // per group: N valid, #==min, #==max
     p += ((sizeof(int) * 3 * (size_t)G) + 15) & ~(size_t)15;
     R *xs = reinterpret_cast<R *>(p);
-  for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+  // cell_list (device list of *n_list_dev cell ids): redo only those cells (the fallback of k_qdm_cell)
+  const int64_t n_cells = cell_list ? (int64_t)*n_list_dev : C;
+  for (int64_t ci = blockIdx.x; ci < n_cells; ci += gridDim.x) {
+    const int64_t c = cell_list ? (int64_t)cell_list[ci] : ci;
     CellTab<R> ct;
     if (af) ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
     const R *x = sim + c * sc;

@@ -66,17 +66,16 @@ template <int EPT> struct CellCfg {
     static constexpr size_t lds_bytes = off_misc + 64 * 8;  // reduction scratch
 };
 
-template <int EPT, bool DIAG = false>
-__global__ __launch_bounds__(1024) void k_train_cell(
-    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
-    const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
-    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C,
-    const int *__restrict__ tog64)
+// Phases A + B, shared by k_train_cell and k_qdm_cell: the cell's series -> order-preserving keys in LDS, the time
+// indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
+// (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
+// stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
+template <int EPT>
+__device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
+                                                          uint32_t *red, int stop_after, int &nvalid_out)
 {
     using Cfg = CellCfg<EPT>;
-    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW, BS = Cfg::BS;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
     uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0);
     uint16_t *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
@@ -84,22 +83,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     uint32_t *cnthi = reinterpret_cast<uint32_t *>(smem + Cfg::off_cnthi);
     uint16_t *base = reinterpret_cast<uint16_t *>(smem + Cfg::off_base);
     uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
-    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg::off_bits);
-    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
-
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    // persistent-style grid: each block walks its cells grid-stride
-    // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
-    unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
-    auto stamp = [&](int seg) { if constexpr (DIAG) { unsigned long long now = __builtin_readcyclecounter(); if (seg >= 0) tacc[seg] += now - tlast; tlast = now; } };
-    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
-    const int npass_arr = mode == 0 ? 1 : 2;
-    bool flag_cell = false;
-
-    for (int arr = 0; arr < npass_arr; arr++) {
-        // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
-        // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
-        const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
         // ---------------- A. load, keys, range ----------------
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
@@ -143,11 +127,12 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         nv = 0; kmin = 0xFFFFFFFFu; kmax = 0u;
         for (int w = 0; w < Cfg::NWAVE; w++) { nv += (int)red[3 * w]; kmin = min(kmin, red[3 * w + 1]); kmax = max(kmax, red[3 * w + 2]); }
         const int nvalid = nv;
+        nvalid_out = nv;
         const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
         const int nbits = 32 - __clz((int)(range + 1u) | 0) ;
         __syncthreads();
 
-        if (debug_phase == 1) continue;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
+        if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         // ---------------- B. LSD radix sort of the time indexes ----------------
         // Pass 1 takes the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no
         // information), so it is a counting sort with LDS atomics: 16384 u16 bins packed two per dword, histogram by
@@ -259,9 +244,47 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             cur ^= 1;
         }
         const uint16_t *sorted = cur ? idx1 : idx0;
-        if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
+        if (stop_after == 2) return sorted;
         for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
         __syncthreads();
+
+        return sorted;
+}
+
+template <int EPT, bool DIAG = false>
+__global__ __launch_bounds__(1024) void k_train_cell(
+    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
+    const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
+    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C,
+    const int *__restrict__ tog64)
+{
+    using Cfg = CellCfg<EPT>;
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
+    uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
+    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg::off_bits);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // persistent-style grid: each block walks its cells grid-stride
+    // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
+    unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
+    auto stamp = [&](int seg) { if constexpr (DIAG) { unsigned long long now = __builtin_readcyclecounter(); if (seg >= 0) tacc[seg] += now - tlast; tlast = now; } };
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+    const int npass_arr = mode == 0 ? 1 : 2;
+    bool flag_cell = false;
+
+    for (int arr = 0; arr < npass_arr; arr++) {
+        // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
+        // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
+        const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
+        // ---------------- A + B. load, keys, LSD radix sort of the time indexes, rank[] ----------------
+        int nvalid;
+        const uint16_t *sorted = cell_load_sort<EPT>(x, T, smem, red, debug_phase == 1 ? 1 : (debug_phase == 2 ? 2 : 0), nvalid);
+        if (debug_phase == 1) continue;
+        if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
         if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
 
         // ---------------- C0. a single group holding every time step (group="time"): the sorted order IS the row
