@@ -436,25 +436,33 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
             const int dbg = getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0;
-            auto go = [&](auto cfg, auto diag) -> int {
+            auto go = [&](auto cfg, auto diag, auto dqm, auto t64) -> int {
                 constexpr int EPT = decltype(cfg)::value;
-                constexpr bool DIAG = decltype(diag)::value;
+                constexpr bool DIAG = decltype(diag)::value, DQM = decltype(dqm)::value, TOG64 = decltype(t64)::value;
                 size_t lds = xs::CellCfg<EPT>::lds_bytes;
                 int rc2;
-                if ((rc2 = set_lds(xs::k_train_cell<EPT, DIAG>, lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_cell<EPT, DIAG, DQM, TOG64>, lds, ctx, "the per-cell sort"))) return rc2;
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);  // blocks walk the cells grid-stride
                 LaunchScope ls(ctx, "k_train_cell");
-                hipLaunchKernelGGL((xs::k_train_cell<EPT, DIAG>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
-                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr,
-                                   pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
+                hipLaunchKernelGGL((xs::k_train_cell<EPT, DIAG, DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream,
+                                   (const float *)s0.dev, (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted,
+                                   pl->d_tog_ptr, pl->d_tog_idx, G, (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev,
                                    (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, dbg, C, pl->d_tog64);
                 return check_launch("k_train_cell");
             };
             using std::integral_constant;
-            if (dbg == 9 && ept == 11) rc = go(integral_constant<int, 11>{}, std::true_type{});  // cycle-share diagnostic build
-            else rc = ept == 4 ? go(integral_constant<int, 4>{}, std::false_type{})
-                 : ept == 8 ? go(integral_constant<int, 8>{}, std::false_type{})
-                            : go(integral_constant<int, 11>{}, std::false_type{});
+            using std::false_type;
+            using std::true_type;
+            // the mode switches are template parameters of the kernel: pick the instantiation
+            auto pick_t64 = [&](auto cfg, auto dqm) -> int {
+                return pl->d_tog64 ? go(cfg, false_type{}, dqm, true_type{}) : go(cfg, false_type{}, dqm, false_type{});
+            };
+            auto pick_dqm = [&](auto cfg) -> int { return mode == 2 ? pick_t64(cfg, true_type{}) : pick_t64(cfg, false_type{}); };
+            if (dbg && ept == 11 && mode != 2 && pl->d_tog64)  // timing aids (XSDBA_HIP_DEBUG_PHASE): diagnostic build
+                rc = go(integral_constant<int, 11>{}, true_type{}, false_type{}, true_type{});
+            else rc = ept == 4 ? pick_dqm(integral_constant<int, 4>{})
+                 : ept == 8 ? pick_dqm(integral_constant<int, 8>{})
+                            : pick_dqm(integral_constant<int, 11>{});
             if (rc) return rc;
             // cells whose shortcut assumptions failed (rare) are redone by the generic kernel: a small fixed grid
             // walks the flagged rows, reading the count on the device (no host round trip, the call stays async)

@@ -251,14 +251,17 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         return sorted;
 }
 
-template <int EPT, bool DIAG = false>
+// DQM: dqm_train (group-mean normalisation + scaling); TOG64: the padded [G][64] toggle table is used.  Both are
+// template parameters (as are the timing aids under DIAG) so that the group loop carries no mode branches.
+template <int EPT, bool DIAG = false, bool DQM = false, bool TOG64 = false>
 __global__ __launch_bounds__(1024) void k_train_cell(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
     const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase, int64_t C,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase_arg, int64_t C,
     const int *__restrict__ tog64)
 {
+    const int debug_phase = DIAG ? debug_phase_arg : 0;  // timing aids exist in the diagnostic build only
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
 
         // ---------------- C0. a single group holding every time step (group="time"): the sorted order IS the row
-        if (G == 1 && mode != 2 && row_ptr[1] - row_ptr[0] == (int)T) {
+        if (G == 1 && !DQM && row_ptr[1] - row_ptr[0] == (int)T) {
             const int n = nvalid;
             for (int k = tid; k < Q; k += NT) {
                 auto load = [&](int i) { return from_key(keys[sorted[i]]); };
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         constexpr int NCH = 2 * Cfg::NWAVE;
         const int gpc = (G + NCH - 1) / NCH;
         const int half = lane >> 5;
+        const unsigned hshift = 16u * (unsigned)half;
         const int gA0 = min(G, (2 * wid) * gpc), gA1 = min(G, gA0 + gpc);
         const int gB0 = min(G, (2 * wid + 1) * gpc), gB1 = min(G, gB0 + gpc);
         uint32_t *bitsA = bits_all + (2 * wid) * BITW, *bitsB = bitsA + BITW;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
         int preA = -1, preA_len = 0, preA_base = 0, preB = -1, preB_len = 0, preB_base = 0;
         // tog64 (when every toggle list has <= 64 entries, e.g. doy windows): row g of a [G][64] table padded with -1
         // holds the list g-1 -> g, so the prefetch is one independent vector load (no pointer chase through SMEM)
-        if (tog64) {
+        if (TOG64) {
             if (gA0 + 1 < gA1) preA = tog64[(size_t)(gA0 + 1) * 64 + lane];
             if (gB0 + 1 < gB1) preB = tog64[(size_t)(gB0 + 1) * 64 + lane];
         } else {
@@ -336,11 +340,12 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             double dlocA = 0.0, dlocB = 0.0;
             // Toggles are issued in two waves of LDS traffic — all the rank reads, then all the XORs — because the
             // compiler must otherwise order every rank read behind the previous atomic (both live in the same LDS
-            // array): one LDS round trip per batch instead of two per element.  Only DQM needs the old bit back.
+            // array): one LDS round trip per batch instead of two per element.
+            // Only DQM needs the old bit back.
             auto flip = [&](uint32_t *bits, int t, int r, double &dloc) {
                 if (t >= 0 && r < nvalid) {
                     const uint32_t m = 1u << (r & 31);
-                    if (mode == 2) {
+                    if (DQM) {
                         uint32_t old = atomicXor(&bits[r >> 5], m);
                         float v = from_key(keys[t]);
                         dloc += (old & m) ? -(double)v : (double)v;
@@ -375,14 +380,14 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 flip(bitsA, tA, rA, dlocA);
                 flip(bitsB, tB, rB, dlocB);
                 if (vA) {
-                    if (tog64) { if (gA + 1 < gA1) preA = tog64[(size_t)(gA + 1) * 64 + lane]; }
+                    if (TOG64) { if (gA + 1 < gA1) preA = tog64[(size_t)(gA + 1) * 64 + lane]; }
                     else if (gA + 1 < gA1) { preA_base = tog_ptr[gA]; preA_len = tog_ptr[gA + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
                 }
                 if (vB) {
-                    if (tog64) { if (gB + 1 < gB1) preB = tog64[(size_t)(gB + 1) * 64 + lane]; }
+                    if (TOG64) { if (gB + 1 < gB1) preB = tog64[(size_t)(gB + 1) * 64 + lane]; }
                     else if (gB + 1 < gB1) { preB_base = tog_ptr[gB]; preB_len = tog_ptr[gB + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
                 }
-                if (!tog64) {  // lists longer than 64 entries (coarse groups)
+                if (!TOG64) {  // lists longer than 64 entries (coarse groups)
                     for (int i = lane + 64; i < lenA; i += 64) { int t = tog_idx[lbA + i]; flip(bitsA, t, (int)rank[t], dlocA); }
                     for (int i = lane + 64; i < lenB; i += 64) { int t = tog_idx[lbB + i]; flip(bitsB, t, (int)rank[t], dlocB); }
                 }
@@ -398,12 +403,13 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             const int exclp = inclp - clp;
             const int totp = __builtin_amdgcn_readlane(inclp, 63);
             const int nA = totp & 0xFFFF, nB = (int)((unsigned)totp >> 16);
+            const unsigned long long ballotA = __ballot((clp & 0xFFFF) != 0), ballotB = __ballot(((unsigned)clp >> 16) != 0u);
             stamp(1);  // popcount + scan
             const int n = half ? nB : nA;
             const int g = half ? gB : gA;
             const bool vh = half ? vB : vA;
             float mu = 0.f, inv = 0.f;
-            if (mode == 2) {
+            if (DQM) {
                 gsumA += wave_sum(dlocA); gsumA = __shfl(gsumA, 0, 64);
                 gsumB += wave_sum(dlocB); gsumB = __shfl(gsumB, 0, 64);
                 const double gs = half ? gsumB : gsumA;
@@ -414,17 +420,19 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
             // rank-space position of the j-th member of this half's vector
             auto select_rank = [&](int j, int &L, int &wi, int &pos, uint32_t (&wv)[WPL]) {
-                L = 0;
-                int eL = 0;
+                // owner lane: the last lane whose exclusive count is <= j.  Branch-free bisection on the raw
+                // ds_bpermute (byte-addressed lane index kept pre-shifted), this half's 16-bit field by one v_bfe
+                int L4 = 0, eL = 0;
 #pragma unroll
                 for (int s = 32; s > 0; s >>= 1) {
-                    int cand = L + s;
-                    int ep = __shfl(exclp, cand & 63, 64);
-                    int e = half ? (int)((unsigned)ep >> 16) : (ep & 0xFFFF);
-                    bool ok = cand < 64 && e <= j;
-                    L = ok ? cand : L;
+                    const int cand4 = L4 + 4 * s;  // <= 4 * 63: the steps sum to 63
+                    const int ep = __builtin_amdgcn_ds_bpermute(cand4, exclp);
+                    const int e = (int)(((unsigned)ep >> hshift) & 0xFFFFu);
+                    const bool ok = e <= j;
+                    L4 = ok ? cand4 : L4;
                     eL = ok ? e : eL;
                 }
+                L = L4 >> 2;
                 int rem = j - eL;
                 const uint32_t *wp = bits_h + L * WPL;
 #pragma unroll
@@ -493,9 +501,22 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 int hrank = (L * WPL + hwi) * 32 + hpos;
                 const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words
                 if (__any(need_slow)) {
-                    int L2, wi2, pos2;
-                    select_rank(lo + 1, L2, wi2, pos2, wv);  // wv is dead by now: reuse its registers
-                    if (need_slow) hrank = (L2 * WPL + wi2) * 32 + pos2;
+                    // (nearly every round has such a lane) it is the first member of the next lane that holds any:
+                    // that lane from the ballot of non-empty lanes, its first set bit from its words — no second select
+                    const unsigned long long restm = L < 63 ? ((half ? ballotB : ballotA) >> (L + 1)) : 0ull;
+                    const int L2 = restm ? L + __ffsll(restm) : L;
+                    const uint32_t *wp2 = bits_h + L2 * WPL;
+#pragma unroll
+                    for (int i = 0; i < WPL; i++) wv[i] = wp2[i];  // wv is dead by now: reuse its registers
+                    bool f2 = false;
+                    int hr2 = 0;
+#pragma unroll
+                    for (int i = 0; i < WPL; i++) {
+                        const bool take = !f2 && wv[i] != 0u;
+                        hr2 = take ? (L2 * WPL + i) * 32 + __ffs((int)wv[i]) - 1 : hr2;
+                        f2 = f2 || take;
+                    }
+                    if (need_slow) hrank = hr2;
                 }
                 stamp(5);  // next set bit (+ second select)
                 // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
@@ -503,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 const int id0 = min((int)sorted[rs0], TPAD - 1), id1 = min((int)sorted[rs1], TPAD - 1);
                 float v = from_key(keys[id0]), vhi = from_key(keys[id1]);
                 stamp(4);  // value lookups
-                if (mode == 2) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
+                if (DQM) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
                 float res;
                 if (casek == 3) res = __builtin_nanf("");
                 else if (casek != 0) res = v;
@@ -522,7 +543,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             }
             stamp(6);  // upper value, interpolation, stores
             nA_prev = nA; nB_prev = nB;
-            if (mode == 2 && vh && (lane & 31) == 0) {
+            if (DQM && vh && (lane & 31) == 0) {
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced below
                 else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
             }
