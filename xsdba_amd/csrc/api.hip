@@ -502,24 +502,33 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
                      const R *trend_cm)
 {
     const size_t tab = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
-    int rc;
     const char *name = scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust";
-    if (tab <= (size_t)ctx->lds_limit) {
-        if ((rc = set_lds(xs::k_qm_adjust<R, true>, tab, ctx, "the factor table"))) return rc;
-        LaunchScope ls(ctx, name);
-        hipLaunchKernelGGL((xs::k_qm_adjust<R, true>), dim3((unsigned)C), dim3(adj_threads()), tab, ctx->stream, (const R *)s.dev, T, C,
-                           s.st, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node,
-                           scaling, trend_cm, (unsigned char *)nullptr, (size_t)0);
-    } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
-        const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
-        void *scratch;
-        if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
-        LaunchScope ls(ctx, name);
-        hipLaunchKernelGGL((xs::k_qm_adjust<R, false>), dim3(nblk), dim3(256), 0, ctx->stream, (const R *)s.dev, T, C, s.st,
-                           s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, (int64_t)1, T, node, scaling,
-                           trend_cm, (unsigned char *)scratch, tab);
-    }
-    return check_launch("k_qm_adjust");
+    if (s.st != 1) return fail(XSDBA_E_ARG, "internal: the adjust kernels expect time-contiguous rows");
+    // mode switches are template parameters of the kernel: pick the instantiation
+    auto go = [&](auto grouped, auto dqm) -> int {
+        constexpr bool GROUPED = decltype(grouped)::value, DQM = decltype(dqm)::value;
+        int rc;
+        if (tab <= (size_t)ctx->lds_limit) {
+            if ((rc = set_lds(xs::k_qm_adjust<R, true, GROUPED, DQM>, tab, ctx, "the factor table"))) return rc;
+            LaunchScope ls(ctx, name);
+            hipLaunchKernelGGL((xs::k_qm_adjust<R, true, GROUPED, DQM>), dim3((unsigned)C), dim3(adj_threads()), tab, ctx->stream,
+                               (const R *)s.dev, T, C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node,
+                               scaling, trend_cm, (unsigned char *)nullptr, (size_t)0);
+        } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
+            void *scratch;
+            if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
+            LaunchScope ls(ctx, name);
+            hipLaunchKernelGGL((xs::k_qm_adjust<R, false, GROUPED, DQM>), dim3(nblk), dim3(256), 0, ctx->stream, (const R *)s.dev, T,
+                               C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node, scaling, trend_cm,
+                               (unsigned char *)scratch, tab);
+        }
+        return check_launch("k_qm_adjust");
+    };
+    using std::false_type;
+    using std::true_type;
+    if (G > 1) return scaling ? go(true_type{}, true_type{}) : go(true_type{}, false_type{});
+    return scaling ? go(false_type{}, true_type{}) : go(false_type{}, false_type{});
 }
 
 template <typename R>

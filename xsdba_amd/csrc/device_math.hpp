@@ -140,14 +140,16 @@ __device__ __forceinline__ R interp1d_eval(double x, bool x_is_double, const R *
     return slope * ((R)x - xs[idx - 1]) + ys[idx - 1];
 }
 
-template <typename R> __device__ __forceinline__ double row_nearest(double x, const R *xs, int n, int *which)
+// XF: the type the abscissa arrives in (float for a float32 series: the bisection then compares floats, which orders
+// exactly like the float64 comparison of the same values; the squared distances are always float64)
+template <typename R, typename XF> __device__ __forceinline__ double row_nearest(XF x, const R *xs, int n, int *which)
 {
     int lo = 0, hi = n;
-    while (lo < hi) { int mid = (lo + hi) >> 1; if ((double)xs[mid] < x) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { int mid = (lo + hi) >> 1; if ((XF)xs[mid] < x) lo = mid + 1; else hi = mid; }
     double best = __builtin_inf();
     int bi = -1;
-    if (lo > 0) { double d = x - (double)xs[lo - 1]; best = d * d; bi = lo - 1; }
-    if (lo < n) { double d = x - (double)xs[lo]; if (d * d < best) { best = d * d; bi = lo; } }
+    if (lo > 0) { double d = (double)x - (double)xs[lo - 1]; best = d * d; bi = lo - 1; }
+    if (lo < n) { double d = (double)x - (double)xs[lo]; if (d * d < best) { best = d * d; bi = lo; } }
     *which = bi;
     return best;
 }
@@ -157,14 +159,14 @@ template <typename R> __device__ __forceinline__ double row_nearest(double x, co
 // nbutils._extrapolate_on_quantiles (nbutils.py:397-416), for an integer group coordinate r = g0+1.
 // Rows are visited outward (r, r-1, r+1, r-2, ...) while dr^2 < best; exact distance ties keep the
 // first visited node (cKDTree's choice at ties is implementation-defined).
-template <typename R>
-__device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R> &ct, int extrap, int &node)
+template <typename R, typename XF>
+__device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct, int extrap, int &node)
 {
     node = -1;
     if (x != x || !ct.any_valid) return nan_of<R>();
     const int G = ct.G, Q = ct.Q, r = g0 + 1;
-    if (x < ct.xfirst[g0]) return extrap == 0 ? ct.yfirst[g0] : nan_of<R>();
-    if (x > ct.xlast[g0]) return extrap == 0 ? ct.ylast[g0] : nan_of<R>();
+    if ((double)x < ct.xfirst[g0]) return extrap == 0 ? ct.yfirst[g0] : nan_of<R>();
+    if ((double)x > ct.xlast[g0]) return extrap == 0 ? ct.ylast[g0] : nan_of<R>();
     double best = __builtin_inf();
     R val = nan_of<R>();
     for (int dr = 0; dr <= G + 1; dr++) {
@@ -177,7 +179,7 @@ __device__ __forceinline__ R interp2d_nearest(double x, int g0, const CellTab<R>
             int n = ct.rn[g];
             if (n == 0) continue;
             int w;
-            double d2 = row_nearest<R>(x, ct.xs + (size_t)g * Q, n, &w) + d2r;
+            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * Q, n, &w) + d2r;
             if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
         }
     }
@@ -191,7 +193,7 @@ __device__ __forceinline__ R celltab_eval(const CellTab<R> &ct, double x, bool x
     if (ct.G == 1)
         return interp1d_eval<R>(x, x_is_double, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, node);
     if (g0 < 0) { node = -1; return nan_of<R>(); }
-    return interp2d_nearest<R>(x, g0, ct, extrap, node);
+    return interp2d_nearest<R, double>(x, g0, ct, extrap, node);
 }
 
 }  // namespace xs

@@ -191,12 +191,27 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
 {
     const int n = G * Q;
     if (threadIdx.x == 0) *t.any = 0;
+    bool has_nan = false;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         int g = i / Q, k = i - g * Q;
-        t.xs[i] = xq[(size_t)g * xq_row_stride + k];
-        t.ys[i] = yq[i];
+        const R xv = xq[(size_t)g * xq_row_stride + k], yv = yq[i];
+        t.xs[i] = xv;
+        t.ys[i] = yv;
+        has_nan |= (xv != xv) || (yv != yv);
     }
-    __syncthreads();
+    if (!__syncthreads_or(has_nan ? 1 : 0)) {
+        // the usual case, no NaN anywhere in the cell's table: rows are already compact
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            const R *xr = t.xs + (size_t)g * Q, *yr = t.ys + (size_t)g * Q;
+            t.rn[g] = Q; t.xfirst[g] = (double)xr[0]; t.xlast[g] = (double)xr[Q - 1]; t.yfirst[g] = yr[0]; t.ylast[g] = yr[Q - 1];
+        }
+        if (threadIdx.x == 0) *t.any = 1;
+        __syncthreads();
+        CellTab<R> ct;
+        ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
+        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1;
+        return ct;
+    }
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         R *xr = t.xs + (size_t)g * Q, *yr = t.ys + (size_t)g * Q;
         int m = 0;
@@ -228,37 +243,48 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
 // TAB_LDS: the compacted table lives in LDS (the normal case); otherwise (tables larger than the LDS, e.g.
 // float64 with 50 quantiles x 366 groups) each block compacts it into its own slice of a global scratch
 // buffer (L2-resident) and the block walks the cells grid-stride.
-template <typename R, bool TAB_LDS>
-__global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
+// GROUPED (more than one group: 2-D nearest neighbour) and DQM (scaling + trend supplied) are template parameters so
+// that the per-element loop carries no mode branches.  The series are cell-major contiguous rows (time stride 1).
+template <typename R, bool TAB_LDS, bool GROUPED, bool DQM>
+__global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
                             const R *__restrict__ af, const R *__restrict__ hist_q, int G, int Q,
                             const int *__restrict__ gidx, int interp, int extrap, int kind, R *__restrict__ scen,
-                            int64_t ost, int64_t osc, int *__restrict__ node, const R *__restrict__ scaling,
+                            int64_t osc, int *__restrict__ node, const R *__restrict__ scaling,
                             const R *__restrict__ trend, unsigned char *__restrict__ gscratch, size_t gstride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *tabmem = TAB_LDS ? smem : gscratch + (size_t)blockIdx.x * gstride;
     TabLds<R> tl = tab_carve<R>(tabmem, G, Q);
+    const int Ti = (int)T;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
         const R *x = sim + c * sc;
         R *o = scen + c * osc;
-        for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-            R v = x[t * st];
-            int g0 = G > 1 ? gidx[t] : 0;
+        const R *scal = DQM ? scaling + (size_t)c * G : nullptr;
+        const R *trc = DQM ? trend + (size_t)c * T : nullptr;
+        int *ndc = node ? node + (size_t)c * T : nullptr;
+        for (int t = threadIdx.x; t < Ti; t += blockDim.x) {
+            R v = x[t];
+            const int g0 = (GROUPED || DQM) ? gidx[t] : 0;
             R tr = (R)0;
-            if (scaling) {
-                int gs = gidx[t];
-                R s = gs >= 0 ? scaling[(size_t)c * G + gs] : nan_of<R>();
+            if constexpr (DQM) {
+                R s = g0 >= 0 ? scal[g0] : nan_of<R>();
                 v = apply_corr<R>(v, s, kind);
-                tr = trend[(size_t)c * T + t];
+                tr = trc[t];
                 v = apply_corr<R>(v, invert<R>(tr, kind), kind);
             }
             int nd;
-            R a = celltab_eval<R>(ct, (double)v, false, g0, interp, extrap, nd);
+            R a;
+            if constexpr (GROUPED) {
+                if (g0 < 0) { nd = -1; a = nan_of<R>(); }
+                else a = interp2d_nearest<R, R>(v, g0, ct, extrap, nd);
+            } else {
+                a = interp1d_eval<R>((double)v, false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd);
+            }
             R y = kind ? apply_corr<R>(v, a, kind) : a;
-            if (scaling) y = apply_corr<R>(y, tr, kind);
-            o[t * ost] = y;
-            if (node) node[(size_t)c * T + t] = nd;
+            if constexpr (DQM) y = apply_corr<R>(y, tr, kind);
+            o[t] = y;
+            if (ndc) ndc[t] = nd;
         }
         __syncthreads();  // everyone is done with the table before the next cell overwrites it
     }

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     else if (sq > (double)qn[Q - 1]) { a = row[Q - 1]; flag_cell |= a != a; if (extrap != 0) a = __builtin_nanf(""); }
                     else {
                         int w;
-                        (void)row_nearest<float>(sq, qn, Q, &w);
+                        (void)row_nearest<float, double>(sq, qn, Q, &w);
                         a = row[w];
                         flag_cell |= a != a;
                     }
