@@ -62,11 +62,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     int *tmeta = reinterpret_cast<int *>(ty + QC::QMAX);        // [0] pairs, [1] yfirst, [2] ylast (bit patterns), [3] bad nodes
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + QC::off_red);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = tid >> 6;
     uint32_t *bits = reinterpret_cast<uint32_t *>(smem + QC::off_bits) + wid * BITW;
     uint16_t *pw = reinterpret_cast<uint16_t *>(smem + QC::off_pw) + wid * BITW;
 
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        int lane = tid & 63;  // opaque per cell: lane-derived addresses are recomputed, not spilled across the sort
+        __asm__ volatile("" : "+v"(lane));
         int nvalid;
         const uint16_t *sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid);
         uint16_t *r2buf = (sorted == idx1) ? idx0 : idx1;  // 2 * average rank per time step, 0 = no rank

@@ -83,27 +83,35 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
     uint32_t *cnthi = reinterpret_cast<uint32_t *>(smem + Cfg::off_cnthi);
     uint16_t *base = reinterpret_cast<uint16_t *>(smem + Cfg::off_base);
     uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // the thread index is made opaque per call: everything derived from it (addresses, element indexes) is then
+    // recomputed here instead of being hoisted out of the caller's cell loop and spilled to scratch across it
+    int tid = threadIdx.x;
+    __asm__ volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
         // ---------------- A. load, keys, range ----------------
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        const int Ti = (int)T;  // <= TPAD
         if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
             // all the loads of the series are issued before the first one is consumed (one HBM latency per array
-            // instead of one per 2048 elements)
+            // instead of one per 2048 elements).  They are unconditional — addresses clamped to the last full pair,
+            // out-of-range results replaced by NaN afterwards — so that nothing orders them behind a branch.
             constexpr int NL = (EPT + 1) / 2;
+            const int Te = Ti & ~1;                 // elements covered by whole pairs (T >= 64)
+            const float xlast = x[Ti - 1];          // the odd tail element, uniform address
             float2 v2[NL];
 #pragma unroll
             for (int j = 0; j < NL; j++) {
                 const int i = 2 * tid + j * 2 * NT;
-                v2[j] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
-                if (i + 1 < T) v2[j] = *reinterpret_cast<const float2 *>(x + i);
-                else if (i < T) v2[j].x = x[i];
+                v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
             }
 #pragma unroll
             for (int j = 0; j < NL; j++) {
                 const int i = 2 * tid + j * 2 * NT;
                 if (i < TPAD) {
-                    uint32_t k0 = to_key(v2[j].x), k1 = to_key(v2[j].y);
+                    float a = v2[j].x, b = v2[j].y;
+                    if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
+                    uint32_t k0 = to_key(a), k1 = to_key(b);
                     *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
                     if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
                     if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
@@ -111,7 +119,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
             }
         } else {
             for (int i = tid; i < TPAD; i += NT) {
-                uint32_t k = i < T ? to_key(x[i]) : 0xFFFFFFFFu;
+                uint32_t k = i < Ti ? to_key(x[i]) : 0xFFFFFFFFu;
                 keys[i] = k;
                 if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
             }
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg::off_bits);
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = tid >> 6;
     // persistent-style grid: each block walks its cells grid-stride
     // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
     unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
@@ -280,6 +288,9 @@ __global__ __launch_bounds__(1024) void k_train_cell(
     bool flag_cell = false;
 
     for (int arr = 0; arr < npass_arr; arr++) {
+        // opaque per pass: lane-derived addresses are recomputed here, not kept live (spilled) across the sort
+        int lane = tid & 63;
+        __asm__ volatile("" : "+v"(lane));
         // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
         // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
         const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
