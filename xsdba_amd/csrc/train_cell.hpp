@@ -429,8 +429,9 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 if (vh && n && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
             }
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
-            // rank-space position of the j-th member of this half's vector
-            auto select_rank = [&](int j, int &L, int &wi, int &pos, uint32_t (&wv)[WPL]) {
+            // rank-space positions of the j-th member of this half's vector (lrank) and of the member after it (hrank;
+            // found = it lies in the same lane's words)
+            auto select_pair = [&](int j, int &L, int &lrank, int &hrank, bool &found) {
                 // owner lane: the last lane whose exclusive count is <= j.  Branch-free bisection on the raw
                 // ds_bpermute (byte-addressed lane index kept pre-shifted), this half's 16-bit field by one v_bfe
                 int L4 = 0, eL = 0;
@@ -446,31 +447,47 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 L = L4 >> 2;
                 int rem = j - eL;
                 const uint32_t *wp = bits_h + L * WPL;
+                uint32_t wv[WPL];
 #pragma unroll
                 for (int i = 0; i < WPL; i++) wv[i] = wp[i];
-                int sub = 0, run = 0;
-                wi = 0;
-#pragma unroll
-                for (int i = 0; i < WPL - 1; i++) {
-                    int ci = __popc(wv[i]);
-                    run += ci;
-                    bool ge = rem >= run;
-                    wi += ge ? 1 : 0;
-                    sub += ge ? ci : 0;
-                }
-                rem -= sub;
+                // the word holding the rem-th member: running popcounts, monotone selects
+                bool ge[WPL];
+                int run = 0, sub = 0, wi = 0;
                 uint32_t w = wv[0];
 #pragma unroll
-                for (int i = 1; i < WPL; i++) w = (wi == i) ? wv[i] : w;
-                pos = 0;
+                for (int i = 0; i < WPL - 1; i++) {
+                    run += __popc(wv[i]);
+                    ge[i] = rem >= run;
+                    w = ge[i] ? wv[i + 1] : w;
+                    sub = ge[i] ? run : sub;
+                    wi = ge[i] ? i + 1 : wi;
+                }
+                rem -= sub;
+                // first non-empty word after it (scanned backwards, the nearest one wins)
+                int nw = 0;
+                uint32_t nwv = 0u;
+#pragma unroll
+                for (int i = WPL - 1; i >= 1; i--) {
+                    const bool c = wv[i] != 0u && !ge[i - 1];  // i > wi
+                    nw = c ? i : nw;
+                    nwv = c ? wv[i] : nwv;
+                }
+                const uint32_t wsel = w;
+                int pos = 0;
 #pragma unroll
                 for (int s = 16; s > 0; s >>= 1) {
                     int cw = __popc(w & ((1u << s) - 1u));
-                    bool ge = rem >= cw;
-                    rem -= ge ? cw : 0;
-                    w = ge ? (w >> s) : w;
-                    pos += ge ? s : 0;
+                    bool g2 = rem >= cw;
+                    rem -= g2 ? cw : 0;
+                    w = g2 ? (w >> s) : w;
+                    pos += g2 ? s : 0;
                 }
+                const int wbase = L * WPL * 32;
+                lrank = wbase + wi * 32 + pos;
+                const uint32_t rest = (wsel >> pos) >> 1;  // members above pos in the same word
+                const bool inword = rest != 0u;
+                found = inword || nw != 0;
+                hrank = inword ? lrank + __ffs((int)rest) : wbase + nw * 32 + __ffs((int)nwv) - 1;
             };
             if (debug_phase == 3 || debug_phase == 4) { if (n == 12345 && lane == 0) out_hq[obase] = (float)exclp; continue; }
             for (int kb = 0; kb < Q; kb += 32) {
@@ -490,26 +507,10 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
                 }
                 stamp(2);  // DQM mean, quantile index math
-                int L, wi, pos;
-                uint32_t wv[WPL];
-                select_rank(lo, L, wi, pos, wv);
-                stamp(3);  // select(lo)
-                const int lrank = (L * WPL + wi) * 32 + pos;
-                // upper neighbour = next set bit: same word, then the owner lane's following words
-                uint32_t wfull = wv[0];
-#pragma unroll
-                for (int i = 1; i < WPL; i++) wfull = (wi == i) ? wv[i] : wfull;
-                uint32_t rest = pos < 31 ? (wfull >> (pos + 1)) : 0u;
-                bool found = rest != 0u;
-                int hwi = wi, hpos = pos + 1 + (found ? __ffs((int)rest) - 1 : 0);
-#pragma unroll
-                for (int i = 1; i < WPL; i++) {
-                    bool take = !found && i > wi && wv[i] != 0u;
-                    hwi = take ? i : hwi;
-                    hpos = take ? __ffs((int)wv[i]) - 1 : hpos;
-                    found = found || take;
-                }
-                int hrank = (L * WPL + hwi) * 32 + hpos;
+                int L, lrank, hrank;
+                bool found;
+                select_pair(lo, L, lrank, hrank, found);
+                stamp(3);  // select(lo) + next member in the owner lane's words
                 const bool need_slow = casek == 0 && !found;  // the next member lives in another lane's words
                 if (__any(need_slow)) {
                     // (nearly every round has such a lane) it is the first member of the next lane that holds any:
@@ -517,17 +518,13 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     const unsigned long long restm = L < 63 ? ((half ? ballotB : ballotA) >> (L + 1)) : 0ull;
                     const int L2 = restm ? L + __ffsll(restm) : L;
                     const uint32_t *wp2 = bits_h + L2 * WPL;
+                    uint32_t w2[WPL];
 #pragma unroll
-                    for (int i = 0; i < WPL; i++) wv[i] = wp2[i];  // wv is dead by now: reuse its registers
-                    bool f2 = false;
+                    for (int i = 0; i < WPL; i++) w2[i] = wp2[i];
                     int hr2 = 0;
 #pragma unroll
-                    for (int i = 0; i < WPL; i++) {
-                        const bool take = !f2 && wv[i] != 0u;
-                        hr2 = take ? (L2 * WPL + i) * 32 + __ffs((int)wv[i]) - 1 : hr2;
-                        f2 = f2 || take;
-                    }
-                    if (need_slow) hrank = hr2;
+                    for (int i = WPL - 1; i >= 0; i--) hr2 = w2[i] != 0u ? i * 32 + __ffs((int)w2[i]) - 1 : hr2;
+                    if (need_slow) hrank = L2 * WPL * 32 + hr2;
                 }
                 stamp(5);  // next set bit (+ second select)
                 // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
