@@ -315,38 +315,40 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             continue;
         }
         // ---------------- C. membership bit-vectors in rank space + select ----------------
-        // The groups are cut into 2*NWAVE contiguous chunks; every wave walks TWO chunks in lock-step, one per
-        // half-wave (lanes 0-31: chunk A, lanes 32-63: chunk B), each with its own bit-vector.  Lane k of a half
+        // Every wave owns a contiguous range [r0, r1) of groups and walks it OUTWARD from its middle gc with two
+        // bit-vectors in lock-step, one per half-wave: lanes 0-31 (stream A) take gc, gc+1, ... upward, lanes 32-63
+        // (stream B) take gc-1, gc-2, ... downward.  The vector of group gc is built once from its row list and
+        // copied to B (XOR lists work in both directions), which halves the number of builds.  Lane k of a half
         // serves quantile k: it selects the lower neighbour, then finds the upper one as the next set bit.
-        constexpr int NCH = 2 * Cfg::NWAVE;
-        const int gpc = (G + NCH - 1) / NCH;
+        const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
         const int half = lane >> 5;
         const unsigned hshift = 16u * (unsigned)half;
-        const int gA0 = min(G, (2 * wid) * gpc), gA1 = min(G, gA0 + gpc);
-        const int gB0 = min(G, (2 * wid + 1) * gpc), gB1 = min(G, gB0 + gpc);
+        const int r0 = min(G, wid * gpw), r1 = min(G, r0 + gpw);
+        const int gc = r0 + (r1 - r0) / 2;
+        const int cntA = r1 - gc, cntB = gc - r0;  // cntA >= cntB
         uint32_t *bitsA = bits_all + (2 * wid) * BITW, *bitsB = bitsA + BITW;
-        for (int i = lane; i < 2 * BITW; i += 64) bitsA[i] = 0u;
+        for (int i = lane; i < BITW; i += 64) bitsA[i] = 0u;
         lds_wave_fence();
         const uint32_t *bits_h = half ? bitsB : bitsA;
         double gsumA = 0.0, gsumB = 0.0;
-        // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select
+        // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select.
+        // "list r" is the symmetric difference of rows r-1 and r: row r of the padded [G][64] table tog64 (when every
+        // list has <= 64 entries, e.g. doy windows: one independent vector load, no pointer chase through SMEM), else
+        // tog_idx[tog_ptr[r-1] .. tog_ptr[r])
         int preA = -1, preA_len = 0, preA_base = 0, preB = -1, preB_len = 0, preB_base = 0;
-        // tog64 (when every toggle list has <= 64 entries, e.g. doy windows): row g of a [G][64] table padded with -1
-        // holds the list g-1 -> g, so the prefetch is one independent vector load (no pointer chase through SMEM)
-        if (TOG64) {
-            if (gA0 + 1 < gA1) preA = tog64[(size_t)(gA0 + 1) * 64 + lane];
-            if (gB0 + 1 < gB1) preB = tog64[(size_t)(gB0 + 1) * 64 + lane];
-        } else {
-            if (gA0 + 1 < gA1) { preA_base = tog_ptr[gA0]; preA_len = tog_ptr[gA0 + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
-            if (gB0 + 1 < gB1) { preB_base = tog_ptr[gB0]; preB_len = tog_ptr[gB0 + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
-        }
+        auto load_list = [&](int r, int &pre, int &base, int &len) {
+            if (TOG64) pre = tog64[(size_t)r * 64 + lane];
+            else { base = tog_ptr[r - 1]; len = tog_ptr[r] - base; pre = lane < len ? tog_idx[base + lane] : -1; }
+        };
+        if (cntA > 1) load_list(gc + 1, preA, preA_base, preA_len);  // A, it = 1: gc -> gc+1
+        if (cntB > 0) load_list(gc, preB, preB_base, preB_len);      // B, it = 0: gc -> gc-1
         // quantile-index math depends on (n, k) only: cached while both halves keep their n
         int nA_prev = -1, nB_prev = -1, c_case = 3, c_lo = 0;
         float c_gamma = 0.f;
-        const int n_iter = max(gA1 - gA0, gB1 - gB0);
+        const int n_iter = cntA;
         for (int it = 0; it < n_iter; it++) {
-            const int gA = gA0 + it, gB = gB0 + it;
-            const bool vA = gA < gA1, vB = gB < gB1;
+            const int gA = gc + it, gB = gc - 1 - it;
+            const bool vA = true, vB = it < cntB;
             stamp(-1);
             double dlocA = 0.0, dlocB = 0.0;
             // Toggles are issued in two waves of LDS traffic — all the rank reads, then all the XORs — because the
@@ -366,38 +368,35 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 }
             };
             if (it == 0) {
-                // initial build of both vectors from their row lists, 8 rounds (512 entries) at a time
-                auto build = [&](uint32_t *bits, int g, double &dloc) {
-                    const int *l = row_sorted + row_ptr[g];
-                    const int len = row_ptr[g + 1] - row_ptr[g];
-                    for (int i0 = 0; i0 < len; i0 += 512) {
-                        int ts[8], rs[8];
+                // the vector of the middle group from its row list, 8 rounds (512 entries) at a time, then copied to B
+                const int *l = row_sorted + row_ptr[gc];
+                const int len = row_ptr[gc + 1] - row_ptr[gc];
+                for (int i0 = 0; i0 < len; i0 += 512) {
+                    int ts[8], rs[8];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) { int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+                    for (int u = 0; u < 8; u++) { int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
 #pragma unroll
-                        for (int u = 0; u < 8; u++) rs[u] = ts[u] >= 0 ? (int)rank[ts[u]] : 0x7FFFFFFF;
+                    for (int u = 0; u < 8; u++) rs[u] = ts[u] >= 0 ? (int)rank[ts[u]] : 0x7FFFFFFF;
 #pragma unroll
-                        for (int u = 0; u < 8; u++) flip(bits, ts[u], rs[u], dloc);
-                    }
-                };
-                if (vA) build(bitsA, gA, dlocA);
-                if (vB) build(bitsB, gB, dlocB);
-            } else if (debug_phase != 4) {
+                    for (int u = 0; u < 8; u++) flip(bitsA, ts[u], rs[u], dlocA);
+                }
+                lds_wave_fence();
+#pragma unroll
+                for (int j = 0; j < WPL; j++) bitsB[lane + 64 * j] = bitsA[lane + 64 * j];
+                lds_wave_fence();
+            }
+            if (debug_phase != 4) {
                 // consume the lists prefetched during the previous group FIRST, then issue the next prefetch: the
-                // wait for tA/tB then never covers the loads just issued
-                const int tA = vA ? preA : -1, tB = vB ? preB : -1;
-                const int lenA = vA ? preA_len : 0, lenB = vB ? preB_len : 0, lbA = preA_base, lbB = preB_base;
+                // wait for tA/tB then never covers the loads just issued.  A: list gA (gA-1 -> gA), none for its
+                // first group; B: list gB+1 (gB+1 -> gB)
+                const bool doA = it > 0;
+                const int tA = doA ? preA : -1, tB = vB ? preB : -1;
+                const int lenA = doA ? preA_len : 0, lenB = vB ? preB_len : 0, lbA = preA_base, lbB = preB_base;
                 const int rA = tA >= 0 ? (int)rank[tA] : 0x7FFFFFFF, rB = tB >= 0 ? (int)rank[tB] : 0x7FFFFFFF;
                 flip(bitsA, tA, rA, dlocA);
                 flip(bitsB, tB, rB, dlocB);
-                if (vA) {
-                    if (TOG64) { if (gA + 1 < gA1) preA = tog64[(size_t)(gA + 1) * 64 + lane]; }
-                    else if (gA + 1 < gA1) { preA_base = tog_ptr[gA]; preA_len = tog_ptr[gA + 1] - preA_base; preA = lane < preA_len ? tog_idx[preA_base + lane] : -1; }
-                }
-                if (vB) {
-                    if (TOG64) { if (gB + 1 < gB1) preB = tog64[(size_t)(gB + 1) * 64 + lane]; }
-                    else if (gB + 1 < gB1) { preB_base = tog_ptr[gB]; preB_len = tog_ptr[gB + 1] - preB_base; preB = lane < preB_len ? tog_idx[preB_base + lane] : -1; }
-                }
+                if (it + 1 < cntA) load_list(gA + 1, preA, preA_base, preA_len);
+                if (it + 1 < cntB) load_list(gB, preB, preB_base, preB_len);
                 if (!TOG64) {  // lists longer than 64 entries (coarse groups)
                     for (int i = lane + 64; i < lenA; i += 64) { int t = tog_idx[lbA + i]; flip(bitsA, t, (int)rank[t], dlocA); }
                     for (int i = lane + 64; i < lenB; i += 64) { int t = tog_idx[lbB + i]; flip(bitsB, t, (int)rank[t], dlocB); }
@@ -421,8 +420,11 @@ __global__ __launch_bounds__(1024) void k_train_cell(
             const bool vh = half ? vB : vA;
             float mu = 0.f, inv = 0.f;
             if (DQM) {
-                gsumA += wave_sum(dlocA); gsumA = __shfl(gsumA, 0, 64);
-                gsumB += wave_sum(dlocB); gsumB = __shfl(gsumB, 0, 64);
+                // at it == 0 dlocA holds the sum of the built vector, which B starts from, and dlocB B's first toggles
+                const double sA = __shfl(wave_sum(dlocA), 0, 64), sB = __shfl(wave_sum(dlocB), 0, 64);
+                if (it == 0) gsumB = sA;
+                gsumA += sA;
+                gsumB += sB;
                 const double gs = half ? gsumB : gsumA;
                 mu = n ? (float)(gs / (double)n) : __builtin_nanf("");
                 inv = invert<float>(mu, kind);
