@@ -169,7 +169,18 @@ __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct
     if ((double)x > ct.xlast[g0]) return extrap == 0 ? ct.ylast[g0] : nan_of<R>();
     double best = __builtin_inf();
     R val = nan_of<R>();
-    for (int dr = 0; dr <= G + 1; dr++) {
+    {   // the element's own row first, outside the outward loop: its nearest node is almost always closer than
+        // one row step (d^2 < 1), which ends the search right here
+        const int n = ct.rn[g0];
+        if (n) {
+            int w;
+            best = row_nearest<R, XF>(x, ct.xs + (size_t)g0 * Q, n, &w);
+            val = ct.ys[(size_t)g0 * Q + w];
+            node = r * Q + w;
+        }
+        if (best <= 1.0) return val;
+    }
+    for (int dr = 1; dr <= G + 1; dr++) {
         double d2r = (double)dr * (double)dr;
         if (d2r >= best) break;
         for (int s = 0; s < (dr ? 2 : 1); s++) {

@@ -192,12 +192,21 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     const int n = G * Q;
     if (threadIdx.x == 0) *t.any = 0;
     bool has_nan = false;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        int g = i / Q, k = i - g * Q;
-        const R xv = xq[(size_t)g * xq_row_stride + k], yv = yq[i];
-        t.xs[i] = xv;
-        t.ys[i] = yv;
-        has_nan |= (xv != xv) || (yv != yv);
+    if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const R xv = xq[i], yv = yq[i];
+            t.xs[i] = xv;
+            t.ys[i] = yv;
+            has_nan |= (xv != xv) || (yv != yv);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int g = i / Q, k = i - g * Q;
+            const R xv = xq[(size_t)g * xq_row_stride + k], yv = yq[i];
+            t.xs[i] = xv;
+            t.ys[i] = yv;
+            has_nan |= (xv != xv) || (yv != yv);
+        }
     }
     if (!__syncthreads_or(has_nan ? 1 : 0)) {
         // the usual case, no NaN anywhere in the cell's table: rows are already compact
