@@ -565,18 +565,20 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
     const bool m_lds = getenv("XSDBA_HIP_TREND_MLDS") != nullptr;  // window means in LDS: measured slower (occupancy)
     int rc;
+    // regression layout: a lane per group when there are many short groups (day-of-year), else a half-wave per group
+    const int lane_per_group = (pl->G >= 128 && pl->max_mem <= 256) ? 1 : 0;
     if (m_lds && lds2 <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_group_trend<R, true>, lds2, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(trend_threads()), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(trend_threads()), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
     }
     return check_launch("k_group_trend");
 }

@@ -312,7 +312,7 @@ template <typename R, bool M_LDS>
 __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
-                              const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm)
+                              const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *coef = reinterpret_cast<double *>(smem);
@@ -385,8 +385,33 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n); m[t] = mean_of(s, n); }
     }
     __syncthreads();
-    // per-group least squares: one half-wave (32 lanes) per group, members loaded in parallel, sums by xor-shuffles
-    {
+    // per-group least squares.  Many short groups (day-of-year: 365 groups of ~30 members): one LANE per group, a
+    // serial loop over its members and no cross-lane reduction at all.
+    if (lane_per_group) {
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
+            double sx = 0, sy = 0;
+            int n = 0;
+            for (int p = p0; p < p1; p++) {
+                const int t = mem_idx[p];
+                const R v = m[t];
+                if (v == v) { sx += tnum[t]; sy += (double)v; n++; }
+            }
+            const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
+            double slope = 0.0;
+            if (degree >= 1 && n >= 2) {
+                double sxx = 0, sxy = 0;
+                for (int p = p0; p < p1; p++) {
+                    const int t = mem_idx[p];
+                    const R v = m[t];
+                    if (v == v) { const double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                }
+                slope = sxx > 0 ? sxy / sxx : 0.0;
+            }
+            coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
+        }
+    } else {
+        // few long groups: one half-wave (32 lanes) per group, members loaded in parallel, sums by xor-shuffles
         const int hw = threadIdx.x >> 5, nhw = blockDim.x >> 5, hl = threadIdx.x & 31;
         auto hsum = [](double v) {
 #pragma unroll
