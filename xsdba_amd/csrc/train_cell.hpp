@@ -259,68 +259,52 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         return sorted;
 }
 
-// DQM: dqm_train (group-mean normalisation + scaling); TOG64: the padded [G][64] toggle table is used.  Both are
-// template parameters (as are the timing aids under DIAG) so that the group loop carries no mode branches.
-template <int EPT, bool DIAG = false, bool DQM = false, bool TOG64 = false>
-__global__ __launch_bounds__(1024) void k_train_cell(
-    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
-    const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
-    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase_arg, int64_t C,
-    const int *__restrict__ tog64)
+// Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell) ...
+struct LdsVals {
+    const uint32_t *keys;      // [TPAD] order-preserving keys by time index
+    const uint16_t *sorted;    // [TPAD] time index by rank
+    int tpad;
+    __device__ __forceinline__ float at_time(int t) const { return from_key(keys[t]); }
+    // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
+    __device__ __forceinline__ void at_ranks(int r0, int r1, float &v0, float &v1) const
+    {
+        const int id0 = min((int)sorted[r0], tpad - 1), id1 = min((int)sorted[r1], tpad - 1);
+        v0 = from_key(keys[id0]);
+        v1 = from_key(keys[id1]);
+    }
+};
+// ... or the series itself and a per-block array of keys in rank order, both in global memory / L2 (k_train_long)
+struct GlobalVals {
+    const float *x;            // the cell's series
+    const uint32_t *by_rank;   // keys in rank order
+    __device__ __forceinline__ float at_time(int t) const { return x[t]; }
+    __device__ __forceinline__ void at_ranks(int r0, int r1, float &v0, float &v1) const
+    {
+        const uint32_t k0 = by_rank[r0], k1 = by_rank[r1];
+        v0 = from_key(k0);
+        v1 = from_key(k1);
+    }
+};
+
+// Phase C of the per-cell training kernels: the quantiles of every group of one series from rank[] (LDS, rank of each
+// time step in the sorted order, >= nvalid for NaN) — membership bit-vectors in rank space + select.
+// Geo: TPAD / WPL / BITW / NWAVE of the vectors.  Called by all 1024 threads; no block-level barrier inside.
+template <typename Geo, bool DIAG, bool DQM, bool TOG64, typename Vals, typename Stamp>
+__device__ __forceinline__ void cell_group_quantiles(
+    const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid, int lane, int wid,
+    const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr,
+    const int *__restrict__ tog_idx, const int *__restrict__ tog64, int G, const float *__restrict__ q, int Q, int kind,
+    int mode, int arr, int64_t c, float *__restrict__ af, float *out_hq, float *scaling, bool &flag_cell,
+    int debug_phase, Stamp &stamp)
 {
-    const int debug_phase = DIAG ? debug_phase_arg : 0;  // timing aids exist in the diagnostic build only
-    using Cfg = CellCfg<EPT>;
-    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, WPL = Cfg::WPL, BITW = Cfg::BITW;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
-    uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
-    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg::off_bits);
-    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
-
-    const int tid = threadIdx.x, wid = tid >> 6;
-    // persistent-style grid: each block walks its cells grid-stride
-    // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
-    unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
-    auto stamp = [&](int seg) { if constexpr (DIAG) { unsigned long long now = __builtin_readcyclecounter(); if (seg >= 0) tacc[seg] += now - tlast; tlast = now; } };
-    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
-    const int npass_arr = mode == 0 ? 1 : 2;
-    bool flag_cell = false;
-
-    for (int arr = 0; arr < npass_arr; arr++) {
-        // opaque per pass: lane-derived addresses are recomputed here, not kept live (spilled) across the sort
-        int lane = tid & 63;
-        __asm__ volatile("" : "+v"(lane));
-        // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
-        // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
-        const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
-        // ---------------- A + B. load, keys, LSD radix sort of the time indexes, rank[] ----------------
-        int nvalid;
-        const uint16_t *sorted = cell_load_sort<EPT>(x, T, smem, red, debug_phase == 1 ? 1 : (debug_phase == 2 ? 2 : 0), nvalid);
-        if (debug_phase == 1) continue;
-        if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
-        if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
-
-        // ---------------- C0. a single group holding every time step (group="time"): the sorted order IS the row
-        if (G == 1 && !DQM && row_ptr[1] - row_ptr[0] == (int)T) {
-            const int n = nvalid;
-            for (int k = tid; k < Q; k += NT) {
-                auto load = [&](int i) { return from_key(keys[sorted[i]]); };
-                float res = n ? quantile_sorted<float>(load, n, q[k]) : __builtin_nanf("");
-                const size_t o = (size_t)c * Q + k;
-                if (mode == 0 || arr == 0) out_hq[o] = res;
-                else af[o] = get_corr<float>(out_hq[o], res, kind);
-            }
-            __syncthreads();
-            continue;
-        }
+    constexpr int TPAD = Geo::TPAD, WPL = Geo::WPL, BITW = Geo::BITW;
         // ---------------- C. membership bit-vectors in rank space + select ----------------
         // Every wave owns a contiguous range [r0, r1) of groups and walks it OUTWARD from its middle gc with two
         // bit-vectors in lock-step, one per half-wave: lanes 0-31 (stream A) take gc, gc+1, ... upward, lanes 32-63
         // (stream B) take gc-1, gc-2, ... downward.  The vector of group gc is built once from its row list and
         // copied to B (XOR lists work in both directions), which halves the number of builds.  Lane k of a half
         // serves quantile k: it selects the lower neighbour, then finds the upper one as the next set bit.
-        const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
+        const int gpw = (G + Geo::NWAVE - 1) / Geo::NWAVE;
         const int half = lane >> 5;
         const unsigned hshift = 16u * (unsigned)half;
         const int r0 = min(G, wid * gpw), r1 = min(G, r0 + gpw);
@@ -360,7 +344,7 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                     const uint32_t m = 1u << (r & 31);
                     if (DQM) {
                         uint32_t old = atomicXor(&bits[r >> 5], m);
-                        float v = from_key(keys[t]);
+                        float v = vals.at_time(t);
                         dloc += (old & m) ? -(double)v : (double)v;
                     } else {
                         (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -531,8 +515,8 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 stamp(5);  // next set bit (+ second select)
                 // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
                 const int rs0 = min(lrank, TPAD - 1), rs1 = min(casek == 0 ? hrank : lrank, TPAD - 1);
-                const int id0 = min((int)sorted[rs0], TPAD - 1), id1 = min((int)sorted[rs1], TPAD - 1);
-                float v = from_key(keys[id0]), vhi = from_key(keys[id1]);
+                float v, vhi;
+                vals.at_ranks(rs0, rs1, v, vhi);
                 stamp(4);  // value lookups
                 if (DQM) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
                 float res;
@@ -557,6 +541,70 @@ __global__ __launch_bounds__(1024) void k_train_cell(
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced below
                 else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
             }
+        }
+}
+
+// DQM: dqm_train (group-mean normalisation + scaling); TOG64: the padded [G][64] toggle table is used.  Both are
+// template parameters (as are the timing aids under DIAG) so that the group loop carries no mode branches.
+template <int EPT, bool DIAG = false, bool DQM = false, bool TOG64 = false>
+__global__ __launch_bounds__(1024) void k_train_cell(
+    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
+    const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
+    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int debug_phase_arg, int64_t C,
+    const int *__restrict__ tog64)
+{
+    const int debug_phase = DIAG ? debug_phase_arg : 0;  // timing aids exist in the diagnostic build only
+    using Cfg = CellCfg<EPT>;
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
+    uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
+    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg::off_bits);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg::off_misc);
+
+    const int tid = threadIdx.x, wid = tid >> 6;
+    // persistent-style grid: each block walks its cells grid-stride
+    // diagnostic build (XSDBA_HIP_DEBUG_PHASE=9): cycle shares of the phase-C segments, written to out_hq[0..7]
+    unsigned long long tacc[DIAG ? 8 : 1] = {0}, tlast = 0;
+    auto stamp = [&](int seg) { if constexpr (DIAG) { unsigned long long now = __builtin_readcyclecounter(); if (seg >= 0) tacc[seg] += now - tlast; tlast = now; } };
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+    const int npass_arr = mode == 0 ? 1 : 2;
+    bool flag_cell = false;
+
+    for (int arr = 0; arr < npass_arr; arr++) {
+        // opaque per pass: lane-derived addresses are recomputed here, not kept live (spilled) across the sort
+        int lane = tid & 63;
+        __asm__ volatile("" : "+v"(lane));
+        // hist goes first: its quantiles are an output anyway and are read back (L2 / Infinity Cache) by the ref
+        // pass to form af, so nothing is parked in scratch and every output byte is written exactly once
+        const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
+        // ---------------- A + B. load, keys, LSD radix sort of the time indexes, rank[] ----------------
+        int nvalid;
+        const uint16_t *sorted = cell_load_sort<EPT>(x, T, smem, red, debug_phase == 1 ? 1 : (debug_phase == 2 ? 2 : 0), nvalid);
+        if (debug_phase == 1) continue;
+        if (debug_phase == 2) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)sorted[nvalid / 2]; __syncthreads(); continue; }
+        if (debug_phase == 5) { if (tid == 0) out_hq[(size_t)c * G * Q] = (float)rank[nvalid / 2]; __syncthreads(); continue; }
+
+        // ---------------- C0. a single group holding every time step (group="time"): the sorted order IS the row
+        if (G == 1 && !DQM && row_ptr[1] - row_ptr[0] == (int)T) {
+            const int n = nvalid;
+            for (int k = tid; k < Q; k += NT) {
+                auto load = [&](int i) { return from_key(keys[sorted[i]]); };
+                float res = n ? quantile_sorted<float>(load, n, q[k]) : __builtin_nanf("");
+                const size_t o = (size_t)c * Q + k;
+                if (mode == 0 || arr == 0) out_hq[o] = res;
+                else af[o] = get_corr<float>(out_hq[o], res, kind);
+            }
+            __syncthreads();
+            continue;
+        }
+        // ---------------- C. membership bit-vectors in rank space + select ----------------
+        {
+            const LdsVals vals{keys, sorted, TPAD};
+            cell_group_quantiles<Cfg, DIAG, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr,
+                                                         tog_idx, tog64, G, q, Q, kind, mode, arr, c, af, out_hq, scaling,
+                                                         flag_cell, debug_phase, stamp);
         }
         __syncthreads();  // all waves are done with keys / sorted / rank before the next array reuses them
     }
