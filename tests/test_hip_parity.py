@@ -460,6 +460,32 @@ def test_fast_train_fallback_cells(hip, train_kernel):
             assert_close(af, eaf, rtol=2e-6, atol=2e-4, what=f"dqm af {kind}")
 
 
+@pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5")])
+def test_long_series_train(hip, T, gname):
+    """11 265 .. 22 528 steps: the split-sort + merge kernel (k_train_long) — both toggle-table forms, an odd length,
+    the maximum length, NaNs, ties across the two halves, an all-NaN cell; EQM bit-exact, DQM within 2 ulp"""
+    rng = np.random.default_rng(T)
+    C = 3
+    gidx, G, W = GROUPINGS[gname](T)
+    q = _nodes(20)
+    for kind in "+*":
+        ref, hist, _ = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+        hist[0] = np.round(hist[0])          # ties, many of them between the two halves of the series
+        ref[2, : T // 2 + 7] = np.nan        # one half (and a bit) missing
+        if kind == "*":
+            hist[1] = np.nan
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+        assert_close(hq, ehq, rtol=0.0, what=f"hist_q {kind}")
+        assert_close(af, eaf, rtol=0.0, what=f"af {kind}")
+    ref, hist, _ = _synth(rng, C, T, "+", np.float32, nan_frac=0.01)
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, "+")
+    assert_close(sc, esc, rtol=2.4e-7, atol=2e-5, what="scaling")
+    assert_close(hq, ehq, rtol=2.4e-7, atol=1e-4, what="hist_q (dqm)")
+    assert_close(af, eaf, rtol=2.4e-7, atol=1e-4, what="af (dqm)")
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_vecquantiles_vs_oracle(hip, dtype):
     """nbutils.vecquantiles (a5): one quantile per row; NaN q, no valid value, a single value, q = 0 and 1"""

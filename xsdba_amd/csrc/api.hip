@@ -17,6 +17,7 @@
 #include "kernels.hpp"
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
+#include "train_long.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -469,6 +470,40 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
         }
     }
+    if constexpr (std::is_same<R, float>::value) {
+        // 11 265 .. 22 528 time steps (e.g. 60 years daily): split sort + merge, train_long.hpp
+        const char *force = getenv("XSDBA_HIP_TRAIN");
+        const bool fast_long = !fast && mode != 3 && pl->simple && T > 11 * 1024 && T <= xs::LongCfg::TPAD && G > 1 &&
+                               !(force && !strcmp(force, "rows"));
+        if (fast_long) {
+            void *flags, *scratch;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, 2 * ctx->n_cu);
+            if ((rc = ensure(ctx, S_SCR, xs::LongCfg::scratch_bytes * nblk, &scratch))) return rc;
+            auto go = [&](auto dqm, auto t64) -> int {
+                constexpr bool DQM = decltype(dqm)::value, TOG64 = decltype(t64)::value;
+                const size_t lds = xs::LongCfg::lds_bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_long<DQM, TOG64>, lds, ctx, "the per-cell sort"))) return rc2;
+                LaunchScope ls(ctx, "k_train_long");
+                hipLaunchKernelGGL((xs::k_train_long<DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
+                                   (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
+                                   flag_count, flag_list, C, pl->d_tog64, (unsigned char *)scratch,
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
+                return check_launch("k_train_long");
+            };
+            using std::false_type;
+            using std::true_type;
+            rc = mode == 2 ? (pl->d_tog64 ? go(true_type{}, true_type{}) : go(true_type{}, false_type{}))
+                           : (pl->d_tog64 ? go(false_type{}, true_type{}) : go(false_type{}, false_type{}));
+            if (rc) return rc;
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
+            fast = true;
+        }
+    }
     if (!fast && (rc = launch_rows(nullptr, nullptr, C))) return rc;
     if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
     return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
@@ -567,16 +602,18 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     int rc;
     // regression layout: a lane per group when there are many short groups (day-of-year), else a half-wave per group
     const int lane_per_group = (pl->G >= 128 && pl->max_mem <= 256) ? 1 : 0;
+    // the in-register window means hold 24 values per thread: long series take 1024 threads to stay on that path
+    const unsigned nthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();
     if (m_lds && lds2 <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_group_trend<R, true>, lds2, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
-        hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(trend_threads()), lds2, ctx->stream,
+        hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
                            pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
-        hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(trend_threads()), lds1, ctx->stream,
+        hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
                            pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
     }

@@ -259,7 +259,8 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         return sorted;
 }
 
-// Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell) ...
+// Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has
+// the global-memory counterpart
 struct LdsVals {
     const uint32_t *keys;      // [TPAD] order-preserving keys by time index
     const uint16_t *sorted;    // [TPAD] time index by rank
@@ -273,19 +274,6 @@ struct LdsVals {
         v1 = from_key(keys[id1]);
     }
 };
-// ... or the series itself and a per-block array of keys in rank order, both in global memory / L2 (k_train_long)
-struct GlobalVals {
-    const float *x;            // the cell's series
-    const uint32_t *by_rank;   // keys in rank order
-    __device__ __forceinline__ float at_time(int t) const { return x[t]; }
-    __device__ __forceinline__ void at_ranks(int r0, int r1, float &v0, float &v1) const
-    {
-        const uint32_t k0 = by_rank[r0], k1 = by_rank[r1];
-        v0 = from_key(k0);
-        v1 = from_key(k1);
-    }
-};
-
 // Phase C of the per-cell training kernels: the quantiles of every group of one series from rank[] (LDS, rank of each
 // time step in the sorted order, >= nvalid for NaN) — membership bit-vectors in rank space + select.
 // Geo: TPAD / WPL / BITW / NWAVE of the vectors.  Called by all 1024 threads; no block-level barrier inside.

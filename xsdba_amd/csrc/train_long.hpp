@@ -1,0 +1,149 @@
+// train_long.hpp — the per-cell training kernel for series of 11 265 .. 22 528 time steps (e.g. 60 years daily).
+//
+// One series no longer fits the LDS next to its sort scratch, so the sort is split:
+//   1. each HALF of the series goes through cell_load_sort<11> (the sort of k_train_cell); its keys in rank order and
+//      the matching time indexes are parked in a per-block global scratch slice (L2-resident);
+//   2. MERGE: both key sequences come back into LDS; every element finds its final rank as its position in its own
+//      half plus the count of smaller keys in the other half (bisection in LDS; equal keys: first half first) ->
+//      rank[t] (LDS) and the keys in final rank order (global scratch);
+//   3. phase C is the one of k_train_cell (cell_group_quantiles) with 704-word vectors; values are fetched from the
+//      series itself (DQM sums) and from the rank-ordered key array (order statistics), both L2 hits.
+// Same results as k_train_cell / k_train_rows: the rank order is a total order of the same keys, ties broken by time
+// (which never changes a quantile value).
+#pragma once
+#include "train_cell.hpp"
+
+namespace xs {
+
+struct LongCfg {
+    using H = CellCfg<11>;
+    static constexpr int NT = 1024, HALF = H::TPAD, TPAD = 2 * HALF;
+    static constexpr int NWORDS = TPAD / 32, WPL = (NWORDS + 63) / 64, BITW = WPL * 64, NWAVE = NT / 64;
+    // merge view of the LDS: [K0 | K1 | rank]; phase-C view: [2 * NWAVE vectors | rank]
+    static constexpr size_t off_k0 = 0, off_k1 = (size_t)HALF * 4, off_rank = (size_t)TPAD * 4;
+    static constexpr size_t off_bits = 0;
+    static_assert((size_t)2 * NWAVE * BITW * 4 <= off_rank, "the vectors must end before rank[]");
+    static_assert(off_rank + (size_t)TPAD * 2 <= H::off_misc, "rank[] must end before the reduction scratch");
+    static constexpr size_t lds_bytes = H::lds_bytes;
+    // per-block global scratch: keys in rank order of each half, their time indexes, keys in final rank order
+    static constexpr size_t scr_ks = 0, scr_ts = (size_t)TPAD * 4, scr_by_rank = scr_ts + (size_t)TPAD * 2;
+    static constexpr size_t scratch_bytes = scr_by_rank + (size_t)TPAD * 4;
+};
+
+// loads that must see what other threads of this workgroup stored to global memory: bypass the per-CU L1
+__device__ __forceinline__ uint32_t load_l2(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint16_t load_l2(const uint16_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ... after the storing waves have drained their stores (write-through to L2) and the workgroup has met at a barrier.
+// An agent-scope fence would also write back / invalidate caches for other workgroups, which nobody needs here.
+__device__ __forceinline__ void stores_done()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+struct GlobalValsL2 {
+    const float *x;
+    const uint32_t *by_rank;
+    __device__ __forceinline__ float at_time(int t) const { return x[t]; }
+    __device__ __forceinline__ void at_ranks(int r0, int r1, float &v0, float &v1) const
+    {
+        const uint32_t k0 = load_l2(by_rank + r0), k1 = load_l2(by_rank + r1);
+        v0 = from_key(k0);
+        v1 = from_key(k1);
+    }
+};
+
+template <bool DQM, bool TOG64>
+__global__ __launch_bounds__(1024) void k_train_long(
+    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
+    const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
+    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *out_hq, float *scaling,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64,
+    unsigned char *__restrict__ gscratch, int debug_phase)
+{
+    using H = CellCfg<11>;
+    using L = LongCfg;
+    constexpr int NT = L::NT, HALF = L::HALF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t *keys = reinterpret_cast<const uint32_t *>(smem + H::off_keys);  // sort view
+    uint32_t *K0 = reinterpret_cast<uint32_t *>(smem + L::off_k0), *K1 = reinterpret_cast<uint32_t *>(smem + L::off_k1);
+    uint16_t *rank = reinterpret_cast<uint16_t *>(smem + L::off_rank);
+    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + L::off_bits);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + H::off_misc);
+    unsigned char *scr = gscratch + (size_t)blockIdx.x * L::scratch_bytes;
+    uint32_t *ks = reinterpret_cast<uint32_t *>(scr + L::scr_ks);        // [2][HALF]
+    uint16_t *ts = reinterpret_cast<uint16_t *>(scr + L::scr_ts);        // [2][HALF]
+    uint32_t *by_rank = reinterpret_cast<uint32_t *>(scr + L::scr_by_rank);
+
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const int Ti = (int)T;
+    const int T0 = ((Ti / 2) + 1) & ~1;  // even: the second half keeps the 8-byte alignment of the row
+    auto nostamp = [](int) {};
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const int npass_arr = mode == 0 ? 1 : 2;
+        bool flag_cell = false;
+        for (int arr = 0; arr < npass_arr; arr++) {
+            int lane = tid & 63;
+            __asm__ volatile("" : "+v"(lane));
+            const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
+            // ---------------- 1. sort each half, park (key, time) in rank order ----------------
+            int nv[2];
+            for (int h = 0; h < 2; h++) {
+                const int Th = h ? Ti - T0 : T0;
+                const uint16_t *sorted = cell_load_sort<11>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h]);
+                for (int r = tid; r < HALF; r += NT) {
+                    const int id = sorted[r];
+                    ks[h * HALF + r] = keys[min(id, HALF - 1)];
+                    ts[h * HALF + r] = (uint16_t)id;
+                }
+                stores_done();
+                __syncthreads();  // the next sort (or the merge) overwrites keys / sorted
+            }
+            const int nv0 = nv[0], nv1 = nv[1], nvalid = nv0 + nv1;
+            if (debug_phase == 1) continue;  // timing aid: the two half sorts only
+            // ---------------- 2. merge: final rank of every time step ----------------
+            for (int r = tid; r < HALF; r += NT) { K0[r] = load_l2(ks + r); K1[r] = load_l2(ks + HALF + r); }
+            __syncthreads();
+            for (int h = 0; h < 2; h++) {
+                const int Th = h ? Ti - T0 : T0, nh = h ? nv1 : nv0, no = h ? nv0 : nv1;
+                const uint32_t *mine = h ? K1 : K0, *other = h ? K0 : K1;
+                for (int p = tid; p < HALF; p += NT) {
+                    const int id = load_l2(ts + h * HALF + p);
+                    if (id >= Th) continue;  // padding of the half-sort
+                    const int t = id + (h ? T0 : 0);
+                    if (p >= nh) { rank[t] = 0xFFFFu; continue; }  // NaN: never a member
+                    const uint32_t key = mine[p];
+                    int lo = 0, hi = no;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const uint32_t ko = other[mid];
+                        const bool before = h ? (ko <= key) : (ko < key);  // equal keys: the first half first
+                        if (before) lo = mid + 1; else hi = mid;
+                    }
+                    const int rf = p + lo;
+                    rank[t] = (uint16_t)rf;
+                    by_rank[rf] = key;
+                }
+            }
+            stores_done();
+            __syncthreads();  // rank[] complete, K0 / K1 dead: the vectors take their place
+            if (debug_phase == 2) continue;  // timing aid: sorts + merge
+            // ---------------- 3. group quantiles ----------------
+            {
+                const GlobalValsL2 vals{x, by_rank};
+                cell_group_quantiles<L, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr,
+                                                           tog_idx, tog64, G, q, Q, kind, mode, arr, c, af, out_hq, scaling,
+                                                           flag_cell, 0, nostamp);
+            }
+            __syncthreads();  // everyone is done with rank[] / the vectors before the next sort reuses the LDS
+        }
+        const int any = __syncthreads_or(flag_cell ? 1 : 0);
+        if (any && tid == 0 && flag_list) {
+            const int slot = atomicAdd(flag_count, 1);
+            flag_list[slot] = (int)c;
+        }
+    }
+}
+
+}  // namespace xs
