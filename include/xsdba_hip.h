@@ -148,6 +148,16 @@ int xsdba_hip_rank_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t 
                           int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
                           int32_t window, int rank_window, double *out, int64_t out_stride_t, int64_t out_stride_c);
 
+/* ---- f2: the max_tail_factor mask of qm_adjust / dqm_adjust / qdm_adjust (_adjustment.py:648-658 + 672-673,
+ * :734-746 + 775-776, :846-857 + 882-883): scen[c][t] <- sim[c][t] wherever
+ * sim[c][t] > max_tail_factor * hist_q_raw[c][group_of_time[t]][nq-1] (the product in the data dtype, as numpy's
+ * weak scalar promotion does; NaN or a time step in no group never masks).  scen is read and written in place
+ * (strides out_stride_*); hist_q_raw is [cell][group][quantile]. */
+int xsdba_hip_tail_mask(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                        int64_t stride_t, int64_t stride_c, const void *hist_q_raw, int32_t n_groups, int32_t nq,
+                        const int32_t *group_of_time, double max_tail_factor, void *scen, int64_t out_stride_t,
+                        int64_t out_stride_c);
+
 /* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
 int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
                                 int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,

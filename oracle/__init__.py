@@ -172,6 +172,20 @@ def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest",
     return scen, sim_q
 
 
+def tail_mask(sim, scen, hist_q_raw, gidx, max_tail_factor):
+    """scen with the max_tail_factor mask applied (a copy)"""
+    sim = np.asarray(sim)
+    Cn, T = sim.shape
+    out = np.array(scen, dtype=sim.dtype, order="C", copy=True)
+    hq = np.ascontiguousarray(hist_q_raw, sim.dtype)
+    G, Q = hq.shape[1], hq.shape[2]
+    g = np.zeros(T, np.int32) if gidx is None else np.ascontiguousarray(gidx, np.int32)
+    st, sc = _strides(sim)
+    _check(lib().xsdba_oracle_tail_mask(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(hq), C.c_int(G), C.c_int(Q),
+                                        _p(g), C.c_double(float(max_tail_factor)), _p(out), _i64(1), _i64(T)), "tail_mask")
+    return out
+
+
 def rank_groups(x, gidx, G, W, rank_window=False):
     x = np.asarray(x)
     Cn, T = x.shape

@@ -208,6 +208,30 @@ API int xsdba_oracle_qdm_adjust(const void *sim, int dtype, int64_t T, int64_t C
     return rc;
 }
 
+/* the max_tail_factor mask of qm_adjust / dqm_adjust / qdm_adjust (_adjustment.py:648-658 + 672-673): last_quantile =
+ * hist_q_raw.isel(quantiles=-1) broadcast on the group of each time step (utils.broadcast, "nearest" = the step's own
+ * group), mask = sim > max_tail_factor * last_quantile (python float * float32 array -> float32 product),
+ * scen = scen.where(~mask, sim).  In place on scen. */
+API int xsdba_oracle_tail_mask(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                               const void *hq_raw, int G, int Q, const int32_t *gidx, double factor, void *scen,
+                               int64_t ost, int64_t osc)
+{
+    for (int64_t c = 0; c < C; c++)
+        for (int64_t t = 0; t < T; t++) {
+            int g = G > 1 ? gidx[t] : 0;
+            if (g < 0 || g >= G) continue;
+            size_t iq = ((size_t)c * G + g) * Q + (Q - 1);
+            if (dtype == 0) {
+                float v = ((const float *)sim)[c * sc + t * st], lim = (float)factor * ((const float *)hq_raw)[iq];
+                if (v > lim) ((float *)scen)[c * osc + t * ost] = v;
+            } else {
+                double v = ((const double *)sim)[c * sc + t * st], lim = factor * ((const double *)hq_raw)[iq];
+                if (v > lim) ((double *)scen)[c * osc + t * ost] = v;
+            }
+        }
+    return 0;
+}
+
 /* utils.rank(pct=True) through Grouper.apply for every cell: out[c*osc + t*ost] float64 */
 API int xsdba_oracle_rank_groups(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
                                  const int32_t *gidx, int G, int W, int rank_window, double *out, int64_t ost,

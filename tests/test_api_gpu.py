@@ -204,6 +204,38 @@ class TestQDM:
         assert bool(np.isfinite(out.sim_q.values).all())
 
 
+@pytest.mark.parametrize("cls", ["EmpiricalQuantileMapping", "DetrendedQuantileMapping", "QuantileDeltaMapping"])
+@pytest.mark.parametrize("group", ["time", "time.month"])
+def test_max_tail_factor(random, cls, group):
+    """reference tests/test_adjustment.py:597-647 (DQM), :891-941 (QDM), :1131-1181 (EQM): an outlier far above
+    max_tail_factor x the largest hist quantile keeps its input value; without the option it is adjusted"""
+    def series(start, n, hi, seed_vals=None):
+        vals = random.uniform(0.001, hi, size=(n, 3))
+        if seed_vals is not None:
+            vals[0] = seed_vals
+        t = xs.date_range(start, n, "standard").values
+        return DataArray(vals, ("time", "lat"), {"time": t, "lat": np.arange(3)}, {"units": "mm d-1"})
+
+    n_hist = 31 * 365 + 8  # 1990-01-01 .. 2020-12-31
+    ref, hist = series("1990-01-01", n_hist, 20), series("1990-01-01", n_hist, 10)
+    sim = series("2021-01-01", 30 * 365 + 7, 10, seed_vals=300)
+    Adj = getattr(xs, cls)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        adj = Adj.train(ref, hist, kind="*", group=group)
+        scen = adj.adjust(sim)
+        assert float(scen.isel(time=0, lat=0).values) > 300
+        assert bool(np.isnan(adj.ds.hist_q_raw.values).all())  # dummy variable without the option
+        adj = Adj.train(ref, hist, kind="*", group=group, max_tail_factor=10)
+        assert not np.isnan(adj.ds.hist_q_raw.values).any()
+        scen10 = adj.adjust(sim)
+    assert float(scen10.isel(time=0, lat=0).values) == 300
+    # everything that is not masked is adjusted exactly as without the option
+    a, b = scen.transpose("lat", "time").values, scen10.transpose("lat", "time").values
+    assert (a != b).sum() == 3 and np.array_equal(a[:, 1:], b[:, 1:])
+    assert "max_tail_factor=10" in adj.ds.attrs["adj_params"]
+
+
 @pytest.mark.parametrize("interp,expi", [("nearest", 2.9), ("linear", 2.95)])
 @pytest.mark.parametrize("extrap,expe", [("constant", 4.4), ("nan", np.nan)])
 def test_interp_on_quantiles_constant(interp, expi, extrap, expe):

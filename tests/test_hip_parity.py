@@ -277,6 +277,32 @@ def test_qdm_nan_factors_fall_back(hip):
         assert_close(scen, escen, rtol=0.0, what=f"scen ({extrap})")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["time", "month", "doy31"])
+def test_tail_mask_vs_oracle(hip, gname, dtype):
+    """max_tail_factor mask (_adjustment.py:648-658, 672-673): bit-exact vs the oracle, host and device buffers, NaNs,
+    time steps in no group"""
+    rng = np.random.default_rng(11)
+    T, C = 2000, 5
+    gidx, G, W = GROUPINGS[gname](T)
+    gidx = gidx.copy()
+    if G > 1:
+        gidx[3::50] = -1
+    sim = rng.gamma(2.0, 4.0, (C, T)).astype(dtype)
+    sim[rng.random((C, T)) < 0.02] = np.nan
+    scen = (sim * 1.7).astype(dtype)
+    hq_raw = np.sort(rng.gamma(2.0, 4.0, (C, G, 12)), axis=-1).astype(dtype)
+    hq_raw[1, :, -1] = np.nan  # no limit for that cell: nothing masked
+    exp = oracle.tail_mask(sim, scen, hq_raw, gidx if G > 1 else None, 0.9)
+    assert 0 < (exp != scen)[~np.isnan(sim)].sum() < sim.size // 2
+    got = hip.tail_mask(sim, scen.copy(), hq_raw, gidx if G > 1 else None, 0.9)
+    assert_close(got, exp, rtol=0.0, what="tail_mask host")
+    ctx = hip.default_context()
+    d_sim, d_scen = ctx.to_device(sim), ctx.to_device(scen)
+    hip.tail_mask(d_sim, d_scen, hq_raw, gidx if G > 1 else None, 0.9)
+    assert_close(d_scen.download(), exp, rtol=0.0, what="tail_mask device")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

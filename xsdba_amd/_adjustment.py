@@ -4,8 +4,9 @@ qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` 
 body is ONE call into the HIP library that covers every group of every cell of the block.
 
 Not yet on the device path (rows "next" of SURVEY §8f; they raise NotImplementedError instead of running
-anything on the CPU): ``adapt_freq_thresh``, ``jitter_*``, ``max_tail_factor``, ``add_dims``,
+anything on the CPU): ``adapt_freq_thresh``, ``jitter_*``, ``add_dims``,
 grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+``max_tail_factor`` is on the device: ``hist_q_raw`` at training, ``hip.tail_mask`` after the adjustment.
 """
 from __future__ import annotations
 
@@ -72,13 +73,14 @@ def _prep_train(ds, group):
 def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
     _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
-                 max_tail_factor=max_tail_factor)
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
     af, hq = hip.eqm_train(r2, h2, gidx, G, group.window, q, kind)
-    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq,
-                         hist_q_raw=np.full_like(hq, np.nan))  # dummy unless max_tail_factor (:273-275)
+    # hist_q_raw = quantiles of hist BEFORE the pre-processing steps (:254-256); none of those runs here, so it equals
+    # hist_q; a NaN dummy unless max_tail_factor (:273-275)
+    hq_raw = hq.copy() if max_tail_factor is not None else np.full_like(hq, np.nan)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw)
     out["af"].attrs["kind"] = kind
     return out
 
@@ -86,13 +88,13 @@ def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitt
 def _fused_dqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
     _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
-                 max_tail_factor=max_tail_factor)
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
     af, hq, sc = hip.dqm_train(r2, h2, gidx, G, group.window, q, kind)
-    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq,
-                         hist_q_raw=np.full_like(hq, np.nan), scaling=sc)
+    # hist_q_raw: quantiles of the raw (not normalised) hist (:151-153)
+    hq_raw = hip.quantile_groups(h2, gidx, G, group.window, q) if max_tail_factor is not None else np.full_like(hq, np.nan)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, scaling=sc)
     out["af"].attrs["kind"] = kind
     out["scaling"].attrs["kind"] = kind
     return out
@@ -110,10 +112,10 @@ def dqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_
     """Train step on one group (the per-group body kept for ``Grouper.apply(dqm_train.func, ...)``;
     _adjustment.py:150-190): group-mean normalisation, quantiles, af, scaling."""
     _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
-                 max_tail_factor=max_tail_factor)
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref_dim = Grouper.filter_dim(ds.ref, dim)
     sim_dim = Grouper.filter_dim(ds.hist, dim)
+    hist_q_raw = nbu.quantile(ds.hist, quantiles, sim_dim) if max_tail_factor is not None else None
     mu_ref, mu_hist = ds.ref.mean(ref_dim), ds.hist.mean(sim_dim)
     refn = u.apply_correction(ds.ref, u.invert(mu_ref, kind), kind)
     histn = u.apply_correction(ds.hist, u.invert(mu_hist, kind), kind)
@@ -121,7 +123,9 @@ def dqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_
     hist_q = nbu.quantile(histn, quantiles, sim_dim)
     af = u.get_correction(hist_q, ref_q, kind)
     scaling = u.get_correction(mu_hist, mu_ref, kind=kind)
-    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": full_like(hist_q, np.nan), "scaling": scaling})
+    if hist_q_raw is None:
+        hist_q_raw = full_like(hist_q, np.nan)
+    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": hist_q_raw, "scaling": scaling})
 
 
 @map_groups(
@@ -134,12 +138,12 @@ def eqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_
               jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None) -> Dataset:
     """EQM: train step on one group (per-group body, _adjustment.py:253-286)."""
     _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd,
-                 max_tail_factor=max_tail_factor)
+                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref_q = nbu.quantile(ds.ref, quantiles, Grouper.filter_dim(ds.ref, dim))
     hist_q = nbu.quantile(ds.hist, quantiles, Grouper.filter_dim(ds.hist, dim))
     af = u.get_correction(hist_q, ref_q, kind)
-    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": full_like(hist_q, np.nan)})
+    hist_q_raw = hist_q.copy() if max_tail_factor is not None else full_like(hist_q, np.nan)
+    return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": hist_q_raw})
 
 
 def _prep_adjust(ds, group: Grouper, interp: str):
@@ -158,6 +162,15 @@ def _prep_adjust(ds, group: Grouper, interp: str):
     return sim, s2, gidx, G, cell_dims, cell_shape, dt
 
 
+def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor):
+    """mask no bias adjustment where sim is larger than n times the largest raw hist quantile (_adjustment.py:648-658,
+    672-673); the group broadcast of the reference is "nearest" for every grouping this path accepts"""
+    if max_tail_factor is None:
+        return scen
+    hq_raw = table_view(as_dataarray(ds["hist_q_raw"]), cell_dims, group.prop).astype(dt, copy=False)
+    return hip.tail_mask(s2, np.ascontiguousarray(scen), hq_raw, gidx if G > 1 else None, max_tail_factor)
+
+
 def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=None):
     coords = {k: c for k, c in sim.coords.items() if k in cell_dims or k == dim}
     return DataArray(arr.reshape(cell_shape + (arr.shape[-1],)), cell_dims + (dim,), coords, attrs or {}, name)
@@ -166,11 +179,12 @@ def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=No
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[])
 def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """QM (DQM and EQM): adjust step on one block (_adjustment.py:594-676)."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
     scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
 
@@ -178,7 +192,7 @@ def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None,
 def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
     means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     if isinstance(detrend, PolyDetrend):
         if detrend.group.name != group.name or detrend.group.window != group.window or detrend.kind != kind or detrend.preserve_mean or detrend.mult_skip_zeros:
             raise NotImplementedError("dqm_adjust on the HIP path takes detrend=<int> or a PolyDetrend on the same group/kind")
@@ -195,6 +209,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
     tnum = group._time_index(sim).numeric_ns
     scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "trend": _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")})
 
@@ -202,7 +217,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], sim_q=[])
 def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, rank_window=None, max_tail_factor=None) -> Dataset:
     """QDM adjustment on one block (_adjustment.py:783-886)."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh, max_tail_factor=max_tail_factor)
+    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     if rank_window is None:
         rank_window = False
         if group.window > 1:
@@ -221,5 +236,6 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
     quantiles = np.asarray(ds["quantiles"].values, dt)
     scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})

@@ -761,6 +761,49 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     return sync_if(ctx, o.copy_back || oq.copy_back || !is_device_ptr(sim));
 }
 
+template <typename R>
+int tail_mask_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *hq_raw,
+                   int G, int Q, const int32_t *gidx, double factor, void *scen, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || Q <= 0 || !hq_raw || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (T > (1ll << 30) || C > 65535ll * 65535ll) return fail(XSDBA_E_ARG, "series too long / too many cells");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
+    SeriesIn s, so;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    // scen is read-modify-write: its current values come in like an input series, the result leaves like an output
+    if ((rc = series_in<R>(ctx, S_IN1, S_CM1, scen, T, C, ost, osc, &so))) return rc;
+    const void *dhq;
+    if ((rc = stage_in(ctx, S_TAB0, hq_raw, (size_t)C * G * Q * sizeof(R), &dhq))) return rc;
+    const bool inplace = is_device_ptr(scen) && ost == 1;  // so.dev is the caller's buffer itself
+    R *dst = (R *)const_cast<void *>(so.dev);
+    {
+        LaunchScope ls(ctx, "k_tail_mask");
+        const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 64);
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t nc = std::min<int64_t>(65535, C - c0);
+            hipLaunchKernelGGL(xs::k_tail_mask<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream,
+                               (const R *)s.dev + c0 * s.sc, T, nc, s.sc, (const R *)dhq + (size_t)c0 * G * Q, G, Q, pl->d_gidx,
+                               (R)factor, dst + c0 * so.sc, so.sc);
+        }
+        if ((rc = check_launch("k_tail_mask"))) return rc;
+    }
+    if (!inplace) {
+        // the masked copy lives in library scratch (cell-major, row stride so.sc): send it back in the caller's layout
+        if (is_device_ptr(scen)) {
+            if ((rc = launch_transpose<R>(ctx, (const R *)dst, C, T, so.sc, 1, (R *)scen, osc, ost))) return rc;
+        } else {
+            SeriesOut o;
+            if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM2, scen, T, C, ost, osc, &o))) return rc;
+            if (so.sc == T) HIP_TRY(hipMemcpyAsync(o.kernel_dst, dst, (size_t)T * C * sizeof(R), hipMemcpyDeviceToDevice, ctx->stream));
+            else if ((rc = launch_transpose<R>(ctx, (const R *)dst, C, T, so.sc, 1, (R *)o.kernel_dst, T, 1))) return rc;
+            if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+        }
+    }
+    return sync_if(ctx, true);
+}
+
 int check_ctx(xsdba_hip_ctx *ctx)
 {
     if (!ctx) return fail(XSDBA_E_ARG, "null context");
@@ -1019,6 +1062,16 @@ API int xsdba_hip_rank_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int6
     if (rc) return rc;
     return DISPATCH(dtype, (qdm_impl<float>(ctx, x, T, C, st, sc, nullptr, nullptr, G, 0, gidx, W, rank_window, 0, 0, '+', nullptr, out, ost, osc)),
                     (qdm_impl<double>(ctx, x, T, C, st, sc, nullptr, nullptr, G, 0, gidx, W, rank_window, 0, 0, '+', nullptr, out, ost, osc)));
+}
+
+API int xsdba_hip_tail_mask(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                            const void *hist_q_raw, int32_t G, int32_t Q, const int32_t *gidx, double max_tail_factor,
+                            void *scen, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (tail_mask_impl<float>(ctx, sim, T, C, st, sc, hist_q_raw, G, Q, gidx, max_tail_factor, scen, ost, osc)),
+                    (tail_mask_impl<double>(ctx, sim, T, C, st, sc, hist_q_raw, G, Q, gidx, max_tail_factor, scen, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

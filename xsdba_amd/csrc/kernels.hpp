@@ -524,6 +524,26 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// max_tail_factor mask (_adjustment.py:648-658, 672-673): values above factor * (last raw hist quantile of their group)
+// keep the (pre-processed) input instead of the adjusted value.  Elementwise, cell-major rows, in place on scen.
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_tail_mask(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const R *__restrict__ hq_raw,
+                            int G, int Q, const int *__restrict__ gidx, R factor, R *__restrict__ scen, int64_t osc)
+{
+    const int64_t c = blockIdx.y;
+    const R *x = sim + c * sc;
+    R *o = scen + c * osc;
+    const R *last = hq_raw + (size_t)c * G * Q + (Q - 1);
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
+        const int g = G > 1 ? gidx[t] : 0;
+        if (g < 0) continue;
+        const R v = x[t], lim = factor * last[(size_t)g * Q];
+        if (v > lim) o[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // layout kernels: time-major / arbitrary strides <-> cell-major contiguous [cell][time]
 // ---------------------------------------------------------------------------------------------
 template <typename E>

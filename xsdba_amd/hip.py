@@ -209,6 +209,22 @@ def qdm_adjust(sim, af, quantiles, gidx, W, rank_window=False, interp="nearest",
     return scen, sim_q
 
 
+def tail_mask(sim, scen, hist_q_raw, gidx, max_tail_factor, ctx=None):
+    """the max_tail_factor mask (_adjustment.py:648-658, 672-673), in place on ``scen`` [C, T]: values of ``sim`` above
+    ``max_tail_factor`` times the last raw hist quantile of their group keep the input value"""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G, Q = hist_q_raw.shape[1], hist_q_raw.shape[2]
+    hq = _table(hist_q_raw, s.dtype, (s.C, G, Q))
+    g = _gidx(gidx, s.T, G)
+    if not s.dev and not (isinstance(scen, np.ndarray) and scen.dtype == s.dtype and scen.flags.c_contiguous and scen.shape == (s.C, s.T)):
+        raise ValueError("scen must be a C-contiguous [cell, time] array of the series dtype")
+    check(load().xsdba_hip_tail_mask(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                     _vp(hq), C.c_int(G), C.c_int(Q), _vp(g), C.c_double(float(max_tail_factor)), _vp(scen),
+                                     _i64(1), _i64(s.T)), "tail_mask")
+    return scen
+
+
 def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
     """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
     ctx = ctx or default_context()
@@ -234,5 +250,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]
