@@ -158,6 +158,27 @@ int xsdba_hip_tail_mask(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t 
                         const int32_t *group_of_time, double max_tail_factor, void *scen, int64_t out_stride_t,
                         int64_t out_stride_c);
 
+/* ---- f1: pre-processing in front of the quantile kernels.  Random draws are a pure function of
+ * (seed, first_cell + cell, time step, stream) — see xsdba_amd/csrc/preproc.hpp — so results are reproducible and do
+ * not depend on how cells are sharded over GPUs (pass the shard's first global cell index as first_cell).
+ *
+ * processing.jitter (processing.py:178-257): values < lower become U(nextafter(minimum), lower), values >= upper
+ * become U(upper, maximum); lower / upper = NaN switches that end off (minimum NaN = 0). */
+int xsdba_hip_jitter(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                     int64_t stride_c, double lower, double minimum, double upper, double maximum, uint64_t seed,
+                     int64_t first_cell, void *out, int64_t out_stride_t, int64_t out_stride_c);
+
+/* _processing._adapt_freq (_processing.py:20-142) for every (cell, group) block (dims [time, window] pooled).
+ * ref != NULL (training, _adjustment.py:64-65): P0_ref, P0_hist (float64 [cell][group]), pth (data dtype
+ * [cell][group]) and dP0 (nullable) are OUTPUTS.  ref == NULL (adjusting, _adjustment.py:639-645, window must be 1):
+ * P0_ref, P0_hist, pth are INPUTS from the training.  sim_ad [cell][time] (strides out_stride_*) receives sim with the
+ * frequency-adapted values. */
+int xsdba_hip_adapt_freq(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int dtype, int64_t n_time,
+                         int64_t n_cell, int64_t stride_t, int64_t stride_c, const int32_t *group_of_time,
+                         int32_t n_groups, int32_t window, double thresh, uint64_t seed, int64_t first_cell,
+                         double *P0_ref, double *P0_hist, void *pth, double *dP0, void *sim_ad,
+                         int64_t out_stride_t, int64_t out_stride_c);
+
 /* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
 int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
                                 int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,

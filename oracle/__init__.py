@@ -186,6 +186,38 @@ def tail_mask(sim, scen, hist_q_raw, gidx, max_tail_factor):
     return out
 
 
+def jitter(x, lower=None, minimum=None, upper=None, maximum=None, seed=0, first_cell=0):
+    x = np.ascontiguousarray(x)
+    Cn, T = x.shape
+    out = np.empty_like(x)
+    nan = float("nan")
+    f = lambda v: nan if v is None else float(v)  # noqa: E731
+    _check(lib().xsdba_oracle_jitter(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(1), _i64(T), C.c_double(f(lower)), C.c_double(f(minimum)),
+                                     C.c_double(f(upper)), C.c_double(f(maximum)), C.c_uint64(int(seed)), _i64(first_cell), _p(out),
+                                     _i64(1), _i64(T)), "jitter")
+    return out
+
+
+def adapt_freq(sim, ref, gidx, G, W, thresh, seed=0, first_cell=0, P0_ref=None, P0_hist=None, pth=None):
+    """returns (sim_ad, pth, dP0, P0_ref, P0_hist)"""
+    sim = np.ascontiguousarray(sim)
+    Cn, T = sim.shape
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    if ref is not None:
+        ref = np.ascontiguousarray(ref, sim.dtype)
+        P0_ref, P0_hist, pth = np.empty((Cn, G)), np.empty((Cn, G)), np.empty((Cn, G), sim.dtype)
+    else:
+        P0_ref, P0_hist = np.ascontiguousarray(P0_ref, np.float64), np.ascontiguousarray(P0_hist, np.float64)
+        pth = np.ascontiguousarray(pth, sim.dtype)
+    dP0 = np.empty((Cn, G))
+    out = np.empty_like(sim)
+    _check(lib().xsdba_oracle_adapt_freq(_p(sim), _p(ref) if ref is not None else None, _dt(sim), _i64(T), _i64(Cn), _i64(1), _i64(T),
+                                         _p(gidx), C.c_int(G), C.c_int(W), C.c_double(float(thresh)), C.c_uint64(int(seed)),
+                                         _i64(first_cell), _p(P0_ref), _p(P0_hist), _p(pth), _p(dP0), _p(out), _i64(1), _i64(T)),
+           "adapt_freq")
+    return out, pth, dP0, P0_ref, P0_hist
+
+
 def rank_groups(x, gidx, G, W, rank_window=False):
     x = np.asarray(x)
     Cn, T = x.shape

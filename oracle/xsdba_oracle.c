@@ -337,3 +337,150 @@ API int xsdba_oracle_vecquantiles(const void *x, int dtype, int64_t T, int64_t C
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Pre-processing rows.  The reference draws from numpy's unseeded global generator
+ * (processing.py:234, _processing.py:122), so only the distribution of its output is defined.  This restatement and
+ * the device kernels (xsdba_amd/csrc/preproc.hpp) share one counter-based generator, which pins them to each other
+ * bit for bit; the reference's own properties are checked statistically in tests/.
+ *   h(cell, t, stream) = mix64(mix64(seed ^ (cell + 1) * 0x9E3779B97F4A7C15) ^ (stream << 40) ^ t)
+ *   u53(h) = (h >> 11) * 2^-53;  streams: 1 jitter lower, 2 jitter upper, 3 adapt_freq tie-break, 4 adapt_freq fill.
+ * --------------------------------------------------------------------------------------------------------- */
+static uint64_t mix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static uint64_t rng_hash(uint64_t seed, int64_t cell, int64_t t, int stream)
+{
+    return mix64(mix64(seed ^ ((uint64_t)(cell + 1) * 0x9E3779B97F4A7C15ull)) ^ ((uint64_t)stream << 40) ^ (uint64_t)t);
+}
+static double u53(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+/* processing.jitter (processing.py:178-257): x < lower -> U(nextafter(minimum, +inf), lower); x >= upper ->
+ * U(upper, maximum) with maximum stepped down one ulp for dtypes narrower than float64; np.random.uniform(low, high)
+ * = low + (high - low) * random_sample() in float64, cast to the data dtype.  NaN lower / upper = off. */
+API int xsdba_oracle_jitter(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, double lower,
+                            double minimum, double upper, double maximum, uint64_t seed, int64_t cell0, void *out,
+                            int64_t ost, int64_t osc)
+{
+    if (!isnan(upper) && isnan(maximum)) return -1;
+    double m0 = isnan(minimum) ? 0.0 : minimum;
+    double jmin = dtype == 0 ? (double)nextafterf((float)m0, INFINITY) : nextafter(m0, INFINITY);
+    double jmax = dtype == 0 ? (double)nextafterf((float)maximum, -INFINITY) : maximum;
+    for (int64_t c = 0; c < C; c++)
+        for (int64_t t = 0; t < T; t++) {
+            double v = dtype == 0 ? (double)((const float *)x)[c * sc + t * st] : ((const double *)x)[c * sc + t * st];
+            double r = v;
+            if (!isnan(v)) {
+                if (!isnan(lower) && v < lower) r = jmin + (lower - jmin) * u53(rng_hash(seed, cell0 + c, t, 1));
+                if (!isnan(upper) && v >= upper) r = upper + (jmax - upper) * u53(rng_hash(seed, cell0 + c, t, 2));
+            }
+            if (dtype == 0) ((float *)out)[c * osc + t * ost] = (r == v) ? ((const float *)x)[c * sc + t * st] : (float)r;
+            else ((double *)out)[c * osc + t * ost] = r;
+        }
+    return 0;
+}
+
+typedef struct { double v; uint32_t tag; } af_item;
+static int af_cmp(const void *a, const void *b)
+{
+    const af_item *x = (const af_item *)a, *y = (const af_item *)b;
+    if (x->v < y->v) return -1;
+    if (x->v > y->v) return 1;
+    return x->tag < y->tag ? -1 : (x->tag > y->tag ? 1 : 0);
+}
+
+/* _processing._adapt_freq (_processing.py:75-142) on every (cell, group) block, dims [time, window] pooled; the time
+ * series keeps the window-centre element of each block (base.py:438-439).  ref != NULL: training branch (P0_ref,
+ * P0_hist, pth, dP0 are outputs); ref == NULL: adjust branch, the three are inputs (:76-83, 93-96).
+ *   P0 = ecdf(x, thresh) = #(x <= thresh) / #notnull (utils.py:87-105)                         [:90-92]
+ *   dP0 = where(P0_hist == 0, nan, (P0_hist - P0_ref) / P0_hist)                                [:94]
+ *   pth = vecquantiles(ref, P0_hist).where(dP0 > 0): np.nanquantile in float64, cast to dtype   [:103-105]
+ *   rnk = rank(sim, pct=True, use_random_tiebreak=True): a random order inside tie groups,
+ *         k/N rescaled mx*(rnk-mn)/(mx-mn) (utils.py:622-635)                                   [:109]
+ *   keep = (rnk < P0_ref/P0_hist*P0_sim) | (rnk > P0_sim) | isnull(sim)                         [:112]
+ *   sim_ad = sim where keep or no adaptation needed, else (pth - thresh) * U[0,1).astype(dtype) + thresh  [:115-122]
+ * Tie order: (value, 16 random bits of stream 3 mixed with the group, slot in the block). */
+API int xsdba_oracle_adapt_freq(const void *sim, const void *ref, int dtype, int64_t T, int64_t C, int64_t st,
+                                int64_t sc, const int32_t *gidx, int G, int W, double thresh, uint64_t seed,
+                                int64_t cell0, double *P0_ref, double *P0_hist, void *pth, double *dP0_out,
+                                void *sim_ad, int64_t ost, int64_t osc)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (rc) { plan_free(&pl); return rc; }
+    if (!ref && W != 1) { plan_free(&pl); return -1; }
+#define LOADV(p, c, t) (dtype == 0 ? (double)((const float *)(p))[(c) * sc + (t) * st] : ((const double *)(p))[(c) * sc + (t) * st])
+    af_item *items = (af_item *)malloc(sizeof(af_item) * (size_t)(pl.max_row + 1));
+    double *rbuf = (double *)malloc(sizeof(double) * (size_t)(pl.max_row + 1));
+    for (int64_t c = 0; c < C; c++) {
+        for (int64_t t = 0; t < T; t++) {  /* sim_ad starts as sim */
+            if (dtype == 0) ((float *)sim_ad)[c * osc + t * ost] = ((const float *)sim)[c * sc + t * st];
+            else ((double *)sim_ad)[c * osc + t * ost] = ((const double *)sim)[c * sc + t * st];
+        }
+        for (int g = 0; g < G; g++) {
+            int64_t p0 = pl.row_ptr[g], L = pl.row_ptr[g + 1] - p0;
+            size_t og = (size_t)c * G + g;
+            int64_t N = 0, n0 = 0;
+            for (int64_t i = 0; i < L; i++) {
+                double v = LOADV(sim, c, pl.row_idx[p0 + i]);
+                if (!isnan(v)) { N++; if (v <= thresh) n0++; }
+            }
+            double P0_sim = N ? (double)n0 / (double)N : NAN, p0r, p0h, pthv;
+            if (ref) {
+                int64_t nr = 0, c0r = 0;
+                for (int64_t i = 0; i < L; i++) {
+                    double v = LOADV(ref, c, pl.row_idx[p0 + i]);
+                    if (!isnan(v)) { rbuf[nr++] = v; if (v <= thresh) c0r++; }
+                }
+                p0r = nr ? (double)c0r / (double)nr : NAN;
+                p0h = P0_sim;
+                double d = p0h == 0.0 ? NAN : (p0h - p0r) / p0h;
+                pthv = NAN;
+                if (d > 0.0) {
+                    quick_sort_f64(rbuf, nr);
+                    pthv = vecq_sorted(rbuf, nr, p0h);
+                    if (dtype == 0) pthv = (double)(float)pthv;
+                }
+                P0_ref[og] = p0r; P0_hist[og] = p0h;
+                if (dtype == 0) ((float *)pth)[og] = (float)pthv; else ((double *)pth)[og] = pthv;
+            } else {
+                p0r = P0_ref[og]; p0h = P0_hist[og];
+                pthv = dtype == 0 ? (double)((const float *)pth)[og] : ((const double *)pth)[og];
+            }
+            double dP0 = p0h == 0.0 ? NAN : (p0h - p0r) / p0h;
+            if (dP0_out) dP0_out[og] = dP0;
+            if (!(dP0 > 0.0)) continue;
+            uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
+            int64_t m = 0;
+            for (int64_t i = 0; i < L; i++) {
+                int64_t tt = pl.row_idx[p0 + i];
+                double v = LOADV(sim, c, tt);
+                if (isnan(v)) continue;
+                items[m].v = v;
+                items[m].tag = ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)i;
+                m++;
+            }
+            qsort(items, (size_t)m, sizeof(af_item), af_cmp);
+            double lowb = (p0r / p0h) * P0_sim;
+            for (int64_t p = 0; p < m; p++) {
+                int64_t tt = pl.row_idx[p0 + (items[p].tag & 0xFFFFu)];
+                if (gidx[tt] != g) continue;
+                double rk = (double)(p + 1) / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
+                double rnk = mx * (rk - mn) / (mx - mn);
+                int keep = (rnk < lowb) || (rnk > P0_sim);
+                if (keep) continue;
+                double u = u53(rng_hash(seed, cell0 + c, tt, 4));
+                if (dtype == 0) ((float *)sim_ad)[c * osc + tt * ost] = ((float)pthv - (float)thresh) * (float)u + (float)thresh;
+                else ((double *)sim_ad)[c * osc + tt * ost] = (pthv - thresh) * u + thresh;
+            }
+        }
+    }
+#undef LOADV
+    free(items); free(rbuf);
+    plan_free(&pl);
+    return 0;
+}

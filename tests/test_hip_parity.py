@@ -303,6 +303,61 @@ def test_tail_mask_vs_oracle(hip, gname, dtype):
     assert_close(d_scen.download(), exp, rtol=0.0, what="tail_mask device")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_jitter_bit_exact_vs_oracle(hip, dtype):
+    """processing.jitter (processing.py:178-257): same counter-based draws on both sides -> bit-exact; open ends"""
+    rng = np.random.default_rng(2)
+    x = rng.gamma(0.6, 3.0, (7, 1500)).astype(dtype)
+    x[rng.random(x.shape) < 0.05] = np.nan
+    for kw in (dict(lower=1.0), dict(upper=8.0, maximum=12.0), dict(lower=0.5, minimum=0.1, upper=8.0, maximum=9.0)):
+        got = hip.jitter(x, seed=77, first_cell=5, **kw)
+        exp = oracle.jitter(x, seed=77, first_cell=5, **kw)
+        assert_close(got, exp, rtol=0.0, what=f"jitter {kw}")
+        lo, hi = kw.get("lower"), kw.get("upper")
+        if lo is not None:
+            m = x < lo
+            assert ((got[m] > kw.get("minimum", 0.0)) & (got[m] < lo)).all() and (got[m] != x[m]).all()
+        if hi is not None:
+            m = x >= hi
+            assert ((got[m] >= hi) & (got[m] < kw["maximum"])).all()
+        keep = ~((x < (lo if lo is not None else -np.inf)) | (x >= (hi if hi is not None else np.inf)))
+        assert np.array_equal(got[keep], x[keep], equal_nan=True)
+    # another shard offset reproduces the same cells
+    a = hip.jitter(x[3:], lower=1.0, seed=77, first_cell=8)
+    assert np.array_equal(a, hip.jitter(x, lower=1.0, seed=77, first_cell=5)[3:], equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["time", "month", "doy31", "doy1"])
+def test_adapt_freq_bit_exact_vs_oracle(hip, gname, dtype):
+    """_processing._adapt_freq (_processing.py:75-142), training and adjust branches: P0 / dP0 / pth and the adapted
+    series bit-exact vs the oracle (shared counter-based generator), NaNs, cells that need no adaptation"""
+    rng = np.random.default_rng(4)
+    T, C = 2920, 6
+    gidx, G, W = GROUPINGS[gname](T)
+    pr = rng.uniform(0, 40, (C, T))
+    sim = np.where(pr < 20, pr / 20, pr).astype(dtype)   # 50 % under 1
+    ref = np.where(pr < 10, pr / 20, pr).astype(dtype)   # 25 % under 1
+    sim[0, ::4] = 0.0                                     # many exact ties
+    ref[1] = sim[1]                                       # no adaptation needed
+    sim[2, rng.random(T) < 0.05] = np.nan
+    ref[3] = np.nan                                       # undefined P0_ref
+    sim[4] = 5.0                                          # nothing under the threshold
+    e = oracle.adapt_freq(sim, ref, gidx, G, W, 1.0, seed=9, first_cell=2)
+    h = hip.adapt_freq(sim, ref, gidx, G, W, 1.0, seed=9, first_cell=2)
+    for name, a, b in zip(("sim_ad", "pth", "dP0", "P0_ref", "P0_hist"), h, e):
+        assert_close(a, b, rtol=0.0, what=f"adapt_freq train {name}")
+    changed = ~np.isclose(h[0], sim, equal_nan=True)
+    assert changed[0].any() and not changed[1].any() and not changed[3].any() and not changed[4].any()
+    assert (sim[changed] <= 1.0).all() and (h[0][changed] >= 1.0).all()
+    # adjust branch: the trained tables on the groups without window
+    sim2 = np.where(pr[:, ::-1] < 22, pr[:, ::-1] / 22, pr[:, ::-1]).astype(dtype)
+    e2 = oracle.adapt_freq(sim2, None, gidx, G, 1, 1.0, seed=10, first_cell=2, P0_ref=e[3], P0_hist=e[4], pth=e[1])
+    h2 = hip.adapt_freq(sim2, None, gidx, G, 1, 1.0, seed=10, first_cell=2, P0_ref=e[3], P0_hist=e[4], pth=e[1])
+    assert_close(h2[0], e2[0], rtol=0.0, what="adapt_freq adjust sim_ad")
+    assert_close(h2[2], e2[2], rtol=0.0, what="adapt_freq adjust dP0")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

@@ -10,6 +10,7 @@
 #include <string>
 #include <type_traits>
 #include <iterator>
+#include <limits>
 #include <cstdlib>
 #include <vector>
 
@@ -18,6 +19,7 @@
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
 #include "train_long.hpp"
+#include "preproc.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -804,6 +806,92 @@ int tail_mask_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, in
     return sync_if(ctx, true);
 }
 
+// ---- pre-processing ---------------------------------------------------------------------
+template <typename R> R next_up(R v) { return std::nextafter(v, std::numeric_limits<R>::infinity()); }
+template <typename R> R next_down(R v) { return std::nextafter(v, -std::numeric_limits<R>::infinity()); }
+
+template <typename R>
+int jitter_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, double lower, double minimum,
+                double upper, double maximum, uint64_t seed, int64_t cell0, void *out, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || !out) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (upper == upper && !(maximum == maximum)) return fail(XSDBA_E_ARG, "If 'upper' is given, so must 'maximum'.");
+    if (T > (1ll << 30)) return fail(XSDBA_E_ARG, "series too long");
+    int rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x, T, C, st, sc, &s))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, out, T, C, ost, osc, &o))) return rc;
+    // processing.py:223-225, 245-251: the open ends are stepped by one ulp in the data dtype
+    const double jmin = (double)next_up<R>((R)(minimum == minimum ? minimum : 0.0));
+    const double jmax = sizeof(R) < 8 ? (double)next_down<R>((R)maximum) : maximum;
+    {
+        LaunchScope ls(ctx, "k_jitter");
+        const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 64);
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t nc = std::min<int64_t>(65535, C - c0);
+            hipLaunchKernelGGL(xs::k_jitter<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream, (const R *)s.dev + c0 * s.sc, T,
+                               s.sc, lower, jmin, upper, jmax, seed, cell0 + c0, (R *)o.kernel_dst + c0 * T, T);
+        }
+        if ((rc = check_launch("k_jitter"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || !is_device_ptr(x));
+}
+
+template <typename R>
+int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_t T, int64_t C, int64_t st, int64_t sc,
+                    const int32_t *gidx, int G, int W, double thresh, uint64_t seed, int64_t cell0, double *P0_ref,
+                    double *P0_hist, void *pth, double *dP0, void *sim_ad, int64_t ost, int64_t osc)
+{
+    using U = typename xs::KeyOf<R>::U;
+    if (C <= 0 || !P0_ref || !P0_hist || !pth || !sim_ad) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (!ref && W != 1) return fail(XSDBA_E_ARG, "adapt_freq on the adjust side runs on the groups without window (window must be 1)");
+    if ((int64_t)C * G > (1ll << 31) - 1) return fail(XSDBA_E_ARG, "n_cell * n_groups exceeds 2^31");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    if (!pl->simple) return fail(XSDBA_E_UNSUPPORTED, "adapt_freq: a time step occurs twice in one group block (coarse group + window)");
+    if (pl->max_row > 65535) return fail(XSDBA_E_ROW_TOO_LONG, "adapt_freq: group block of %d values (max 65535)", pl->max_row);
+    SeriesIn s, r;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    if (ref && (rc = series_in<R>(ctx, S_IN1, S_CM1, ref, T, C, st, sc, &r))) return rc;
+    const size_t ng = (size_t)C * G;
+    OutStage o0, o1, o2, o3;  // P0_ref, P0_hist, pth, dP0: outputs when training, inputs when adjusting
+    const void *i0 = nullptr, *i1 = nullptr, *i2 = nullptr;
+    if (ref) {
+        if ((rc = stage_out(ctx, S_TAB0, P0_ref, ng * sizeof(double), &o0)) || (rc = stage_out(ctx, S_TAB1, P0_hist, ng * sizeof(double), &o1)) ||
+            (rc = stage_out(ctx, S_TAB2, pth, ng * sizeof(R), &o2))) return rc;
+    } else {
+        if ((rc = stage_in(ctx, S_TAB0, P0_ref, ng * sizeof(double), &i0)) || (rc = stage_in(ctx, S_TAB1, P0_hist, ng * sizeof(double), &i1)) ||
+            (rc = stage_in(ctx, S_TAB2, pth, ng * sizeof(R), &i2))) return rc;
+    }
+    if ((rc = stage_out(ctx, S_MISC, dP0, ng * sizeof(double), &o3))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM2, sim_ad, T, C, ost, osc, &o))) return rc;
+    // sim_ad starts as a copy of sim (cell-major): untouched values and time steps in no group keep it
+    if (s.sc == T) HIP_TRY(hipMemcpyAsync(o.kernel_dst, s.dev, (size_t)T * C * sizeof(R), hipMemcpyDeviceToDevice, ctx->stream));
+    else if ((rc = launch_transpose<R>(ctx, (const R *)s.dev, C, T, s.sc, 1, (R *)o.kernel_dst, T, 1))) return rc;
+    int P = 2;
+    while (P < pl->max_row) P <<= 1;
+    const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+    const size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * (sizeof(U) + sizeof(uint32_t));
+    if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq row sort"))) return rc;
+    {
+        LaunchScope ls(ctx, "k_adapt_freq");
+        hipLaunchKernelGGL(xs::k_adapt_freq<R>, dim3((unsigned)ng), dim3(NT), lds, ctx->stream, (const R *)s.dev,
+                           ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
+                           pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
+                           ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
+                           (double *)o3.dev, (R *)o.kernel_dst, T, P);
+        if ((rc = check_launch("k_adapt_freq"))) return rc;
+    }
+    if (ref && ((rc = finish_out(ctx, &o0)) || (rc = finish_out(ctx, &o1)) || (rc = finish_out(ctx, &o2)))) return rc;
+    if ((rc = finish_out(ctx, &o3))) return rc;
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, true);
+}
+
 int check_ctx(xsdba_hip_ctx *ctx)
 {
     if (!ctx) return fail(XSDBA_E_ARG, "null context");
@@ -1072,6 +1160,27 @@ API int xsdba_hip_tail_mask(xsdba_hip_ctx *ctx, const void *sim, int dtype, int6
     if (rc) return rc;
     return DISPATCH(dtype, (tail_mask_impl<float>(ctx, sim, T, C, st, sc, hist_q_raw, G, Q, gidx, max_tail_factor, scen, ost, osc)),
                     (tail_mask_impl<double>(ctx, sim, T, C, st, sc, hist_q_raw, G, Q, gidx, max_tail_factor, scen, ost, osc)));
+}
+
+API int xsdba_hip_jitter(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, double lower,
+                         double minimum, double upper, double maximum, uint64_t seed, int64_t first_cell, void *out, int64_t ost,
+                         int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (jitter_impl<float>(ctx, x, T, C, st, sc, lower, minimum, upper, maximum, seed, first_cell, out, ost, osc)),
+                    (jitter_impl<double>(ctx, x, T, C, st, sc, lower, minimum, upper, maximum, seed, first_cell, out, ost, osc)));
+}
+
+API int xsdba_hip_adapt_freq(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int dtype, int64_t T, int64_t C, int64_t st,
+                             int64_t sc, const int32_t *gidx, int32_t G, int32_t W, double thresh, uint64_t seed,
+                             int64_t first_cell, double *P0_ref, double *P0_hist, void *pth, double *dP0, void *sim_ad,
+                             int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (adapt_freq_impl<float>(ctx, sim, ref, T, C, st, sc, gidx, G, W, thresh, seed, first_cell, P0_ref, P0_hist, pth, dP0, sim_ad, ost, osc)),
+                    (adapt_freq_impl<double>(ctx, sim, ref, T, C, st, sc, gidx, G, W, thresh, seed, first_cell, P0_ref, P0_hist, pth, dP0, sim_ad, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

@@ -1,0 +1,179 @@
+// preproc.hpp — the pre-processing steps that sit right before the quantile kernels for precipitation-like variables
+// (SURVEY §8 row f1): jitter (processing.py:178-257) and frequency adaptation (_processing.py:20-142).
+//
+// Both draw random numbers.  The reference uses numpy's unseeded global generator (processing.py:234,
+// _processing.py:122), so its output is not reproducible; here every draw is a pure function of
+// (seed, cell, time step, stream) — the same function in oracle/xsdba_oracle.c — so device results are reproducible,
+// independent of the launch geometry and bit-identical to the oracle:
+//     h(cell, t, stream) = mix64( mix64(seed ^ (cell + 1) * 0x9E3779B97F4A7C15) ^ (stream << 40) ^ t )
+//     u53(h) = (h >> 11) * 2^-53  in [0, 1)
+// streams: 1 jitter lower, 2 jitter upper, 3 adapt_freq tie-break, 4 adapt_freq fill.
+#pragma once
+#include "kernels.hpp"
+
+namespace xs {
+
+__device__ __forceinline__ uint64_t rng_hash(uint64_t seed, int64_t cell, int64_t t, int stream)
+{
+    return mix64(mix64(seed ^ ((uint64_t)(cell + 1) * 0x9E3779B97F4A7C15ull)) ^ ((uint64_t)stream << 40) ^ (uint64_t)t);
+}
+__device__ __forceinline__ double u53(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+// ---------------------------------------------------------------------------------------------
+// jitter (processing.py:178-257): values < lower (and not NaN) -> U(nextafter(minimum), lower);
+// values >= upper -> U(upper, maximum) (maximum stepped down once for dtypes narrower than float64).
+// np.random.uniform(low, high) = low + (high - low) * random_sample() in float64, cast to the data dtype.
+// lower / upper NaN = that end is off.  Cell-major rows.
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_jitter(const R *__restrict__ x, int64_t T, int64_t sc, double lower, double jmin, double upper, double jmax,
+                         uint64_t seed, int64_t cell0, R *__restrict__ out, int64_t osc)
+{
+    const int64_t c = blockIdx.y;
+    const R *xr = x + c * sc;
+    R *o = out + c * osc;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
+        const R v = xr[t];
+        R r = v;
+        if (v == v) {
+            if (lower == lower && (double)v < lower) r = (R)(jmin + (lower - jmin) * u53(rng_hash(seed, cell0 + c, t, 1)));
+            if (upper == upper && (double)v >= upper) r = (R)(upper + (jmax - upper) * u53(rng_hash(seed, cell0 + c, t, 2)));
+        }
+        o[t] = r;
+    }
+}
+
+// In-LDS bitonic sort of P (power of two) (key, tag) pairs, lexicographic order, by the whole block.
+template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U *keys, uint32_t *tags, int P)
+{
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < half; i += blockDim.x) {
+                int l = ((i & ~(j - 1)) << 1) | (i & (j - 1));
+                int r = l | j;
+                U a = keys[l], b = keys[r];
+                uint32_t ta = tags[l], tb = tags[r];
+                bool gt = a > b || (a == b && ta > tb);
+                bool up = (l & k) == 0;
+                if (gt == up) { keys[l] = b; keys[r] = a; tags[l] = tb; tags[r] = ta; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// adapt_freq (_processing.py:75-142), one workgroup per (cell, group) row (the group's windowed block, dims
+// [time, window] pooled; base.py:261-272):
+//   P0_sim = #(sim <= thresh) / #valid(sim)  (utils.ecdf :87-105), P0_ref likewise (training) or given (adjusting),
+//   dP0 = (P0_hist - P0_ref) / P0_hist (NaN when P0_hist == 0); nothing changes unless dP0 > 0;
+//   pth = np.nanquantile(ref row in float64, P0_hist) cast to the data dtype (nbutils.vecquantiles :164-195);
+//   rnk = percent rank of every value of the row with ties broken at random (utils.rank use_random_tiebreak :622-629:
+//         a random permutation inside each tie group), (k-1)/(N-1);
+//   values with  rnk in [P0_ref / P0_hist * P0_sim, P0_sim]  become  (pth - thresh) * U[0,1) + thresh  (in the data dtype);
+//   the time series keeps the window-centre element of each block (base.py:438-439), i.e. time step t is corrected by the
+//   block of ITS group.
+// Ties are broken by sorting (key, tag) pairs, tag = 16 random bits (stream 3, mixed with the group) | slot in the row.
+// dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: P * sizeof(U)][tags: P * 4]
+// sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
+                             const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
+                             double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
+                             double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
+                             R *__restrict__ sim_ad, int64_t osc, int P_max)
+{
+    using U = typename KeyOf<R>::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);
+    const int nw = (blockDim.x + 63) >> 6;
+    U *keys = reinterpret_cast<U *>(red + 2 * nw + 2);
+    uint32_t *tags = reinterpret_cast<uint32_t *>(keys + P_max);
+    const int64_t c = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    int P = 2;
+    while (P < L) P <<= 1;
+    const R *xs = sim + c * sc;
+    const size_t og = (size_t)c * G + g;
+
+    // ---- counts of the sim row
+    double cnt0 = 0;  // values <= thresh
+    int nval = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const R v = xs[row_idx[p0 + i]];
+        if (v == v) { nval++; if ((double)v <= thresh) cnt0 += 1.0; }
+    }
+    block_sum_count(cnt0, nval, red);
+    const int N = nval;
+    const double P0_sim = N ? cnt0 / (double)N : __builtin_nan("");
+    double p0r, p0h;
+    R pthv;
+    if (train) {
+        const R *xr = ref + c * rsc;
+        double c0r = 0;
+        int nr = 0;
+        for (int i = threadIdx.x; i < P; i += blockDim.x) {
+            U k = KeyOf<R>::MAXK;
+            if (i < L) {
+                const R v = xr[row_idx[p0 + i]];
+                k = to_key(v);
+                if (v == v) { nr++; if ((double)v <= thresh) c0r += 1.0; }
+            }
+            keys[i] = k;
+        }
+        block_sum_count(c0r, nr, red);
+        p0r = nr ? c0r / (double)nr : __builtin_nan("");
+        p0h = P0_sim;
+        const double d = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
+        pthv = nan_of<R>();
+        if (d > 0.0) {  // block-uniform
+            block_bitonic_sort<U>(keys, P);
+            auto load = [&](int i) { return (double)from_key(keys[i]); };
+            // np.nanquantile on the float64 copy of the row (the gufunc's float64 loop), rounded once
+            pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { P0_ref[og] = p0r; P0_hist[og] = p0h; pth[og] = pthv; if (dP0_out) dP0_out[og] = d; }
+    } else {
+        p0r = P0_ref[og]; p0h = P0_hist[og]; pthv = pth[og];
+        if (threadIdx.x == 0 && dP0_out) dP0_out[og] = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
+    }
+    const double dP0 = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
+    if (!(dP0 > 0.0)) return;  // no adaptation needed (or undefined): sim_ad keeps sim
+
+    // ---- ranks with random tie-break: sort (key, tag)
+    const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        U k = KeyOf<R>::MAXK;
+        uint32_t tg = 0xFFFF0000u | (uint32_t)(i & 0xFFFF);
+        if (i < L) {
+            const int tt = row_idx[p0 + i];
+            k = to_key(xs[tt] + (R)0);  // -0.0 ranks as +0.0 (a tie), like the float comparison of the reference
+            tg = ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)i;
+        }
+        keys[i] = k;
+        tags[i] = tg;
+    }
+    __syncthreads();
+    block_bitonic_sort_pairs<U>(keys, tags, P);
+    const double lowb = (p0r / p0h) * P0_sim;
+    const R th = (R)thresh;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {  // the N valid values come first
+        const int slot = (int)(tags[p] & 0xFFFFu);
+        const int tt = row_idx[p0 + slot];
+        if (gidx[tt] != g) continue;  // not this block's centre element
+        // xarray's pct rank k/N rescaled as utils.rank does: mx * (rnk - mn) / (mx - mn) with mx = N/N, mn = 1/N
+        const double rk = (double)(p + 1) / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
+        const double rnk = mx * (rk - mn) / (mx - mn);  // 0/0 = NaN for a single value: neither test holds -> replaced
+        const bool keep = (rnk < lowb) || (rnk > P0_sim);
+        if (!keep) {
+            const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
+            sim_ad[c * osc + tt] = (pthv - th) * u + th;
+        }
+    }
+}
+
+}  // namespace xs

@@ -225,6 +225,49 @@ def tail_mask(sim, scen, hist_q_raw, gidx, max_tail_factor, ctx=None):
     return scen
 
 
+def jitter(x, lower=None, minimum=None, upper=None, maximum=None, seed=0, first_cell=0, ctx=None):
+    """processing.jitter (processing.py:178-257) on a [cell, time] block; thresholds are plain numbers in the units of x"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    out = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    nan = float("nan")
+    f = lambda v: nan if v is None else float(v)  # noqa: E731
+    check(load().xsdba_hip_jitter(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                  C.c_double(f(lower)), C.c_double(f(minimum)), C.c_double(f(upper)), C.c_double(f(maximum)),
+                                  C.c_uint64(int(seed) & (2**64 - 1)), _i64(first_cell), _vp(out), _i64(1), _i64(s.T)), "jitter")
+    return out
+
+
+def adapt_freq(sim, ref, gidx, G, W, thresh, seed=0, first_cell=0, P0_ref=None, P0_hist=None, pth=None, ctx=None):
+    """_processing._adapt_freq (_processing.py:20-142) on every (cell, group) block.
+    Training (``ref`` given): returns (sim_ad, pth, dP0, P0_ref, P0_hist).  Adjusting (``ref=None``; P0_ref, P0_hist, pth
+    from the training, groups without window): returns the same tuple with the given tables passed through."""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    g = _gidx(gidx, s.T, G)
+    train = ref is not None
+    if train:
+        r = _Series(ref)
+        if (r.C, r.T, r.dtype, r.st, r.sc) != (s.C, s.T, s.dtype, s.st, s.sc):
+            raise ValueError("ref and sim must share shape, dtype and layout")
+        P0_ref, P0_hist = np.empty((s.C, G), np.float64), np.empty((s.C, G), np.float64)
+        pth = np.empty((s.C, G), s.dtype)
+    else:
+        if W != 1:
+            raise ValueError("adapt_freq on the adjust side works on the groups without window")
+        P0_ref, P0_hist = np.ascontiguousarray(P0_ref, np.float64), np.ascontiguousarray(P0_hist, np.float64)
+        pth = np.ascontiguousarray(pth, s.dtype)
+        if P0_ref.shape != (s.C, G) or P0_hist.shape != (s.C, G) or pth.shape != (s.C, G):
+            raise ValueError("P0_ref, P0_hist, pth must be [cell, group]")
+    dP0 = np.empty((s.C, G), np.float64)
+    sim_ad = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_adapt_freq(ctx.handle, s.ptr, r.ptr if train else None, dtype_code(s.dtype), _i64(s.T), _i64(s.C),
+                                      _i64(s.st), _i64(s.sc), _vp(g), C.c_int(G), C.c_int(W), C.c_double(float(thresh)),
+                                      C.c_uint64(int(seed) & (2**64 - 1)), _i64(first_cell), _vp(P0_ref), _vp(P0_hist), _vp(pth),
+                                      _vp(dP0), _vp(sim_ad), _i64(1), _i64(s.T)), "adapt_freq")
+    return sim_ad, pth, dP0, P0_ref, P0_hist
+
+
 def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
     """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
     ctx = ctx or default_context()
@@ -250,5 +293,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]
