@@ -13,7 +13,7 @@ calls raise.
 """
 __version__ = "0.1.0"
 
-from . import _adjustment, adjustment, base, calendar, detrending, nbutils, options, utils  # noqa: E402,F401
+from . import _adjustment, adjustment, base, calendar, detrending, nbutils, options, processing, utils  # noqa: E402,F401
 from .adjustment import (  # noqa: E402,F401
     BaseAdjustment,
     DetrendedQuantileMapping,

@@ -4,9 +4,10 @@ qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` 
 body is ONE call into the HIP library that covers every group of every cell of the block.
 
 Not yet on the device path (rows "next" of SURVEY §8f; they raise NotImplementedError instead of running
-anything on the CPU): ``adapt_freq_thresh``, ``jitter_*``, ``add_dims``,
-grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
-``max_tail_factor`` is on the device: ``hist_q_raw`` at training, ``hip.tail_mask`` after the adjustment.
+anything on the CPU): ``add_dims``, grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+On the device since round 1: ``max_tail_factor`` (``hist_q_raw`` at training, ``hip.tail_mask`` after the adjustment),
+``jitter_*`` and ``adapt_freq_thresh`` (``hip.jitter`` / ``hip.adapt_freq`` in front of the training kernels, the
+frequency adaptation of ``sim`` with the trained ``P0_ref, P0_hist, pth`` in front of the adjust kernels).
 """
 from __future__ import annotations
 
@@ -70,31 +71,57 @@ def _prep_train(ds, group):
     return ref, r2, h2, gidx, G, cell_dims, cell_shape, dt
 
 
+def _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value, jitter_over_thresh_value,
+                     jitter_over_thresh_upper_bnd):
+    """_adjustment._preprocess_dataset (:48-83) on the [cell, time] block of hist: jitter under / over, then the
+    frequency adaptation against ref over the windowed group blocks.  Returns (hist block, extra tables or None)."""
+    from .processing import _draw_seed, quantity_to_float
+
+    if (jitter_over_thresh_value is None) ^ (jitter_over_thresh_upper_bnd is None):
+        raise ValueError("`jitter_over_thresh_value` and `jitter_over_thresh_upper_bnd` must both be specified or both be `None` (default)")
+    if jitter_under_thresh_value:
+        h2 = hip.jitter(h2, lower=quantity_to_float(jitter_under_thresh_value, ref, "jitter_under_thresh_value"), seed=_draw_seed())
+    if jitter_over_thresh_value:
+        h2 = hip.jitter(h2, upper=quantity_to_float(jitter_over_thresh_value, ref, "jitter_over_thresh_value"),
+                        maximum=quantity_to_float(jitter_over_thresh_upper_bnd, ref, "jitter_over_thresh_upper_bnd"), seed=_draw_seed())
+    extra = None
+    if adapt_freq_thresh:
+        th = quantity_to_float(adapt_freq_thresh, ref, "adapt_freq_thresh")
+        h2, pth, _, P0_ref, P0_hist = hip.adapt_freq(h2, r2, gidx, G, group.window, th, seed=_draw_seed())
+        extra = {"P0_ref": P0_ref.astype(h2.dtype), "P0_hist": P0_hist.astype(h2.dtype), "pth": pth}
+    return h2, extra
+
+
 def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
+    h_raw = h2
+    h2, extra = _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value,
+                                 jitter_over_thresh_value, jitter_over_thresh_upper_bnd)
     af, hq = hip.eqm_train(r2, h2, gidx, G, group.window, q, kind)
-    # hist_q_raw = quantiles of hist BEFORE the pre-processing steps (:254-256); none of those runs here, so it equals
-    # hist_q; a NaN dummy unless max_tail_factor (:273-275)
-    hq_raw = hq.copy() if max_tail_factor is not None else np.full_like(hq, np.nan)
-    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw)
+    # hist_q_raw = quantiles of hist BEFORE the pre-processing steps (:254-256); a NaN dummy unless max_tail_factor (:273-275)
+    if max_tail_factor is None:
+        hq_raw = np.full_like(hq, np.nan)
+    else:
+        hq_raw = hq.copy() if h2 is h_raw else hip.quantile_groups(h_raw, gidx, G, group.window, q)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, **(extra or {}))
     out["af"].attrs["kind"] = kind
     return out
 
 
 def _fused_dqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh, jitter_under_thresh_value=jitter_under_thresh_value,
-                 jitter_over_thresh_value=jitter_over_thresh_value, jitter_over_thresh_upper_bnd=jitter_over_thresh_upper_bnd)
     ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
+    h_raw = h2
+    h2, extra = _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value,
+                                 jitter_over_thresh_value, jitter_over_thresh_upper_bnd)
     af, hq, sc = hip.dqm_train(r2, h2, gidx, G, group.window, q, kind)
-    # hist_q_raw: quantiles of the raw (not normalised) hist (:151-153)
-    hq_raw = hip.quantile_groups(h2, gidx, G, group.window, q) if max_tail_factor is not None else np.full_like(hq, np.nan)
-    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, scaling=sc)
+    # hist_q_raw: quantiles of the raw (not pre-processed, not normalised) hist (:151-153)
+    hq_raw = hip.quantile_groups(h_raw, gidx, G, group.window, q) if max_tail_factor is not None else np.full_like(hq, np.nan)
+    out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, scaling=sc,
+                         **(extra or {}))
     out["af"].attrs["kind"] = kind
     out["scaling"].attrs["kind"] = kind
     return out
@@ -162,6 +189,20 @@ def _prep_adjust(ds, group: Grouper, interp: str):
     return sim, s2, gidx, G, cell_dims, cell_shape, dt
 
 
+def _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh):
+    """_adapt_freq_preprocess on the adjust side (_adjustment.py:32-46, 639-645): the frequency adaptation of sim with the
+    trained P0_ref / P0_hist / pth, on the groups WITHOUT window (Grouper(group.name))."""
+    if not adapt_freq_thresh:
+        return s2
+    from .processing import _draw_seed, quantity_to_float
+
+    th = quantity_to_float(adapt_freq_thresh, sim, "adapt_freq_thresh")
+    tabs = [table_view(as_dataarray(ds[k]), cell_dims, group.prop, last=None) for k in ("P0_ref", "P0_hist", "pth")]
+    out = hip.adapt_freq(s2, None, gidx, G, 1, th, seed=_draw_seed(), P0_ref=tabs[0].astype(np.float64),
+                         P0_hist=tabs[1].astype(np.float64), pth=tabs[2].astype(dt, copy=False))
+    return out[0]
+
+
 def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor):
     """mask no bias adjustment where sim is larger than n times the largest raw hist quantile (_adjustment.py:648-658,
     672-673); the group broadcast of the reference is "nearest" for every grouping this path accepts"""
@@ -179,8 +220,8 @@ def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=No
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[])
 def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """QM (DQM and EQM): adjust step on one block (_adjustment.py:594-676)."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
     scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
@@ -192,7 +233,6 @@ def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None,
 def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
     means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     if isinstance(detrend, PolyDetrend):
         if detrend.group.name != group.name or detrend.group.window != group.window or detrend.kind != kind or detrend.preserve_mean or detrend.mult_skip_zeros:
             raise NotImplementedError("dqm_adjust on the HIP path takes detrend=<int> or a PolyDetrend on the same group/kind")
@@ -204,6 +244,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     if degree not in (0, 1):
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0 or 1)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
     sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
@@ -217,7 +258,6 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], sim_q=[])
 def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, rank_window=None, max_tail_factor=None) -> Dataset:
     """QDM adjustment on one block (_adjustment.py:783-886)."""
-    _unsupported(adapt_freq_thresh=adapt_freq_thresh)
     if rank_window is None:
         rank_window = False
         if group.window > 1:
@@ -233,6 +273,7 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
                 stacklevel=2,
             )
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
     quantiles = np.asarray(ds["quantiles"].values, dt)
     scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)

@@ -42,7 +42,7 @@ class XsdbaHipError(RuntimeError):
 
 def build(force: bool = False) -> Path:
     """Compile the library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / "api.hip", CSRC / "kernels.hpp", CSRC / "device_math.hpp", _PKG.parent / "include" / "xsdba_hip.h"]
+    srcs = [CSRC / "api.hip", *sorted(CSRC.glob("*.hpp")), _PKG.parent / "include" / "xsdba_hip.h"]
     if force or not LIB_PATH.exists() or any(s.stat().st_mtime > LIB_PATH.stat().st_mtime for s in srcs):
         env = dict(os.environ)
         proc = subprocess.run(["make", "-C", str(CSRC)], env=env, capture_output=True, text=True)

@@ -875,17 +875,28 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     int P = 2;
     while (P < pl->max_row) P <<= 1;
     const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
-    const size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * (sizeof(U) + sizeof(uint32_t));
+    const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2);
+    // the (key, tag) pairs of the sub-threshold values: as many as the LDS takes, at most the row
+    int Ps = P;
+    while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;
+    const size_t lds = red_b + std::max((size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t)));
     if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq row sort"))) return rc;
+    void *flag;
+    if ((rc = ensure(ctx, S_FLAGS, sizeof(int), &flag))) return rc;
+    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
     {
         LaunchScope ls(ctx, "k_adapt_freq");
         hipLaunchKernelGGL(xs::k_adapt_freq<R>, dim3((unsigned)ng), dim3(NT), lds, ctx->stream, (const R *)s.dev,
                            ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
                            pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
                            ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
-                           (double *)o3.dev, (R *)o.kernel_dst, T, P);
+                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, (int *)flag);
         if ((rc = check_launch("k_adapt_freq"))) return rc;
     }
+    int too_many = 0;
+    HIP_TRY(hipMemcpyAsync(&too_many, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (too_many) return fail(XSDBA_E_ROW_TOO_LONG, "adapt_freq: a group block holds %d values under the threshold, the LDS sort takes %d", too_many, Ps);
     if (ref && ((rc = finish_out(ctx, &o0)) || (rc = finish_out(ctx, &o1)) || (rc = finish_out(ctx, &o2)))) return rc;
     if ((rc = finish_out(ctx, &o3))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;

@@ -75,7 +75,8 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 //   the time series keeps the window-centre element of each block (base.py:438-439), i.e. time step t is corrected by the
 //   block of ITS group.
 // Ties are broken by sorting (key, tag) pairs, tag = 16 random bits (stream 3, mixed with the group) | slot in the row.
-// dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: P * sizeof(U)][tags: P * 4]
+// dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: max(P_max, Ps) * sizeof(U)] with [tags: Ps * 4] behind the first Ps keys,
+// Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values; a block with more of them raises *err_flag
 // sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
 // ---------------------------------------------------------------------------------------------
 template <typename R>
@@ -83,14 +84,14 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max)
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = reinterpret_cast<double *>(smem);
     const int nw = (blockDim.x + 63) >> 6;
     U *keys = reinterpret_cast<U *>(red + 2 * nw + 2);
-    uint32_t *tags = reinterpret_cast<uint32_t *>(keys + P_max);
+    uint32_t *tags = reinterpret_cast<uint32_t *>(keys + (P_max < P_sub_cap ? P_max : P_sub_cap));
     const int64_t c = blockIdx.x / G;
     const int g = blockIdx.x % G;
     const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
@@ -144,35 +145,78 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
     const double dP0 = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
     if (!(dP0 > 0.0)) return;  // no adaptation needed (or undefined): sim_ad keeps sim
 
-    // ---- ranks with random tie-break: sort (key, tag)
-    const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        U k = KeyOf<R>::MAXK;
-        uint32_t tg = 0xFFFF0000u | (uint32_t)(i & 0xFFFF);
-        if (i < L) {
-            const int tt = row_idx[p0 + i];
-            k = to_key(xs[tt] + (R)0);  // -0.0 ranks as +0.0 (a tie), like the float comparison of the reference
-            tg = ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)i;
-        }
-        keys[i] = k;
-        tags[i] = tg;
-    }
-    __syncthreads();
-    block_bitonic_sort_pairs<U>(keys, tags, P);
+    // ---- ranks with random tie-break.  With n0 > 0 values <= thresh only those can be replaced: a value above it has
+    // rnk >= n0 / (N - 1) > n0 / N = P0_sim ("too big").  So only the n0 sub-threshold values are sorted, as (key, tag)
+    // pairs; they come first in the full order, hence the same ranks k = 1 .. n0.
+    const int n0 = (int)cnt0;
     const double lowb = (p0r / p0h) * P0_sim;
     const R th = (R)thresh;
-    for (int p = threadIdx.x; p < N; p += blockDim.x) {  // the N valid values come first
-        const int slot = (int)(tags[p] & 0xFFFFu);
-        const int tt = row_idx[p0 + slot];
-        if (gidx[tt] != g) continue;  // not this block's centre element
-        // xarray's pct rank k/N rescaled as utils.rank does: mx * (rnk - mn) / (mx - mn) with mx = N/N, mn = 1/N
-        const double rk = (double)(p + 1) / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
-        const double rnk = mx * (rk - mn) / (mx - mn);  // 0/0 = NaN for a single value: neither test holds -> replaced
+    // percent rank of the k-th value (k = 1 .. N): xarray's k/N rescaled as utils.rank does, mx * (rnk - mn) / (mx - mn)
+    // with mx = N/N, mn = 1/N; 0/0 = NaN for a single value, for which neither test holds -> replaced
+    auto replace_if_in_band = [&](int k, int tt) {
+        const double rk = (double)k / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
+        const double rnk = mx * (rk - mn) / (mx - mn);
         const bool keep = (rnk < lowb) || (rnk > P0_sim);
         if (!keep) {
             const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
             sim_ad[c * osc + tt] = (pthv - th) * u + th;
         }
+    };
+    const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
+    auto tag_of = [&](int tt, int slot) { return ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)slot; };
+    if (n0 == 0) {
+        // nothing under the threshold although the training asks for adaptation: P0_sim = 0 and the smallest value has
+        // rnk = 0 = P0_sim, inside the band, so the reference replaces it.  Lexicographic (key, tag) minimum of the row.
+        U bk = KeyOf<R>::MAXK;
+        uint32_t bt = 0xFFFFFFFFu;
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            const int tt = row_idx[p0 + i];
+            const R v = xs[tt];
+            if (v == v) {
+                const U k = to_key(v + (R)0);
+                const uint32_t tg = tag_of(tt, i);
+                if (k < bk || (k == bk && tg < bt)) { bk = k; bt = tg; }
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const U ok = __shfl_down(bk, o, 64);
+            const uint32_t ot = __shfl_down(bt, o, 64);
+            if (ok < bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
+        }
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) { keys[threadIdx.x >> 6] = bk; tags[threadIdx.x >> 6] = bt; }
+        __syncthreads();
+        if (threadIdx.x == 0 && N > 0) {
+            for (int w = 1; w < nw; w++) if (keys[w] < bk || (keys[w] == bk && tags[w] < bt)) { bk = keys[w]; bt = tags[w]; }
+            const int tt = row_idx[p0 + (int)(bt & 0xFFFFu)];
+            if (gidx[tt] == g) replace_if_in_band(1, tt);
+        }
+        return;
+    }
+    int Ps = 2;
+    while (Ps < n0) Ps <<= 1;
+    if (Ps > P_sub_cap) {  // block-uniform: does not fit the LDS, reported through the error flag
+        if (threadIdx.x == 0) atomicMax(err_flag, n0);
+        return;
+    }
+    int *fill = reinterpret_cast<int *>(red);
+    if (threadIdx.x == 0) *fill = 0;
+    for (int i = threadIdx.x; i < Ps; i += blockDim.x) { keys[i] = KeyOf<R>::MAXK; tags[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int tt = row_idx[p0 + i];
+        const R v = xs[tt];
+        if (v == v && (double)v <= thresh) {
+            const int pos = atomicAdd(fill, 1);
+            keys[pos] = to_key(v + (R)0);  // -0.0 ranks as +0.0 (a tie), like the float comparison of the reference
+            tags[pos] = tag_of(tt, i);
+        }
+    }
+    __syncthreads();
+    block_bitonic_sort_pairs<U>(keys, tags, Ps);
+    for (int p = threadIdx.x; p < n0; p += blockDim.x) {
+        const int tt = row_idx[p0 + (int)(tags[p] & 0xFFFFu)];
+        if (gidx[tt] == g) replace_if_in_band(p + 1, tt);  // only the block's centre elements reach the time series
     }
 }
 

@@ -248,6 +248,10 @@ def adapt_freq(sim, ref, gidx, G, W, thresh, seed=0, first_cell=0, P0_ref=None, 
     train = ref is not None
     if train:
         r = _Series(ref)
+        if (r.st, r.sc) != (s.st, s.sc) and isinstance(sim, np.ndarray) and isinstance(ref, np.ndarray):
+            # one pair of strides serves both series: bring host arrays to the same dense [cell, time] layout
+            sim, ref = np.ascontiguousarray(sim), np.ascontiguousarray(ref)
+            s, r = _Series(sim), _Series(ref)
         if (r.C, r.T, r.dtype, r.st, r.sc) != (s.C, s.T, s.dtype, s.st, s.sc):
             raise ValueError("ref and sim must share shape, dtype and layout")
         P0_ref, P0_hist = np.empty((s.C, G), np.float64), np.empty((s.C, G), np.float64)

@@ -1,0 +1,101 @@
+"""Pre-processing functions of the quantile-mapping path (xsdba.processing): ``adapt_freq`` (:46-122),
+``jitter`` / ``jitter_under_thresh`` / ``jitter_over_thresh`` (:124-257), each one call into the HIP library.
+
+Random numbers: the reference draws from numpy's global generator.  Here every call takes ONE integer from that same
+global generator (so ``np.random.seed(...)`` makes a script reproducible, as with the reference) and uses it as the
+seed of the device's counter-based generator (include/xsdba_hip.h, f1)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hip
+from .base import Grouper, parse_group
+from .labeled import Coordinate, DataArray, as_dataarray
+from .utils import cell_time_view
+
+__all__ = ["adapt_freq", "jitter", "jitter_over_thresh", "jitter_under_thresh"]
+
+
+def _draw_seed() -> int:
+    return int(np.random.randint(0, 2**31 - 1)) * 2654435761 + int(np.random.randint(0, 2**31 - 1))
+
+
+def quantity_to_float(q, like: DataArray | None = None, name: str = "threshold") -> float | None:
+    """'1 mm d-1' -> 1.0 when the units are those of ``like`` (units.convert_units_to :226-266 without pint: a quantity in
+    other units raises); plain numbers pass through."""
+    if q is None:
+        return None
+    if isinstance(q, (int, float, np.integer, np.floating)):
+        return float(q)
+    parts = str(q).strip().split(None, 1)
+    try:
+        val = float(parts[0])
+    except ValueError as err:
+        raise ValueError(f"cannot parse the {name} {q!r} (expected '<number> <units>')") from err
+    units = parts[1].strip() if len(parts) > 1 else ""
+    have = str(like.attrs.get("units", "")).strip() if like is not None else ""
+    if units and have and " ".join(units.split()) != " ".join(have.split()):
+        raise NotImplementedError(
+            f"{name} {q!r} is not in the units of the data ({have!r}); unit conversion (pint) is outside this path")
+    return val
+
+
+def _series(da: DataArray, vals, cell_dims, cell_shape, dim, attrs=None):
+    coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == dim}
+    out = DataArray(np.asarray(vals).reshape(cell_shape + (vals.shape[-1],)), cell_dims + (dim,), coords, dict(attrs or da.attrs), da.name)
+    return out.transpose(*da.dims)
+
+
+def jitter(x, lower=None, upper=None, minimum=None, maximum=None) -> DataArray:
+    """Replace values under a threshold and values above another by a uniform random noise (processing.py:178-257):
+    values < lower -> U(minimum, lower) (minimum excluded, default 0); values >= upper -> U(upper, maximum)."""
+    x = as_dataarray(x)
+    lo, up = quantity_to_float(lower, x, "lower"), quantity_to_float(upper, x, "upper")
+    mn, mx = quantity_to_float(minimum, x, "minimum"), quantity_to_float(maximum, x, "maximum")
+    if up is not None and mx is None:
+        raise ValueError("If 'upper' is given, so must 'maximum'.")
+    dim = "time" if "time" in x.dims else x.dims[-1]
+    x2, cell_dims, cell_shape = cell_time_view(x, dim)
+    dt = np.result_type(x2.dtype, np.float32)
+    out = hip.jitter(np.ascontiguousarray(x2, dt), lower=lo, minimum=mn, upper=up, maximum=mx, seed=_draw_seed())
+    res = _series(x, out, cell_dims, cell_shape, dim)
+    return res.astype(x.dtype) if res.dtype != x.dtype and np.issubdtype(x.dtype, np.floating) else res
+
+
+def jitter_under_thresh(x, thresh) -> DataArray:
+    """Replace values smaller than threshold by a uniform random noise (processing.py:124-149)."""
+    return jitter(x, lower=thresh, upper=None, minimum=None, maximum=None)
+
+
+def jitter_over_thresh(x, thresh, upper_bnd) -> DataArray:
+    """Replace values greater than threshold by a uniform random noise (processing.py:152-175)."""
+    return jitter(x, lower=None, upper=thresh, minimum=None, maximum=upper_bnd)
+
+
+@parse_group
+def adapt_freq(ref, sim, *, group: Grouper | str, thresh="0 mm d-1"):
+    """Adapt frequency of values under thresh of `sim`, in order to match ref (processing.py:46-122, Themeßl et al. 2012).
+    Returns (sim_ad, pth, dP0)."""
+    ref, sim = as_dataarray(ref), as_dataarray(sim)
+    if group.add_dims:
+        raise NotImplementedError("Grouper(add_dims=...) is not implemented on the HIP path yet")
+    th = quantity_to_float(thresh, ref, "thresh")
+    dt = np.result_type(ref.dtype, sim.dtype, np.float32)
+    s2, cell_dims, cell_shape = cell_time_view(sim.astype(dt) if sim.dtype != dt else sim, group.dim)
+    r2, _, _ = cell_time_view((ref.astype(dt) if ref.dtype != dt else ref).transpose(*sim.dims), group.dim)
+    gidx, G = group.group_index(sim)
+    sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
+    attrs = dict(sim.attrs)
+    attrs["references"] = ("Themeßl et al. (2012), Empirical-statistical downscaling and error correction of regional climate "
+                           "models and its impact on the climate change signal, Climatic Change, DOI 10.1007/s10584-011-0224-4.")
+    out = _series(sim, sim_ad, cell_dims, cell_shape, group.dim, attrs)
+    prop = group.prop
+    crd = group.get_coordinate(sim)
+    coords = {k: c for k, c in sim.coords.items() if k in cell_dims}
+    coords[prop] = Coordinate(prop, crd.values)
+    units = sim.attrs.get("units", "")
+    pth_da = DataArray(pth.reshape(cell_shape + (G,)), cell_dims + (prop,), coords,
+                       {"long_name": "Smallest value of the timeseries not corrected by frequency adaptation.", "units": units}, "pth")
+    dP0_da = DataArray(dP0.reshape(cell_shape + (G,)), cell_dims + (prop,), coords,
+                       {"long_name": f"Proportion of values smaller than {th} in the timeseries corrected by frequency adaptation"}, "dP0")
+    return out, pth_da, dP0_da
