@@ -218,3 +218,41 @@ def test_vecquantiles_matches_numpy():
         warnings.simplefilter("ignore")
         exp = np.array([np.nanquantile(x[i], q[i]) if not np.isnan(q[i]) else np.nan for i in range(60)])
     assert_close(got, exp, rtol=1e-13, what="vecquantiles vs numpy")
+
+
+# ------------------------------------------------------------------------------------------------
+# f1 pre-processing rows: the reference draws from an unseeded generator, so there are no golden vectors to pin; the
+# oracle is held to the assertions of the reference's own tests instead (tests/test_processing.py:31-64, 91-132)
+# ------------------------------------------------------------------------------------------------
+def test_oracle_jitter_reference_assertions():
+    da = np.array([[0.5, 2.1, np.nan]])
+    out = oracle.jitter(da, lower=1.0, upper=2.0, maximum=3.0, seed=1)
+    assert da[0, 0] != out[0, 0] and 0 < out[0, 0] < 1
+    assert da[0, 1] != out[0, 1] and 2 <= out[0, 1] < 3 and np.isnan(out[0, 2])
+    for dtype, delta in ((np.float64, 1e-8), (np.float32, 1e-6)):  # narrow intervals, :66-75
+        for test_val in (1e-6, 1, 100, 1e6):
+            x = (test_val + np.zeros((1, 1000))).astype(dtype)
+            hi = oracle.jitter(x, upper=test_val * (1 - delta), maximum=test_val, seed=2)
+            lo = oracle.jitter(x, lower=test_val * (1 + delta), minimum=test_val, seed=3)
+            assert (hi < test_val).all() and (lo > test_val).all()
+
+
+def test_oracle_adapt_freq_reference_assertions():
+    rng = np.random.default_rng(0)
+    n = 31 * 365 + 8
+    pr = rng.integers(0, 100, size=(3, n)).astype(np.float64)
+    prsim, prref = np.where(pr < 20, pr / 20, pr), np.where(pr < 10, pr / 20, pr)
+    doy = np.arange(n) % 365
+    cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
+    month = (np.searchsorted(cum, doy, side="right") - 1).astype(np.int32)
+    sim_ad, pth, dP0, P0_ref, P0_hist = oracle.adapt_freq(prsim, prref, month, 12, 1, 1.0, seed=7)
+    zeros = prsim <= 1
+    np.testing.assert_allclose((sim_ad[zeros] > 1).sum() / (n * 3 * 0.2), 0.5, atol=0.1)
+    corrected = sim_ad[zeros & (sim_ad > 1)]
+    assert ((corrected < 20.1) & (corrected > 1)).all()
+    np.testing.assert_array_equal(sim_ad[prsim > 20.5], prsim[prsim > 20.5])
+    np.testing.assert_allclose(pth, 20, rtol=0.05)
+    np.testing.assert_allclose(dP0, 0.5, atol=0.25)
+    # adjust branch with the trained tables: same decisions on the same data and seed
+    again = oracle.adapt_freq(prsim, None, month, 12, 1, 1.0, seed=7, P0_ref=P0_ref, P0_hist=P0_hist, pth=pth)
+    np.testing.assert_array_equal(again[0], sim_ad)

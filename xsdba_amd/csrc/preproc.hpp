@@ -3,7 +3,7 @@
 //
 // Both draw random numbers.  The reference uses numpy's unseeded global generator (processing.py:234,
 // _processing.py:122), so its output is not reproducible; here every draw is a pure function of
-// (seed, cell, time step, stream) — the same function in oracle/xsdba_oracle.c — so device results are reproducible,
+// (seed, cell, time step, stream) — the same function in the CPU checker under oracle/ — so device results are reproducible,
 // independent of the launch geometry and bit-identical to the oracle:
 //     h(cell, t, stream) = mix64( mix64(seed ^ (cell + 1) * 0x9E3779B97F4A7C15) ^ (stream << 40) ^ t )
 //     u53(h) = (h >> 11) * 2^-53  in [0, 1)
