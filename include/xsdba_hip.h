@@ -73,6 +73,21 @@ int xsdba_hip_memcpy_h2d(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t 
 int xsdba_hip_memcpy_d2h(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int xsdba_hip_memset(xsdba_hip_ctx *ctx, void *dst, int value, size_t bytes);
 
+/* ---- f4: streaming blocks of cells through the GPU (the role dask chunks play for the reference,
+ * base.py:640-702).  A context is one HIP stream; copies, kernels and read-backs of different blocks overlap when they
+ * are queued on different contexts of the same device and ordered by events:
+ *   host_register / host_unregister  pin a caller-owned host buffer in place, so that memcpy_async from / to it is a
+ *                                    true asynchronous DMA at PCIe rate (hipHostRegister);
+ *   memcpy_async                     hipMemcpyAsync(hipMemcpyDefault) on the context's stream, returns immediately;
+ *   event_record(ctx, slot)          records event `slot` (0..15) of `ctx` on its stream;
+ *   stream_wait_event(w, src, slot)  work queued on w's stream after this call starts only when event `slot` of `src`
+ *                                    (as last recorded) has completed; a never-recorded event does not block. */
+int xsdba_hip_host_register(xsdba_hip_ctx *ctx, void *host_ptr, size_t bytes);
+int xsdba_hip_host_unregister(xsdba_hip_ctx *ctx, void *host_ptr);
+int xsdba_hip_memcpy_async(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
+int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot);
+int xsdba_hip_stream_wait_event(xsdba_hip_ctx *waiter, xsdba_hip_ctx *src, int slot);
+
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * enable != 0 brackets every kernel launch with an event pair; xsdba_hip_profile_read synchronises the
  * stream and returns, for up to `cap` distinct kernels, name / launch count / total milliseconds

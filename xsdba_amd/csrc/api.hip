@@ -82,6 +82,7 @@ struct xsdba_hip_ctx {
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    hipEvent_t user_ev[16] = {};  // event_record / stream_wait_event slots, created on first use
     int lds_limit = 160 * 1024;
     int n_cu = 256;
 };
@@ -971,6 +972,7 @@ API int xsdba_hip_destroy(xsdba_hip_ctx *ctx)
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    for (auto e : ctx->user_ev) if (e) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return 0;
@@ -1029,6 +1031,53 @@ API int xsdba_hip_memcpy_d2h(xsdba_hip_ctx *ctx, void *dst, const void *src, siz
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));  // also device -> device
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_host_register(xsdba_hip_ctx *ctx, void *host_ptr, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!host_ptr || !bytes) return fail(XSDBA_E_ARG, "null/empty host buffer");
+    HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return 0;
+}
+
+API int xsdba_hip_host_unregister(xsdba_hip_ctx *ctx, void *host_ptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!host_ptr) return 0;
+    HIP_TRY(hipHostUnregister(host_ptr));
+    return 0;
+}
+
+API int xsdba_hip_memcpy_async(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (slot < 0 || slot >= 16) return fail(XSDBA_E_ARG, "event slot %d out of range [0,16)", slot);
+    if (!ctx->user_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->user_ev[slot], hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ctx->user_ev[slot], ctx->stream));
+    return 0;
+}
+
+API int xsdba_hip_stream_wait_event(xsdba_hip_ctx *waiter, xsdba_hip_ctx *src, int slot)
+{
+    int rc = check_ctx(waiter);
+    if (rc) return rc;
+    if (!src || slot < 0 || slot >= 16) return fail(XSDBA_E_ARG, "bad source context / event slot");
+    if (src->device != waiter->device) return fail(XSDBA_E_ARG, "both contexts must live on the same device");
+    if (!src->user_ev[slot]) return 0;  // never recorded: nothing to wait for
+    HIP_TRY(hipStreamWaitEvent(waiter->stream, src->user_ev[slot], 0));
     return 0;
 }
 
