@@ -194,6 +194,18 @@ int xsdba_hip_adapt_freq(xsdba_hip_ctx *ctx, const void *sim, const void *ref, i
                          double *P0_ref, double *P0_hist, void *pth, double *dP0, void *sim_ad,
                          int64_t out_stride_t, int64_t out_stride_c);
 
+/* ---- f3: Scaling (adjustment.py:985-1050, _adjustment.py:941-974).  group_means: the NaN-skipping mean of every
+ * (cell, group) block, dims [time, window] pooled (scaling_train :953-958 takes two of them and their correction);
+ * scaling_adjust: scen = sim (+|*) af[cell][group_of_time[t]]  (utils.broadcast with interp="nearest" :180-248, then
+ * apply_correction); time steps in no group give NaN. */
+int xsdba_hip_group_means(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                          int64_t stride_c, const int32_t *group_of_time, int32_t n_groups, int32_t window,
+                          void *out /* [cell][group] */);
+int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                             int64_t stride_t, int64_t stride_c, const void *af /* [cell][group] */,
+                             const int32_t *group_of_time, int32_t n_groups, char kind, void *scen,
+                             int64_t out_stride_t, int64_t out_stride_c);
+
 /* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
 int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
                                 int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,

@@ -218,6 +218,28 @@ def adapt_freq(sim, ref, gidx, G, W, thresh, seed=0, first_cell=0, P0_ref=None, 
     return out, pth, dP0, P0_ref, P0_hist
 
 
+def group_means(x, gidx, G, W):
+    x = np.ascontiguousarray(x)
+    Cn, T = x.shape
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    out = np.empty((Cn, G), x.dtype)
+    _check(lib().xsdba_oracle_group_means(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(gidx), C.c_int(G), C.c_int(W), _p(out)),
+           "group_means")
+    return out
+
+
+def scaling_adjust(sim, af, gidx, kind="+"):
+    sim = np.ascontiguousarray(sim)
+    Cn, T = sim.shape
+    af = np.ascontiguousarray(af, sim.dtype)
+    G = af.shape[1]
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    out = np.empty_like(sim)
+    _check(lib().xsdba_oracle_scaling_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(af), _p(gidx), C.c_int(G),
+                                             C.c_char(kind.encode()), _p(out), _i64(1), _i64(T)), "scaling_adjust")
+    return out
+
+
 def rank_groups(x, gidx, G, W, rank_window=False):
     x = np.asarray(x)
     Cn, T = x.shape

@@ -484,3 +484,45 @@ API int xsdba_oracle_adapt_freq(const void *sim, const void *ref, int dtype, int
     plan_free(&pl);
     return 0;
 }
+
+/* Scaling: scaling_train (_adjustment.py:941-958) needs the mean of every (cell, group) block with the
+ * dims [time, window] pooled (xarray .mean(), skipna); scaling_adjust (:961-974) applies af[group of t] (utils.broadcast
+ * "nearest" :180-248, apply_correction :149-165). */
+API int xsdba_oracle_group_means(const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t *gidx,
+                                 int G, int W, void *out)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (rc) { plan_free(&pl); return rc; }
+    for (int64_t c = 0; c < C; c++)
+        for (int g = 0; g < G; g++) {
+            double s = 0;
+            int64_t n = 0;
+            for (int64_t i = pl.row_ptr[g]; i < pl.row_ptr[g + 1]; i++) {
+                int64_t t = pl.row_idx[i];
+                double v = dtype == 0 ? (double)((const float *)x)[c * sc + t * st] : ((const double *)x)[c * sc + t * st];
+                if (!isnan(v)) { s += v; n++; }
+            }
+            double m = n ? s / (double)n : NAN;
+            if (dtype == 0) ((float *)out)[(size_t)c * G + g] = (float)m; else ((double *)out)[(size_t)c * G + g] = m;
+        }
+    plan_free(&pl);
+    return 0;
+}
+
+API int xsdba_oracle_scaling_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                                    const int32_t *gidx, int G, char kind, void *scen, int64_t ost, int64_t osc)
+{
+    for (int64_t c = 0; c < C; c++)
+        for (int64_t t = 0; t < T; t++) {
+            int g = G > 1 ? gidx[t] : 0;
+            if (dtype == 0) {
+                float v = ((const float *)sim)[c * sc + t * st], f = g >= 0 ? ((const float *)af)[(size_t)c * G + g] : NAN;
+                ((float *)scen)[c * osc + t * ost] = g < 0 ? NAN : (kind == '+' ? v + f : v * f);
+            } else {
+                double v = ((const double *)sim)[c * sc + t * st], f = g >= 0 ? ((const double *)af)[(size_t)c * G + g] : NAN;
+                ((double *)scen)[c * osc + t * ost] = g < 0 ? NAN : (kind == '+' ? v + f : v * f);
+            }
+        }
+    return 0;
+}

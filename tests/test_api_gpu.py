@@ -56,6 +56,39 @@ def mon_timelonlatseries(values, attrs):
     return DataArray(apply_correction(x, factor, attrs["kind"]).values, x.dims, x.coords, attrs)
 
 
+class TestScaling:
+    """reference tests/test_adjustment.py:206-258"""
+
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_time(self, kind, units, random):
+        n = 10000
+        x = uniform(loc=2, scale=1).ppf(random.random(n))
+        attrs = {"units": units, "kind": kind}
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        ref = timelonlatseries(apply_correction(x, 2, kind), attrs=attrs)
+        scaling = xs.Scaling.train(ref, hist, group="time", kind=kind)
+        np.testing.assert_array_almost_equal(scaling.ds.af.values, 2)
+        p = scaling.adjust(sim)
+        np.testing.assert_array_almost_equal(p.values, ref.values)
+        with pytest.raises(ValueError) as err:
+            scaling.adjust(sim, interp="linear")
+        assert isinstance(err.value.__cause__, NotImplementedError)
+
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_mon_u(self, kind, units, random):
+        n = 10000
+        x = uniform(loc=2, scale=1).ppf(random.random(n))
+        attrs = {"units": units, "kind": kind}
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        ref = mon_timelonlatseries(apply_correction(x, 2, kind), attrs=attrs)
+        scaling = xs.Scaling.train(ref, hist, group="time.month", kind=kind)
+        expected = apply_correction(MON_TRI, 2, kind)
+        np.testing.assert_array_almost_equal(scaling.ds.af.values, expected, 2 if kind == ADDITIVE else 1)
+        p = scaling.adjust(sim)
+        np.testing.assert_array_almost_equal(p.values, ref.values, 1)
+        assert "Scaling(group=Grouper(name='time.month'), kind=" in scaling.ds.attrs["adj_params"]
+
+
 class TestQM:
     @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
     def test_quantiles(self, kind, units, random):

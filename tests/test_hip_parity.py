@@ -358,6 +358,28 @@ def test_adapt_freq_bit_exact_vs_oracle(hip, gname, dtype):
     assert_close(h2[2], e2[2], rtol=0.0, what="adapt_freq adjust dP0")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["time", "month", "doy31", "month5"])
+def test_scaling_vs_oracle(hip, gname, dtype):
+    """Scaling: group means (float64 accumulation: <= 1 ulp of the oracle's sequential sum) and the
+    nearest-group application of the factors (bit-exact)"""
+    rng = np.random.default_rng(21)
+    T, C = 2555, 5
+    gidx, G, W = GROUPINGS[gname](T)
+    gidx = gidx.copy()
+    if G > 1:
+        gidx[7::90] = -1
+    x = (280 + 10 * rng.standard_normal((C, T))).astype(dtype)
+    x[rng.random((C, T)) < 0.03] = np.nan
+    x[2] = np.nan
+    m, em = hip.group_means(x, gidx, G, W), oracle.group_means(x, gidx, G, W)
+    assert_close(m, em, rtol=2.4e-7 if dtype == np.float32 else 1e-11, what="group means")  # summation order
+    af = rng.standard_normal((C, G)).astype(dtype)
+    for kind in "+*":
+        got = hip.scaling_adjust(x, af, gidx if G > 1 else None, kind)
+        assert_close(got, oracle.scaling_adjust(x, af, gidx if G > 1 else None, kind), rtol=0.0, what=f"scaling_adjust {kind}")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

@@ -19,6 +19,7 @@ from .adjustment import (  # noqa: E402,F401
     DetrendedQuantileMapping,
     EmpiricalQuantileMapping,
     QuantileDeltaMapping,
+    Scaling,
     TrainAdjust,
 )
 from .base import Grouper, map_blocks, map_groups, parse_group  # noqa: E402,F401

@@ -280,3 +280,34 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})
+
+
+def _fused_scaling_train(ds, *, group, kind):
+    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    mhist = hip.group_means(h2, gidx, G, group.window)
+    mref = hip.group_means(r2, gidx, G, group.window)
+    af = mref - mhist if kind == u.ADDITIVE else mref / mhist  # utils.get_correction(mhist, mref, kind) :130-146
+    out = _train_dataset(ref, group, [], cell_dims, cell_shape, af=af.astype(dt, copy=False))
+    out = Dataset({"af": out["af"]})
+    out["af"].attrs["kind"] = kind
+    return out
+
+
+@map_groups(fused=_fused_scaling_train, af=[Grouper.PROP])
+def scaling_train(ds, *, dim, kind) -> Dataset:
+    """Scaling: train on one group (_adjustment.py:941-958): the correction between the group means of hist and ref."""
+    mhist = ds.hist.mean(Grouper.filter_dim(ds.hist, dim))
+    mref = ds.ref.mean(Grouper.filter_dim(ds.ref, dim))
+    return Dataset({"af": u.get_correction(mhist, mref, kind)})
+
+
+@map_blocks(reduces=[Grouper.PROP], scen=[])
+def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
+    """Scaling: adjust on one block (_adjustment.py:961-974); the factors are broadcast on the group of each time step
+    (utils.broadcast :180-248 with interp="nearest"; interpolation between group centres is not on the device)."""
+    if interp != "nearest":
+        raise NotImplementedError("scaling_adjust on the HIP path broadcasts the factors with interp='nearest' only")
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    scen = hip.scaling_adjust(s2, af, gidx if G > 1 else None, kind)
+    return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()

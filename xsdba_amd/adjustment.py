@@ -23,7 +23,7 @@ from .labeled import DataArray, Dataset, as_dataarray, as_dataset, is_xarray
 from .options import EXTRA_OUTPUT, OPTIONS
 from .utils import ADDITIVE, equally_spaced_nodes
 
-__all__ = ["BaseAdjustment", "DetrendedQuantileMapping", "EmpiricalQuantileMapping", "QuantileDeltaMapping", "TrainAdjust"]
+__all__ = ["BaseAdjustment", "DetrendedQuantileMapping", "EmpiricalQuantileMapping", "QuantileDeltaMapping", "Scaling", "TrainAdjust"]
 
 
 def gen_call_string(funcname: str, *args, **kwargs) -> str:
@@ -273,3 +273,24 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
 
 for _cls in (EmpiricalQuantileMapping, DetrendedQuantileMapping, QuantileDeltaMapping):
     _register(_cls, "xsdba.adjustment")
+
+
+class Scaling(TrainAdjust):
+    """Scaling bias-adjustment (adjustment.py:985-1050): an additive or multiplicative factor per group so that the mean
+    of `hist` matches the mean of `ref`."""
+
+    _allow_diff_calendars = False
+    _allow_diff_training_times = False
+
+    @classmethod
+    def _train(cls, ref, hist, *, group="time", kind: str = ADDITIVE):
+        from ._adjustment import scaling_train
+
+        ds = scaling_train(Dataset({"ref": ref, "hist": hist}), group=group, kind=kind)
+        ds["af"].attrs.update(long_name="Scaling adjustment factors")
+        return ds, {"group": group, "kind": kind}
+
+    def _adjust(self, sim, interp="nearest"):
+        from ._adjustment import scaling_adjust
+
+        return scaling_adjust(Dataset({"sim": sim, "af": self.ds["af"]}), group=self.group, interp=interp, kind=self.kind)["scen"]

@@ -904,6 +904,59 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     return sync_if(ctx, true);
 }
 
+template <typename R>
+int group_means_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t *gidx, int G,
+                     int W, void *out)
+{
+    if (C <= 0 || !out) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((int64_t)C * G > (1ll << 31) - 1) return fail(XSDBA_E_ARG, "n_cell * n_groups exceeds 2^31");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x, T, C, st, sc, &s))) return rc;
+    OutStage o;
+    if ((rc = stage_out(ctx, S_TAB0, out, (size_t)C * G * sizeof(R), &o))) return rc;
+    const int NT = pl->max_row >= 2048 ? 512 : (pl->max_row >= 256 ? 256 : 64);
+    {
+        LaunchScope ls(ctx, "k_group_mean");
+        hipLaunchKernelGGL(xs::k_group_mean<R>, dim3((unsigned)((size_t)C * G)), dim3(NT), sizeof(double) * (2 * (NT / 64) + 2),
+                           ctx->stream, (const R *)s.dev, s.sc, pl->d_row_ptr, pl->d_row_idx, G, (R *)o.dev);
+        if ((rc = check_launch("k_group_mean"))) return rc;
+    }
+    if ((rc = finish_out(ctx, &o))) return rc;
+    return sync_if(ctx, o.copy_back || !is_device_ptr(x));
+}
+
+template <typename R>
+int scaling_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                        const int32_t *gidx, int G, char kind, void *scen, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || !af || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (T > (1ll << 30)) return fail(XSDBA_E_ARG, "series too long");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    const void *daf;
+    if ((rc = stage_in(ctx, S_TAB0, af, (size_t)C * G * sizeof(R), &daf))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    {
+        LaunchScope ls(ctx, "k_scale_groups");
+        const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 64);
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t nc = std::min<int64_t>(65535, C - c0);
+            hipLaunchKernelGGL(xs::k_scale_groups<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream, (const R *)s.dev + c0 * s.sc,
+                               T, s.sc, (const R *)daf + (size_t)c0 * G, G, pl->d_gidx, (int)kind, (R *)o.kernel_dst + c0 * T, T);
+        }
+        if ((rc = check_launch("k_scale_groups"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || !is_device_ptr(sim));
+}
+
 int check_ctx(xsdba_hip_ctx *ctx)
 {
     if (!ctx) return fail(XSDBA_E_ARG, "null context");
@@ -1241,6 +1294,24 @@ API int xsdba_hip_adapt_freq(xsdba_hip_ctx *ctx, const void *sim, const void *re
     if (rc) return rc;
     return DISPATCH(dtype, (adapt_freq_impl<float>(ctx, sim, ref, T, C, st, sc, gidx, G, W, thresh, seed, first_cell, P0_ref, P0_hist, pth, dP0, sim_ad, ost, osc)),
                     (adapt_freq_impl<double>(ctx, sim, ref, T, C, st, sc, gidx, G, W, thresh, seed, first_cell, P0_ref, P0_hist, pth, dP0, sim_ad, ost, osc)));
+}
+
+API int xsdba_hip_group_means(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                              const int32_t *gidx, int32_t G, int32_t W, void *out)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (group_means_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, out)),
+                    (group_means_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, out)));
+}
+
+API int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                 const void *af, const int32_t *gidx, int32_t G, char kind, void *scen, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (scaling_adjust_impl<float>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)),
+                    (scaling_adjust_impl<double>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

@@ -220,4 +220,41 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Scaling.  k_group_mean: NaN-skipping mean of one (cell, group) block (dims [time, window] pooled,
+// _adjustment.py:953-956), float64 accumulation, one workgroup per block.  k_scale_groups: scen = sim (+|*) af[group of t].
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_group_mean(const R *__restrict__ x, int64_t sc, const int *__restrict__ row_ptr, const int *__restrict__ row_idx,
+                             int G, R *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);
+    const int64_t c = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    const R *xs = x + c * sc;
+    double s = 0;
+    int n = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const R v = xs[row_idx[p0 + i]];
+        if (v == v) { s += (double)v; n++; }
+    }
+    block_sum_count(s, n, red);
+    if (threadIdx.x == 0) out[(size_t)c * G + g] = n ? (R)(s / (double)n) : nan_of<R>();
+}
+
+template <typename R>
+__global__ void k_scale_groups(const R *__restrict__ sim, int64_t T, int64_t sc, const R *__restrict__ af, int G,
+                               const int *__restrict__ gidx, int kind, R *__restrict__ scen, int64_t osc)
+{
+    const int64_t c = blockIdx.y;
+    const R *x = sim + c * sc, *f = af + (size_t)c * G;
+    R *o = scen + c * osc;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
+        const int g = G > 1 ? gidx[t] : 0;
+        o[t] = g >= 0 ? apply_corr<R>(x[t], f[g], kind) : nan_of<R>();
+    }
+}
+
 }  // namespace xs

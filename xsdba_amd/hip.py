@@ -272,6 +272,32 @@ def adapt_freq(sim, ref, gidx, G, W, thresh, seed=0, first_cell=0, P0_ref=None, 
     return sim_ad, pth, dP0, P0_ref, P0_hist
 
 
+def group_means(x, gidx, G, W, ctx=None):
+    """NaN-skipping mean of every (cell, group) block, dims [time, window] pooled -> [C, G] (scaling_train,
+    _adjustment.py:953-956)"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    g = _gidx(gidx, s.T, G)
+    out = np.empty((s.C, G), s.dtype)
+    check(load().xsdba_hip_group_means(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                       _vp(g), C.c_int(G), C.c_int(W), _vp(out)), "group_means")
+    return out
+
+
+def scaling_adjust(sim, af, gidx, kind="+", ctx=None):
+    """scaling_adjust (_adjustment.py:961-974) with the nearest-group broadcast -> scen [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G = af.shape[1]
+    af = _table(af, s.dtype, (s.C, G))
+    g = _gidx(gidx, s.T, G)
+    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_scaling_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                          _vp(af), _vp(g), C.c_int(G), C.c_char(kind.encode()), _vp(scen), _i64(1), _i64(s.T)),
+          "scaling_adjust")
+    return scen
+
+
 def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
     """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
     ctx = ctx or default_context()
@@ -297,5 +323,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]
