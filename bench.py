@@ -6,7 +6,8 @@ synthetic (cell, time) cubes already resident in HBM (generated on the device, S
 workload = the one BASELINE.json's metric names: EmpiricalQuantileMapping, Grouper("time.dayofyear",
 window=31), kind "+", 30 years of daily data (10950 noleap days), nquantiles 20, interp "nearest", on the
 360x180 grid of configs[1] (64800 cells per GPU; weak scaling: every rank owns its own block of cells, no
-data-path collective).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time.
+data-path collective).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time | dqm_doy31_nan
+(BASELINE configs[4]: use --days 21900).
 
 N > 1: launched by torch.distributed.run, one process per GPU; torch is used only for the rendezvous,
 the barrier and the MAX over ranks (and the optional final RCCL gather of scen, timed separately).
@@ -34,7 +35,11 @@ WORKLOADS = {
     "eqm_time": ("eqm", "time", 1, "+", 0),
     "dqm_doy31": ("dqm", "dayofyear", 31, "+", 0),
     "qdm_doy31": ("qdm", "dayofyear", 31, "*", 1),
+    # BASELINE configs[4]: 60 years daily, 30 % of the cells all-NaN ("ocean") + 1 % i.i.d. NaN elsewhere (run it with
+    # --days 21900; cells per GPU as memory allows)
+    "dqm_doy31_nan": ("dqm", "dayofyear", 31, "+", 0),
 }
+NAN_MASK = {"dqm_doy31_nan": (0.30, 0.01)}  # workload -> (fraction of all-NaN cells, i.i.d. NaN fraction elsewhere)
 
 
 def group_index(group: str, T: int):
@@ -105,11 +110,12 @@ def main():
     gidx, G = group_index(group, T)
     q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
     tnum = (np.arange(T, dtype=np.float64) + 10950.0) * 86400e9
-    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3}.get(args.workload, 1)
+    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3, "dqm_doy31_nan": 4}.get(args.workload, 1)
     cell0 = rank * C
-    ref = ctx.synth((C, T), np.float32, gen, 0, seed, cell0, time_major=args.time_major)
-    hist = ctx.synth((C, T), np.float32, gen, 1, seed, cell0, time_major=args.time_major)
-    sim = ctx.synth((C, T), np.float32, gen, 2, seed, cell0, time_major=args.time_major)
+    ncf, nif = NAN_MASK.get(args.workload, (0.0, 0.0))
+    ref = ctx.synth((C, T), np.float32, gen, 0, seed, cell0, ncf, nif, time_major=args.time_major)
+    hist = ctx.synth((C, T), np.float32, gen, 1, seed, cell0, ncf, nif, time_major=args.time_major)
+    sim = ctx.synth((C, T), np.float32, gen, 2, seed, cell0, ncf, nif, time_major=args.time_major)
     ctx.synchronize()
 
     # output buffers are allocated once and reused by every step (a production pipeline does the same; a fresh
