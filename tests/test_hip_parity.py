@@ -380,6 +380,43 @@ def test_scaling_vs_oracle(hip, gname, dtype):
         assert_close(got, oracle.scaling_adjust(x, af, gidx if G > 1 else None, kind), rtol=0.0, what=f"scaling_adjust {kind}")
 
 
+@pytest.mark.parametrize("gname", ["doy31", "month", "time"])
+def test_f64_train_near_collisions(hip, gname):
+    """float64 fast kernel (31-bit range keys + tie repair): clusters of distinct doubles that differ far below the key
+    resolution, exact ties, huge dynamic range, long series; EQM bit-exact, DQM to 2 ulp"""
+    rng = np.random.default_rng(31)
+    T, C = 10950 if gname != "time" else 6000, 4
+    gidx, G, W = GROUPINGS[gname](T)
+    q = _nodes(20, np.float64)
+    base = 280 + 15 * rng.standard_normal((C, T))
+    ref, hist = base.copy(), base[:, ::-1].copy() + 0.5
+    # cell 0: half of the values sit in a cluster 1e-13 wide (thousands of key collisions between distinct doubles)
+    m = rng.random(T) < 0.5
+    hist[0, m] = 300.0 + 1e-13 * rng.permutation(m.sum())
+    ref[0, m] = 299.0 + 1e-12 * rng.permutation(m.sum())
+    # cell 1: heavy exact ties next to a huge dynamic range (no signed zeros: which zero a quantile returns is the
+    # sort's choice in the reference as well, and 1/-0.0 would turn it into the sign of an infinite factor)
+    hist[1] = np.where(rng.random(T) < 0.4, 0.0, rng.gamma(0.3, 50.0, T))
+    hist[1, 5] = 1e300
+    ref[1] = np.round(ref[1])
+    # cell 2: NaNs; cell 3: came from float32
+    hist[2, rng.random(T) < 0.1] = np.nan
+    ref[3], hist[3] = ref[3].astype(np.float32), hist[3].astype(np.float32)
+    for kind in "+*":
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+        assert_close(hq, ehq, rtol=0.0, what=f"hist_q {kind}")
+        assert_close(af, eaf, rtol=0.0, what=f"af {kind}")
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, "+")
+    # float64 group means: summation order (sequential in the oracle, block / running sums on the device)
+    assert_close(sc, esc, rtol=1e-12, atol=1e-10, what="scaling")
+    assert_close(hq, ehq, rtol=1e-12, atol=1e-10, what="hist_q (dqm)")
+    assert_close(af, eaf, rtol=1e-11, atol=1e-9, what="af (dqm)")
+    got = hip.quantile_groups(hist, gidx, G, W, q)
+    assert_close(got, oracle.quantile_groups(hist, gidx, G, W, q), rtol=0.0, what="quantile_groups f64")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

@@ -19,6 +19,7 @@
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
 #include "train_long.hpp"
+#include "train_cell_f64.hpp"
 #include "preproc.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
@@ -502,6 +503,42 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             using std::true_type;
             rc = mode == 2 ? (pl->d_tog64 ? go(true_type{}, true_type{}) : go(true_type{}, false_type{}))
                            : (pl->d_tog64 ? go(false_type{}, true_type{}) : go(false_type{}, false_type{}));
+            if (rc) return rc;
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
+            fast = true;
+        }
+    }
+    if constexpr (std::is_same<R, double>::value) {
+        // float64 series: 31-bit range keys + tie repair, train_cell_f64.hpp
+        const char *force = getenv("XSDBA_HIP_TRAIN");
+        const bool fast64 = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
+        if (fast64) {
+            void *flags;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
+            auto go = [&](auto cfg, auto dqm, auto t64) -> int {
+                constexpr int EPT = decltype(cfg)::value;
+                constexpr bool DQM = decltype(dqm)::value, TOG64 = decltype(t64)::value;
+                const size_t lds = xs::CellCfg<EPT>::lds_bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_cell_f64<EPT, DQM, TOG64>, lds, ctx, "the per-cell sort"))) return rc2;
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
+                LaunchScope ls(ctx, "k_train_cell_f64");
+                hipLaunchKernelGGL((xs::k_train_cell_f64<EPT, DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream,
+                                   (const double *)s0.dev, (const double *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted,
+                                   pl->d_tog_ptr, pl->d_tog_idx, G, (const double *)dq, Q, (int)kind, mode, (double *)oaf.dev,
+                                   (double *)ohq.dev, (double *)osc.dev, flag_count, flag_list, C, pl->d_tog64);
+                return check_launch("k_train_cell_f64");
+            };
+            using std::false_type;
+            using std::integral_constant;
+            using std::true_type;
+            auto pick_t64 = [&](auto cfg, auto dqm) -> int { return pl->d_tog64 ? go(cfg, dqm, true_type{}) : go(cfg, dqm, false_type{}); };
+            auto pick_dqm = [&](auto cfg) -> int { return mode == 2 ? pick_t64(cfg, true_type{}) : pick_t64(cfg, false_type{}); };
+            rc = ept == 4 ? pick_dqm(integral_constant<int, 4>{}) : ept == 8 ? pick_dqm(integral_constant<int, 8>{})
+                                                                              : pick_dqm(integral_constant<int, 11>{});
             if (rc) return rc;
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
             fast = true;

@@ -66,13 +66,12 @@ template <int EPT> struct CellCfg {
     static constexpr size_t lds_bytes = off_misc + 64 * 8;  // reduction scratch
 };
 
-// Phases A + B, shared by k_train_cell and k_qdm_cell: the cell's series -> order-preserving keys in LDS, the time
-// indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
-// (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
-// stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
+// Phase B: LSD radix sort of the time indexes by the keys in LDS (valid keys lie in [kmin, kmin + range], NaN / padding
+// are 0xFFFFFFFF), then rank[t] = position of t.  Returns the sorted index array (one of the two u16 buffers; the other
+// one is free afterwards).  stop_after == 2: return before building rank[].
 template <int EPT>
-__device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
-                                                          uint32_t *red, int stop_after, int &nvalid_out)
+__device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
+                                                              uint32_t kmin, uint32_t range, int stop_after)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
@@ -83,64 +82,8 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
     uint32_t *cnthi = reinterpret_cast<uint32_t *>(smem + Cfg::off_cnthi);
     uint16_t *base = reinterpret_cast<uint16_t *>(smem + Cfg::off_base);
     uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
-    // the thread index is made opaque per call: everything derived from it (addresses, element indexes) is then
-    // recomputed here instead of being hoisted out of the caller's cell loop and spilled to scratch across it
-    int tid = threadIdx.x;
-    __asm__ volatile("" : "+v"(tid));
     const int lane = tid & 63, wid = tid >> 6;
-        // ---------------- A. load, keys, range ----------------
-        int nv = 0;
-        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        const int Ti = (int)T;  // <= TPAD
-        if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
-            // all the loads of the series are issued before the first one is consumed (one HBM latency per array
-            // instead of one per 2048 elements).  They are unconditional — addresses clamped to the last full pair,
-            // out-of-range results replaced by NaN afterwards — so that nothing orders them behind a branch.
-            constexpr int NL = (EPT + 1) / 2;
-            const int Te = Ti & ~1;                 // elements covered by whole pairs (T >= 64)
-            const float xlast = x[Ti - 1];          // the odd tail element, uniform address
-            float2 v2[NL];
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                const int i = 2 * tid + j * 2 * NT;
-                v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
-            }
-#pragma unroll
-            for (int j = 0; j < NL; j++) {
-                const int i = 2 * tid + j * 2 * NT;
-                if (i < TPAD) {
-                    float a = v2[j].x, b = v2[j].y;
-                    if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
-                    uint32_t k0 = to_key(a), k1 = to_key(b);
-                    *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
-                    if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
-                    if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
-                }
-            }
-        } else {
-            for (int i = tid; i < TPAD; i += NT) {
-                uint32_t k = i < Ti ? to_key(x[i]) : 0xFFFFFFFFu;
-                keys[i] = k;
-                if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            nv += __shfl_down(nv, o, 64);
-            kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, o, 64));
-            kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, o, 64));
-        }
-        if (lane == 0) { red[3 * wid] = (uint32_t)nv; red[3 * wid + 1] = kmin; red[3 * wid + 2] = kmax; }
-        __syncthreads();
-        nv = 0; kmin = 0xFFFFFFFFu; kmax = 0u;
-        for (int w = 0; w < Cfg::NWAVE; w++) { nv += (int)red[3 * w]; kmin = min(kmin, red[3 * w + 1]); kmax = max(kmax, red[3 * w + 2]); }
-        const int nvalid = nv;
-        nvalid_out = nv;
-        const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
-        const int nbits = 32 - __clz((int)(range + 1u) | 0) ;
-        __syncthreads();
-
-        if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
+    const int nbits = 32 - __clz((int)(range + 1u) | 0);
         // ---------------- B. LSD radix sort of the time indexes ----------------
         // Pass 1 takes the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no
         // information), so it is a counting sort with LDS atomics: 16384 u16 bins packed two per dword, histogram by
@@ -259,9 +202,81 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         return sorted;
 }
 
+// Phases A + B, shared by k_train_cell and k_qdm_cell: the cell's series -> order-preserving keys in LDS, the time
+// indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
+// (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
+// stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
+template <int EPT>
+__device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
+                                                          uint32_t *red, int stop_after, int &nvalid_out)
+{
+    using Cfg = CellCfg<EPT>;
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
+    // the thread index is made opaque per call: everything derived from it (addresses, element indexes) is then
+    // recomputed here instead of being hoisted out of the caller's cell loop and spilled to scratch across it
+    int tid = threadIdx.x;
+    __asm__ volatile("" : "+v"(tid));
+    const int lane = tid & 63, wid = tid >> 6;
+        // ---------------- A. load, keys, range ----------------
+        int nv = 0;
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        const int Ti = (int)T;  // <= TPAD
+        if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
+            // all the loads of the series are issued before the first one is consumed (one HBM latency per array
+            // instead of one per 2048 elements).  They are unconditional — addresses clamped to the last full pair,
+            // out-of-range results replaced by NaN afterwards — so that nothing orders them behind a branch.
+            constexpr int NL = (EPT + 1) / 2;
+            const int Te = Ti & ~1;                 // elements covered by whole pairs (T >= 64)
+            const float xlast = x[Ti - 1];          // the odd tail element, uniform address
+            float2 v2[NL];
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int i = 2 * tid + j * 2 * NT;
+                v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
+            }
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const int i = 2 * tid + j * 2 * NT;
+                if (i < TPAD) {
+                    float a = v2[j].x, b = v2[j].y;
+                    if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
+                    uint32_t k0 = to_key(a), k1 = to_key(b);
+                    *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
+                    if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
+                    if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
+                }
+            }
+        } else {
+            for (int i = tid; i < TPAD; i += NT) {
+                uint32_t k = i < Ti ? to_key(x[i]) : 0xFFFFFFFFu;
+                keys[i] = k;
+                if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            nv += __shfl_down(nv, o, 64);
+            kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, o, 64));
+            kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, o, 64));
+        }
+        if (lane == 0) { red[3 * wid] = (uint32_t)nv; red[3 * wid + 1] = kmin; red[3 * wid + 2] = kmax; }
+        __syncthreads();
+        nv = 0; kmin = 0xFFFFFFFFu; kmax = 0u;
+        for (int w = 0; w < Cfg::NWAVE; w++) { nv += (int)red[3 * w]; kmin = min(kmin, red[3 * w + 1]); kmax = max(kmax, red[3 * w + 2]); }
+        const int nvalid = nv;
+        nvalid_out = nv;
+        const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
+        __syncthreads();
+
+        if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
+        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after);
+}
+
 // Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has
 // the global-memory counterpart
 struct LdsVals {
+    using value_type = float;
     const uint32_t *keys;      // [TPAD] order-preserving keys by time index
     const uint16_t *sorted;    // [TPAD] time index by rank
     int tpad;
@@ -281,10 +296,12 @@ template <typename Geo, bool DIAG, bool DQM, bool TOG64, typename Vals, typename
 __device__ __forceinline__ void cell_group_quantiles(
     const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid, int lane, int wid,
     const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr,
-    const int *__restrict__ tog_idx, const int *__restrict__ tog64, int G, const float *__restrict__ q, int Q, int kind,
-    int mode, int arr, int64_t c, float *__restrict__ af, float *out_hq, float *scaling, bool &flag_cell,
+    const int *__restrict__ tog_idx, const int *__restrict__ tog64, int G, const typename Vals::value_type *__restrict__ q, int Q, int kind,
+    int mode, int arr, int64_t c, typename Vals::value_type *__restrict__ af, typename Vals::value_type *out_hq,
+    typename Vals::value_type *scaling, bool &flag_cell,
     int debug_phase, Stamp &stamp)
 {
+    using R = typename Vals::value_type;  // float or double series
     constexpr int TPAD = Geo::TPAD, WPL = Geo::WPL, BITW = Geo::BITW;
         // ---------------- C. membership bit-vectors in rank space + select ----------------
         // Every wave owns a contiguous range [r0, r1) of groups and walks it OUTWARD from its middle gc with two
@@ -303,6 +320,7 @@ __device__ __forceinline__ void cell_group_quantiles(
         lds_wave_fence();
         const uint32_t *bits_h = half ? bitsB : bitsA;
         double gsumA = 0.0, gsumB = 0.0;
+        double amax = 0.0;  // float64 DQM: largest magnitude that went through the running sums of this wave
         // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select.
         // "list r" is the symmetric difference of rows r-1 and r: row r of the padded [G][64] table tog64 (when every
         // list has <= 64 entries, e.g. doy windows: one independent vector load, no pointer chase through SMEM), else
@@ -316,7 +334,7 @@ __device__ __forceinline__ void cell_group_quantiles(
         if (cntB > 0) load_list(gc, preB, preB_base, preB_len);      // B, it = 0: gc -> gc-1
         // quantile-index math depends on (n, k) only: cached while both halves keep their n
         int nA_prev = -1, nB_prev = -1, c_case = 3, c_lo = 0;
-        float c_gamma = 0.f;
+        R c_gamma = (R)0;
         const int n_iter = cntA;
         for (int it = 0; it < n_iter; it++) {
             const int gA = gc + it, gB = gc - 1 - it;
@@ -332,8 +350,9 @@ __device__ __forceinline__ void cell_group_quantiles(
                     const uint32_t m = 1u << (r & 31);
                     if (DQM) {
                         uint32_t old = atomicXor(&bits[r >> 5], m);
-                        float v = vals.at_time(t);
+                        R v = vals.at_time(t);
                         dloc += (old & m) ? -(double)v : (double)v;
+                        if constexpr (sizeof(R) == 8) amax = fmax(amax, fabs((double)v));
                     } else {
                         (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -390,7 +409,7 @@ __device__ __forceinline__ void cell_group_quantiles(
             const int n = half ? nB : nA;
             const int g = half ? gB : gA;
             const bool vh = half ? vB : vA;
-            float mu = 0.f, inv = 0.f;
+            R mu = (R)0, inv = (R)0;
             if (DQM) {
                 // at it == 0 dlocA holds the sum of the built vector, which B starts from, and dlocB B's first toggles
                 const double sA = __shfl(wave_sum(dlocA), 0, 64), sB = __shfl(wave_sum(dlocB), 0, 64);
@@ -398,9 +417,19 @@ __device__ __forceinline__ void cell_group_quantiles(
                 gsumA += sA;
                 gsumB += sB;
                 const double gs = half ? gsumB : gsumA;
-                mu = n ? (float)(gs / (double)n) : __builtin_nanf("");
-                inv = invert<float>(mu, kind);
-                if (vh && n && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
+                mu = n ? (R)(gs / (double)n) : nan_of<R>();
+                inv = invert<R>(mu, kind);
+                if (vh && n && (!isfinite(mu) || (kind == '*' && !(inv > (R)0 && isfinite(inv))))) flag_cell = true;
+                if constexpr (sizeof(R) == 8) {
+                    // float64 series: the running sums carry a rounding error of about eps * |largest value seen| per
+                    // toggle.  Keep them only while that stays below ~1e-12 of the group sum; otherwise (huge dynamic
+                    // range, or a group mean next to zero) the generic kernel redoes the cell with fresh sums.
+                    double am = amax;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) am = fmax(am, __shfl_xor(am, o, 64));
+                    amax = am;
+                    if (vh && n && !(am <= 200.0 * fabs(gs))) flag_cell = true;
+                }
             }
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
             // rank-space positions of the j-th member of this half's vector (lrank) and of the member after it (hrank;
@@ -463,21 +492,21 @@ __device__ __forceinline__ void cell_group_quantiles(
                 found = inword || nw != 0;
                 hrank = inword ? lrank + __ffs((int)rest) : wbase + nw * 32 + __ffs((int)nwv) - 1;
             };
-            if (debug_phase == 3 || debug_phase == 4) { if (n == 12345 && lane == 0) out_hq[obase] = (float)exclp; continue; }
+            if (debug_phase == 3 || debug_phase == 4) { if (n == 12345 && lane == 0) out_hq[obase] = (R)exclp; continue; }
             for (int kb = 0; kb < Q; kb += 32) {
                 const int k = kb + (lane & 31);
                 const bool act = vh && k < Q;
                 int casek, lo;  // casek 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
-                float gamma;
+                R gamma;
                 if (kb == 0 && nA == nA_prev && nB == nB_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
                 else {
                     const double qk = (double)q[k < Q ? k : 0];
                     const double vi = (double)n * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
-                    lo = 0; gamma = 0.f;
+                    lo = 0; gamma = (R)0;
                     if (n == 0) casek = 3;
                     else if (vi != vi || vi >= (double)(n - 1)) { casek = 1; lo = n - 1; }
                     else if (vi < 0.0) { casek = 2; lo = 0; }
-                    else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
+                    else { casek = 0; lo = (int)floor(vi); gamma = (R)(vi - (double)lo); }
                     if (kb == 0) { c_case = casek; c_lo = lo; c_gamma = gamma; }
                 }
                 stamp(2);  // DQM mean, quantile index math
@@ -503,31 +532,31 @@ __device__ __forceinline__ void cell_group_quantiles(
                 stamp(5);  // next set bit (+ second select)
                 // both neighbours are looked up together: two independent (index, key) LDS round trips in flight
                 const int rs0 = min(lrank, TPAD - 1), rs1 = min(casek == 0 ? hrank : lrank, TPAD - 1);
-                float v, vhi;
+                R v, vhi;
                 vals.at_ranks(rs0, rs1, v, vhi);
                 stamp(4);  // value lookups
-                if (DQM) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
-                float res;
-                if (casek == 3) res = __builtin_nanf("");
+                if (DQM) { v = apply_corr<R>(v, inv, kind); vhi = apply_corr<R>(vhi, inv, kind); }
+                R res;
+                if (casek == 3) res = nan_of<R>();
                 else if (casek != 0) res = v;
                 else {
-                    float left = v, right = vhi;
-                    float diff = right - left;
-                    if (gamma >= 0.5f) res = (float)((double)right - (double)diff * (1.0 - (double)gamma));
+                    R left = v, right = vhi;
+                    R diff = right - left;
+                    if (gamma >= (R)0.5) res = (R)((double)right - (double)diff * (1.0 - (double)gamma));
                     else res = left + diff * gamma;
                     if (res != res && act) flag_cell = true;  // inf - inf: needs a[n-1]; the generic kernel redoes the cell
                 }
                 if (act) {
                     if (mode == 0) out_hq[obase + k] = res;
                     else if (arr == 0) out_hq[obase + k] = res;  // hist_q
-                    else af[obase + k] = get_corr<float>(out_hq[obase + k], res, kind);  // res = ref_q
+                    else af[obase + k] = get_corr<R>(out_hq[obase + k], res, kind);  // res = ref_q
                 }
             }
             stamp(6);  // upper value, interpolation, stores
             nA_prev = nA; nB_prev = nB;
             if (DQM && vh && (lane & 31) == 0) {
                 if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced below
-                else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
+                else scaling[(size_t)c * G + g] = get_corr<R>(scaling[(size_t)c * G + g], mu, kind);
             }
         }
 }

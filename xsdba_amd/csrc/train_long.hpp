@@ -43,6 +43,7 @@ __device__ __forceinline__ void stores_done()
 }
 
 struct GlobalValsL2 {
+    using value_type = float;
     const float *x;
     const uint32_t *by_rank;
     __device__ __forceinline__ float at_time(int t) const { return x[t]; }
