@@ -447,7 +447,8 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 size_t lds = xs::CellCfg<EPT>::lds_bytes;
                 int rc2;
                 if ((rc2 = set_lds(xs::k_train_cell<EPT, DIAG, DQM, TOG64>, lds, ctx, "the per-cell sort"))) return rc2;
-                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);  // blocks walk the cells grid-stride
+                const int gm = getenv("XSDBA_HIP_GRID_MULT") ? atoi(getenv("XSDBA_HIP_GRID_MULT")) : 4;  // tuning aid
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)std::max(gm, 1) * ctx->n_cu);  // blocks walk the cells grid-stride
                 LaunchScope ls(ctx, "k_train_cell");
                 hipLaunchKernelGGL((xs::k_train_cell<EPT, DIAG, DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream,
                                    (const float *)s0.dev, (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted,
