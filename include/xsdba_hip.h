@@ -206,6 +206,18 @@ int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int
                              const int32_t *group_of_time, int32_t n_groups, char kind, void *scen,
                              int64_t out_stride_t, int64_t out_stride_c);
 
+/* ---- f3: LOCI (adjustment.py:933-1009, _adjustment.py:889-939).  loci_train: per (cell, group) block (dims
+ * [time, window] pooled) hist_thresh = the value of hist with the same CDF as thresh in ref (utils.map_cdf :40-84:
+ * q = (#(ref <= thresh) + 1) / (#valid + 1), np.nanquantile(hist, q)); af = (mean(ref >= thresh) - thresh) /
+ * (mean(hist >= hist_thresh of the element's own group) - hist_thresh).  loci_adjust: scen = max(af * (sim -
+ * hist_thresh) + thresh, 0) with the factors of each time step's group (nearest-group broadcast). */
+int xsdba_hip_loci_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t n_time, int64_t n_cell,
+                         int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
+                         int32_t window, double thresh, void *af /* [cell][group] */, void *hist_thresh /* [cell][group] */);
+int xsdba_hip_loci_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                          int64_t stride_c, const void *af, const void *hist_thresh, const int32_t *group_of_time,
+                          int32_t n_groups, double thresh, void *scen, int64_t out_stride_t, int64_t out_stride_c);
+
 /* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
 int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
                                 int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,

@@ -240,6 +240,30 @@ def scaling_adjust(sim, af, gidx, kind="+"):
     return out
 
 
+def loci_train(ref, hist, gidx, G, W, thresh):
+    """-> (af, hist_thresh) each [C, G]"""
+    ref = np.ascontiguousarray(ref)
+    hist = np.ascontiguousarray(hist, ref.dtype)
+    Cn, T = ref.shape
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    af, sth = np.empty((Cn, G), ref.dtype), np.empty((Cn, G), ref.dtype)
+    _check(lib().xsdba_oracle_loci_train(_p(ref), _p(hist), _dt(ref), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(gidx), C.c_int(G),
+                                         C.c_int(W), C.c_double(float(thresh)), _p(af), _p(sth)), "loci_train")
+    return af, sth
+
+
+def loci_adjust(sim, af, hist_thresh, gidx, thresh):
+    sim = np.ascontiguousarray(sim)
+    Cn, T = sim.shape
+    af, sth = np.ascontiguousarray(af, sim.dtype), np.ascontiguousarray(hist_thresh, sim.dtype)
+    G = af.shape[1]
+    gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    out = np.empty_like(sim)
+    _check(lib().xsdba_oracle_loci_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(af), _p(sth), _p(gidx), C.c_int(G),
+                                          C.c_double(float(thresh)), _p(out), _i64(1), _i64(T)), "loci_adjust")
+    return out
+
+
 def rank_groups(x, gidx, G, W, rank_window=False):
     x = np.asarray(x)
     Cn, T = x.shape

@@ -526,3 +526,87 @@ API int xsdba_oracle_scaling_adjust(const void *sim, int dtype, int64_t T, int64
         }
     return 0;
 }
+
+/* LOCI (_adjustment.py:889-939).  loci_train: s_thresh = map_cdf(x=hist, y=ref, y_value=thresh) per block
+ * (utils.py:35-44: q = searchsorted([-inf, sorted y], thresh, "right") / count(~isnan) = (#(y <= thresh) + 1) / (n + 1);
+ * np.nanquantile(x, q), linear method), sth = its nearest-group broadcast, ws = hist where hist >= sth, wo = ref where
+ * ref >= thresh (masks on the time series), ms / mo = block means (dims [time, window]), af = (mo - thresh) / (ms - s_thresh). */
+API int xsdba_oracle_loci_train(const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                const int32_t *gidx, int G, int W, double thresh, void *af, void *hist_thresh)
+{
+    group_plan pl;
+    int rc = plan_build(&pl, gidx, T, G, W);
+    if (rc) { plan_free(&pl); return rc; }
+#define LD(p, c, t) (dtype == 0 ? (double)((const float *)(p))[(c) * sc + (t) * st] : ((const double *)(p))[(c) * sc + (t) * st])
+    double *buf = (double *)malloc(sizeof(double) * (size_t)(pl.max_row + 1));
+    double *sth = (double *)malloc(sizeof(double) * (size_t)G);
+    for (int64_t c = 0; c < C; c++) {
+        for (int g = 0; g < G; g++) {
+            int64_t nle = 0, nr = 0, nh = 0;
+            for (int64_t i = pl.row_ptr[g]; i < pl.row_ptr[g + 1]; i++) {
+                double v = LD(ref, c, pl.row_idx[i]);
+                if (!isnan(v)) { nr++; if (v <= thresh) nle++; }
+                double h = LD(hist, c, pl.row_idx[i]);
+                if (!isnan(h)) buf[nh++] = h;
+            }
+            double q = ((double)nle + 1.0) / ((double)nr + 1.0), res = NAN;
+            if (nh > 0) {
+                quick_sort_f64(buf, nh);
+                double vi = (double)(nh - 1) * q;
+                int64_t lo = (int64_t)floor(vi);
+                if (lo < 0) lo = 0;
+                if (lo > nh - 1) lo = nh - 1;
+                int64_t hi = lo + 1 > nh - 1 ? nh - 1 : lo + 1;
+                res = buf[lo] + (buf[hi] - buf[lo]) * (vi - (double)lo);
+            }
+            if (dtype == 0) res = (double)(float)res;
+            sth[g] = res;
+            if (dtype == 0) ((float *)hist_thresh)[(size_t)c * G + g] = (float)res; else ((double *)hist_thresh)[(size_t)c * G + g] = res;
+        }
+        for (int g = 0; g < G; g++) {
+            double so = 0, ss = 0;
+            int64_t no = 0, ns = 0;
+            for (int64_t i = pl.row_ptr[g]; i < pl.row_ptr[g + 1]; i++) {
+                int64_t tt = pl.row_idx[i];
+                double vo = LD(ref, c, tt), vs = LD(hist, c, tt);
+                if (vo >= thresh) { so += vo; no++; }
+                int gt = gidx ? gidx[tt] : 0;
+                if (gt >= 0 && vs >= sth[gt]) { ss += vs; ns++; }
+            }
+            double mo = no ? so / (double)no : NAN, ms = ns ? ss / (double)ns : NAN;
+            if (dtype == 0) ((float *)af)[(size_t)c * G + g] = ((float)mo - (float)thresh) / ((float)ms - (float)sth[g]);
+            else ((double *)af)[(size_t)c * G + g] = (mo - thresh) / (ms - sth[g]);
+        }
+    }
+#undef LD
+    free(buf); free(sth);
+    plan_free(&pl);
+    return 0;
+}
+
+/* loci_adjust (_adjustment.py:922-939): scen = (factor * (sim - sth) + thresh).clip(min=0), nearest-group broadcast */
+API int xsdba_oracle_loci_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                                 const void *hist_thresh, const int32_t *gidx, int G, double thresh, void *scen, int64_t ost,
+                                 int64_t osc)
+{
+    for (int64_t c = 0; c < C; c++)
+        for (int64_t t = 0; t < T; t++) {
+            int g = G > 1 ? gidx[t] : 0;
+            if (dtype == 0) {
+                float y = NAN;
+                if (g >= 0) {
+                    y = ((const float *)af)[(size_t)c * G + g] * (((const float *)sim)[c * sc + t * st] - ((const float *)hist_thresh)[(size_t)c * G + g]) + (float)thresh;
+                    if (y < 0.0f) y = 0.0f;
+                }
+                ((float *)scen)[c * osc + t * ost] = y;
+            } else {
+                double y = NAN;
+                if (g >= 0) {
+                    y = ((const double *)af)[(size_t)c * G + g] * (((const double *)sim)[c * sc + t * st] - ((const double *)hist_thresh)[(size_t)c * G + g]) + thresh;
+                    if (y < 0.0) y = 0.0;
+                }
+                ((double *)scen)[c * osc + t * ost] = y;
+            }
+        }
+    return 0;
+}

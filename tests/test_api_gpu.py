@@ -56,6 +56,30 @@ def mon_timelonlatseries(values, attrs):
     return DataArray(apply_correction(x, factor, attrs["kind"]).values, x.dims, x.coords, attrs)
 
 
+class TestLoci:
+    """reference tests/test_adjustment.py:156-203"""
+
+    @pytest.mark.parametrize("group,dec", (["time", 2], ["time.month", 1]))
+    def test_time_and_from_ds(self, group, dec, random):
+        n = 10000
+        x = uniform(loc=0, scale=3).ppf(random.random(n))
+        hist = sim = timelonlatseries(x, attrs={"units": "kg m-2 s-1", "history": "ancient history."})
+        y = x * 2
+        thresh = 2
+        ref_fit = timelonlatseries(np.where(y > thresh, y, 0.1), attrs={"units": "kg m-2 s-1"})
+        ref = timelonlatseries(y, attrs={"units": "kg m-2 s-1"})
+        loci = xs.LOCI.train(ref_fit, hist, group=group, thresh=f"{thresh} kg m-2 s-1")
+        np.testing.assert_array_almost_equal(loci.ds.hist_thresh.values, 1, dec)
+        np.testing.assert_array_almost_equal(loci.ds.af.values, 2, dec)
+        p = loci.adjust(sim, interp="nearest")
+        np.testing.assert_array_almost_equal(p.values, ref.values, dec)
+        assert "Bias-adjusted with LOCI(" in p.attrs["history"] and p.attrs["history"].endswith("ancient history.")
+        loci2 = xs.LOCI.from_dataset(loci.ds)
+        np.testing.assert_array_equal(loci2.adjust(sim, interp="nearest").values, p.values)
+        if group == "time":
+            np.testing.assert_array_equal(loci.adjust(sim).values, p.values)  # default interp: one group, nothing to interpolate
+
+
 class TestScaling:
     """reference tests/test_adjustment.py:206-258"""
 

@@ -417,6 +417,33 @@ def test_f64_train_near_collisions(hip, gname):
     assert_close(got, oracle.quantile_groups(hist, gidx, G, W, q), rtol=0.0, what="quantile_groups f64")
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("gname", ["time", "month", "doy31"])
+def test_loci_vs_oracle(hip, gname, dtype):
+    """LOCI: hist_thresh bit-exact (sort + float64 lerp), af to the summation order of the block means,
+    loci_adjust bit-exact"""
+    rng = np.random.default_rng(23)
+    T, C = 2920, 5
+    gidx, G, W = GROUPINGS[gname](T)
+    ref = rng.gamma(0.8, 6.0, (C, T)).astype(dtype)
+    hist = (rng.gamma(0.9, 4.0, (C, T)) * 0.7).astype(dtype)
+    ref[1, rng.random(T) < 0.05] = np.nan
+    hist[2, rng.random(T) < 0.05] = np.nan
+    hist[3] = np.nan
+    af, sth = hip.loci_train(ref, hist, gidx, G, W, 1.0)
+    eaf, esth = oracle.loci_train(ref, hist, gidx, G, W, 1.0)
+    assert_close(sth, esth, rtol=0.0, what="hist_thresh")
+    assert_close(af, eaf, rtol=5e-6 if dtype == np.float32 else 1e-11, what="af")
+    assert np.isnan(af[3]).all() and np.isfinite(af[:3]).all()
+    sim = (rng.gamma(0.9, 4.0, (C, T)) * 0.8).astype(dtype)
+    gi = gidx.copy()
+    if G > 1:
+        gi[11::100] = -1
+    got = hip.loci_adjust(sim, eaf, esth, gi if G > 1 else None, 1.0)
+    assert_close(got, oracle.loci_adjust(sim, eaf, esth, gi if G > 1 else None, 1.0), rtol=0.0, what="loci_adjust")
+    assert (got[np.isfinite(got)] >= 0).all()
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

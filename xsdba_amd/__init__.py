@@ -18,6 +18,7 @@ from .adjustment import (  # noqa: E402,F401
     BaseAdjustment,
     DetrendedQuantileMapping,
     EmpiricalQuantileMapping,
+    LOCI,
     QuantileDeltaMapping,
     Scaling,
     TrainAdjust,

@@ -311,3 +311,26 @@ def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
     scen = hip.scaling_adjust(s2, af, gidx if G > 1 else None, kind)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
+
+
+@map_blocks(reduces=[Grouper.ADD_DIMS, Grouper.DIM], af=[Grouper.PROP], hist_thresh=[Grouper.PROP])
+def loci_train(ds, *, group, thresh) -> Dataset:
+    """LOCI: train on one block (_adjustment.py:889-919), every group at once on the device."""
+    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    af, sth = hip.loci_train(r2, h2, gidx, G, group.window, thresh)
+    out = _train_dataset(ref, group, [], cell_dims, cell_shape, af=af, hist_thresh=sth)
+    return Dataset({"af": out["af"], "hist_thresh": out["hist_thresh"]})
+
+
+@map_blocks(reduces=[Grouper.PROP], scen=[])
+def loci_adjust(ds, *, group, thresh, interp) -> Dataset:
+    """LOCI: adjust on one block (_adjustment.py:922-939); factors and thresholds of the group of each time step
+    (interp="nearest"; the reference's default "linear" interpolates between group centres, which is not on the device —
+    for a single group both are the same)."""
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
+    if interp != "nearest" and G > 1:
+        raise NotImplementedError("loci_adjust on the HIP path broadcasts factors and thresholds with interp='nearest' only")
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    scen = hip.loci_adjust(s2, af, sth, gidx if G > 1 else None, thresh)
+    return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()

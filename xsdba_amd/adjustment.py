@@ -23,7 +23,7 @@ from .labeled import DataArray, Dataset, as_dataarray, as_dataset, is_xarray
 from .options import EXTRA_OUTPUT, OPTIONS
 from .utils import ADDITIVE, equally_spaced_nodes
 
-__all__ = ["BaseAdjustment", "DetrendedQuantileMapping", "EmpiricalQuantileMapping", "QuantileDeltaMapping", "Scaling", "TrainAdjust"]
+__all__ = ["BaseAdjustment", "DetrendedQuantileMapping", "EmpiricalQuantileMapping", "LOCI", "QuantileDeltaMapping", "Scaling", "TrainAdjust"]
 
 
 def gen_call_string(funcname: str, *args, **kwargs) -> str:
@@ -271,8 +271,6 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
         return out["scen"]
 
 
-for _cls in (EmpiricalQuantileMapping, DetrendedQuantileMapping, QuantileDeltaMapping):
-    _register(_cls, "xsdba.adjustment")
 
 
 class Scaling(TrainAdjust):
@@ -294,3 +292,32 @@ class Scaling(TrainAdjust):
         from ._adjustment import scaling_adjust
 
         return scaling_adjust(Dataset({"sim": sim, "af": self.ds["af"]}), group=self.group, interp=interp, kind=self.kind)["scen"]
+
+
+class LOCI(TrainAdjust):
+    """Local Intensity Scaling (adjustment.py:933-1009; Schmidli et al. 2006): wet-day intensity ratio above a threshold
+    that is mapped from `ref` to `hist` through their CDFs."""
+
+    _allow_diff_calendars = False
+    _allow_diff_training_times = False
+
+    @classmethod
+    def _train(cls, ref, hist, *, thresh, group="time"):
+        from ._adjustment import loci_train
+        from .processing import quantity_to_float
+
+        thresh = quantity_to_float(thresh, ref, "thresh")
+        ds = loci_train(Dataset({"ref": ref, "hist": hist}), group=group, thresh=thresh)
+        ds["af"].attrs.update(long_name="LOCI adjustment factors")
+        ds["hist_thresh"].attrs.update(long_name="Threshold over modeled data")
+        return ds, {"group": group, "thresh": thresh}
+
+    def _adjust(self, sim, interp="linear"):
+        from ._adjustment import loci_adjust
+
+        return loci_adjust(Dataset({"hist_thresh": self.ds["hist_thresh"], "af": self.ds["af"], "sim": sim}), group=self.group,
+                           thresh=self.thresh, interp=interp)["scen"]
+
+
+for _cls in (EmpiricalQuantileMapping, DetrendedQuantileMapping, QuantileDeltaMapping, Scaling, LOCI):
+    _register(_cls, "xsdba.adjustment")

@@ -995,6 +995,72 @@ int scaling_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t 
     return sync_if(ctx, o.copy_back || !is_device_ptr(sim));
 }
 
+template <typename R>
+int loci_train_impl(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int64_t T, int64_t C, int64_t st, int64_t sc,
+                    const int32_t *gidx, int G, int W, double thresh, void *af, void *hist_thresh)
+{
+    using U = typename xs::KeyOf<R>::U;
+    if (C <= 0 || !af || !hist_thresh) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((int64_t)C * G > (1ll << 31) - 1) return fail(XSDBA_E_ARG, "n_cell * n_groups exceeds 2^31");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
+    SeriesIn r, h;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, ref, T, C, st, sc, &r)) || (rc = series_in<R>(ctx, S_IN1, S_CM1, hist, T, C, st, sc, &h))) return rc;
+    OutStage oa, ot;
+    const size_t ng = (size_t)C * G;
+    if ((rc = stage_out(ctx, S_TAB0, af, ng * sizeof(R), &oa)) || (rc = stage_out(ctx, S_TAB1, hist_thresh, ng * sizeof(R), &ot))) return rc;
+    int P = 2;
+    while (P < pl->max_row) P <<= 1;
+    const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+    const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2), lds = red_b + (size_t)P * sizeof(U);
+    if ((rc = set_lds(xs::k_loci_thresh<R>, lds, ctx, "the LOCI row sort"))) return rc;
+    {
+        LaunchScope ls(ctx, "k_loci_thresh");
+        hipLaunchKernelGGL(xs::k_loci_thresh<R>, dim3((unsigned)ng), dim3(NT), lds, ctx->stream, (const R *)r.dev, (const R *)h.dev,
+                           r.sc, pl->d_row_ptr, pl->d_row_idx, G, thresh, (R *)ot.dev);
+        if ((rc = check_launch("k_loci_thresh"))) return rc;
+    }
+    {
+        LaunchScope ls(ctx, "k_loci_factor");
+        hipLaunchKernelGGL(xs::k_loci_factor<R>, dim3((unsigned)ng), dim3(NT), red_b, ctx->stream, (const R *)r.dev, (const R *)h.dev,
+                           r.sc, pl->d_row_ptr, pl->d_row_idx, pl->d_gidx, G, thresh, (const R *)ot.dev, (R *)oa.dev);
+        if ((rc = check_launch("k_loci_factor"))) return rc;
+    }
+    if ((rc = finish_out(ctx, &oa)) || (rc = finish_out(ctx, &ot))) return rc;
+    return sync_if(ctx, oa.copy_back || ot.copy_back || !is_device_ptr(ref));
+}
+
+template <typename R>
+int loci_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                     const void *hist_thresh, const int32_t *gidx, int G, double thresh, void *scen, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || !af || !hist_thresh || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (T > (1ll << 30)) return fail(XSDBA_E_ARG, "series too long");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    const void *daf, *dth;
+    if ((rc = stage_in(ctx, S_TAB0, af, (size_t)C * G * sizeof(R), &daf)) || (rc = stage_in(ctx, S_TAB1, hist_thresh, (size_t)C * G * sizeof(R), &dth))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    {
+        LaunchScope ls(ctx, "k_loci_adjust");
+        const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 64);
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t nc = std::min<int64_t>(65535, C - c0);
+            hipLaunchKernelGGL(xs::k_loci_adjust<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream, (const R *)s.dev + c0 * s.sc, T,
+                               s.sc, (const R *)daf + (size_t)c0 * G, (const R *)dth + (size_t)c0 * G, G, pl->d_gidx, (R)thresh,
+                               (R *)o.kernel_dst + c0 * T, T);
+        }
+        if ((rc = check_launch("k_loci_adjust"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || !is_device_ptr(sim));
+}
+
 int check_ctx(xsdba_hip_ctx *ctx)
 {
     if (!ctx) return fail(XSDBA_E_ARG, "null context");
@@ -1350,6 +1416,25 @@ API int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype,
     if (rc) return rc;
     return DISPATCH(dtype, (scaling_adjust_impl<float>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)),
                     (scaling_adjust_impl<double>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)));
+}
+
+API int xsdba_hip_loci_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
+                             int64_t sc, const int32_t *gidx, int32_t G, int32_t W, double thresh, void *af, void *hist_thresh)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (loci_train_impl<float>(ctx, ref, hist, T, C, st, sc, gidx, G, W, thresh, af, hist_thresh)),
+                    (loci_train_impl<double>(ctx, ref, hist, T, C, st, sc, gidx, G, W, thresh, af, hist_thresh)));
+}
+
+API int xsdba_hip_loci_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                              const void *af, const void *hist_thresh, const int32_t *gidx, int32_t G, double thresh, void *scen,
+                              int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (loci_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, thresh, scen, ost, osc)),
+                    (loci_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, thresh, scen, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

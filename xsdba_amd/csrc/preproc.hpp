@@ -257,4 +257,105 @@ __global__ void k_scale_groups(const R *__restrict__ sim, int64_t T, int64_t sc,
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LOCI (_adjustment.py:889-939).  Two kernels per training, one workgroup per (cell, group) block:
+//   k_loci_thresh: q = (#(ref <= thresh) + 1) / (#valid ref + 1)  (utils._ecdf_1d :35-37: the sorted sample is prefixed
+//                  with -inf), hist_thresh = np.nanquantile(hist block, q) (linear method, float64, cast to the dtype);
+//   k_loci_factor: ms = mean of the block's hist values >= hist_thresh OF THEIR OWN GROUP (the mask is built on the
+//                  time series, :918-919, before the blocks are formed), mo = mean of ref values >= thresh,
+//                  af = (mo - thresh) / (ms - hist_thresh)  (get_correction, multiplicative).
+//   k_loci_adjust: scen = max(af * (sim - hist_thresh) + thresh, 0) with the group of each time step (:934-937).
+// dynamic LDS of k_loci_thresh: [red][keys: P * sizeof(U)]
+// ---------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void k_loci_thresh(const R *__restrict__ ref, const R *__restrict__ hist, int64_t sc, const int *__restrict__ row_ptr,
+                              const int *__restrict__ row_idx, int G, double thresh, R *__restrict__ hist_thresh)
+{
+    using U = typename KeyOf<R>::U;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);
+    const int nw = (blockDim.x + 63) >> 6;
+    U *keys = reinterpret_cast<U *>(red + 2 * nw + 2);
+    const int64_t c = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    int P = 2;
+    while (P < L) P <<= 1;
+    const R *xr = ref + c * sc, *xh = hist + c * sc;
+    double nle = 0;
+    int nr = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const R v = xr[row_idx[p0 + i]];
+        if (v == v) { nr++; if ((double)v <= thresh) nle += 1.0; }
+    }
+    block_sum_count(nle, nr, red);
+    const double q = (nle + 1.0) / ((double)nr + 1.0);
+    double dummy = 0;
+    int nh = 0;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        U k = KeyOf<R>::MAXK;
+        if (i < L) { const R v = xh[row_idx[p0 + i]]; k = to_key(v); if (v == v) nh++; }
+        keys[i] = k;
+    }
+    block_sum_count(dummy, nh, red);
+    block_bitonic_sort<U>(keys, P);
+    if (threadIdx.x == 0) {
+        // np.nanquantile(x, q), method "linear": virtual index (n - 1) q, lerp between the neighbours
+        R res = nan_of<R>();
+        if (nh > 0) {
+            const double vi = (double)(nh - 1) * q;
+            int lo = (int)floor(vi);
+            lo = lo < 0 ? 0 : (lo > nh - 1 ? nh - 1 : lo);
+            const int hi = lo + 1 > nh - 1 ? nh - 1 : lo + 1;
+            const double a = (double)from_key(keys[lo]), b = (double)from_key(keys[hi]), gam = vi - (double)lo;
+            res = (R)(a + (b - a) * gam);
+        }
+        hist_thresh[(size_t)c * G + g] = res;
+    }
+}
+
+template <typename R>
+__global__ void k_loci_factor(const R *__restrict__ ref, const R *__restrict__ hist, int64_t sc, const int *__restrict__ row_ptr,
+                              const int *__restrict__ row_idx, const int *__restrict__ gidx, int G, double thresh,
+                              const R *__restrict__ hist_thresh, R *__restrict__ af)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = reinterpret_cast<double *>(smem);
+    const int64_t c = blockIdx.x / G;
+    const int g = blockIdx.x % G;
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    const R *xr = ref + c * sc, *xh = hist + c * sc, *sth = hist_thresh + (size_t)c * G;
+    double so = 0, ss = 0;
+    int no = 0, ns = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int tt = row_idx[p0 + i];
+        const R vo = xr[tt], vs = xh[tt];
+        if ((double)vo >= thresh) { so += (double)vo; no++; }
+        const int gt = gidx[tt];
+        if (gt >= 0 && vs >= sth[gt]) { ss += (double)vs; ns++; }
+    }
+    block_sum_count(so, no, red);
+    block_sum_count(ss, ns, red);
+    if (threadIdx.x == 0) {
+        const R mo = no ? (R)(so / (double)no) : nan_of<R>(), ms = ns ? (R)(ss / (double)ns) : nan_of<R>();
+        af[(size_t)c * G + g] = (mo - (R)thresh) / (ms - sth[g]);
+    }
+}
+
+template <typename R>
+__global__ void k_loci_adjust(const R *__restrict__ sim, int64_t T, int64_t sc, const R *__restrict__ af,
+                              const R *__restrict__ hist_thresh, int G, const int *__restrict__ gidx, R thresh,
+                              R *__restrict__ scen, int64_t osc)
+{
+    const int64_t c = blockIdx.y;
+    const R *x = sim + c * sc, *f = af + (size_t)c * G, *h = hist_thresh + (size_t)c * G;
+    R *o = scen + c * osc;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
+        const int g = G > 1 ? gidx[t] : 0;
+        R y = nan_of<R>();
+        if (g >= 0) { y = f[g] * (x[t] - h[g]) + thresh; if (y < (R)0) y = (R)0; }  // clip(min=0) keeps NaN
+        o[t] = y;
+    }
+}
+
 }  // namespace xs

@@ -298,6 +298,36 @@ def scaling_adjust(sim, af, gidx, kind="+", ctx=None):
     return scen
 
 
+def loci_train(ref, hist, gidx, G, W, thresh, ctx=None):
+    """loci_train (_adjustment.py:889-919) -> (af, hist_thresh) each [C, G]"""
+    ctx = ctx or default_context()
+    r, h = _Series(ref), _Series(hist)
+    if (r.st, r.sc) != (h.st, h.sc) and isinstance(ref, np.ndarray) and isinstance(hist, np.ndarray):
+        ref, hist = np.ascontiguousarray(ref), np.ascontiguousarray(hist)
+        r, h = _Series(ref), _Series(hist)
+    if (r.C, r.T, r.dtype, r.st, r.sc) != (h.C, h.T, h.dtype, h.st, h.sc):
+        raise ValueError("ref and hist must share shape, dtype and layout")
+    g = _gidx(gidx, r.T, G)
+    af, sth = np.empty((r.C, G), r.dtype), np.empty((r.C, G), r.dtype)
+    check(load().xsdba_hip_loci_train(ctx.handle, r.ptr, h.ptr, dtype_code(r.dtype), _i64(r.T), _i64(r.C), _i64(r.st), _i64(r.sc),
+                                      _vp(g), C.c_int(G), C.c_int(W), C.c_double(float(thresh)), _vp(af), _vp(sth)), "loci_train")
+    return af, sth
+
+
+def loci_adjust(sim, af, hist_thresh, gidx, thresh, ctx=None):
+    """loci_adjust (_adjustment.py:922-939) with the nearest-group broadcast -> scen [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G = af.shape[1]
+    af, sth = _table(af, s.dtype, (s.C, G)), _table(hist_thresh, s.dtype, (s.C, G))
+    g = _gidx(gidx, s.T, G)
+    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_loci_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                       _vp(af), _vp(sth), _vp(g), C.c_int(G), C.c_double(float(thresh)), _vp(scen), _i64(1), _i64(s.T)),
+          "loci_adjust")
+    return scen
+
+
 def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
     """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
     ctx = ctx or default_context()
@@ -323,5 +353,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "loci_train", "loci_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]
