@@ -734,7 +734,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     if ((rc = series_out_begin<double>(ctx, S_OUT1, S_CM2, sim_q, T, C, ost, osc, &oq))) return rc;
     const size_t tab = ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15);
-    const size_t base = ((sizeof(int) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
+    const size_t base = ((sizeof(double) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
     const bool rw = rank_window && W > 1;
     const int *gp = rw ? pl->d_row_ptr : pl->d_mem_ptr, *gi = rw ? pl->d_row_idx : pl->d_mem_idx;
     // generic kernel (ranks by counting over the ranking row); `cells`: only the listed cells, count read on the device

@@ -454,7 +454,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 // K4: qdm_adjust (_adjustment.py:783-886): percent ranks of sim within its group (utils.rank, utils.py:573-638;
 // average ties, NaN -> NaN, p = r/N rescaled with the extreme ranks) + interpolation of af on the quantile
 // axis + apply.  af == nullptr -> ranks only (utils.rank through Grouper.apply).
-// One block per cell; dynamic LDS: [table (if af)][gstat: 4*G ints][xs: T * sizeof(R)]
+// One block per cell; dynamic LDS: [table (if af)][gstat: 3*G doubles][xs: T * sizeof(R)]
 // ---------------------------------------------------------------------------------------------
 template <typename R, bool TAB_LDS>
 __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
@@ -471,8 +471,8 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         tl = tab_carve<R>(TAB_LDS ? p : gscratch + (size_t)blockIdx.x * gstride, G, Q);
         if (TAB_LDS) p += (tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
     }
-    int *gstat = reinterpret_cast<int *>(p);  // per group: N valid, #==min, #==max
-    p += ((sizeof(int) * 3 * (size_t)G) + 15) & ~(size_t)15;
+    double *gstat = reinterpret_cast<double *>(p);  // per group: N valid, pmin, pmax of the percent-rank rescaling
+    p += ((sizeof(double) * 3 * (size_t)G) + 15) & ~(size_t)15;
     R *xs = reinterpret_cast<R *>(p);
   // cell_list (device list of *n_list_dev cell ids): redo only those cells (the fallback of k_qdm_cell)
   const int64_t n_cells = cell_list ? (int64_t)*n_list_dev : C;
@@ -494,7 +494,10 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         }
         int nmin = 0, nmax = 0;
         for (int i = p0; i < p1; i++) { R v = xs[grp_idx[i]]; nmin += (v == mn); nmax += (v == mx); }
-        gstat[3 * g] = N; gstat[3 * g + 1] = nmin; gstat[3 * g + 2] = nmax;
+        const double Nd = (double)N;
+        gstat[3 * g] = Nd;
+        gstat[3 * g + 1] = (((double)nmin + 1.0) / 2.0) / Nd;
+        gstat[3 * g + 2] = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
     }
     __syncthreads();
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
@@ -505,11 +508,9 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
             int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
             int less = 0, eq = 0;
             for (int i = p0; i < p1; i++) { R u = xs[grp_idx[i]]; less += (u < v); eq += (u == v); }
-            double N = (double)gstat[3 * g], nmin = (double)gstat[3 * g + 1], nmax = (double)gstat[3 * g + 2];
+            const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
             double r = (double)less + (double)(eq + 1) / 2.0;
             double pr = r / N;
-            double pmin = ((nmin + 1.0) / 2.0) / N;
-            double pmax = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
             sq = pmax * (pr - pmin) / (pmax - pmin);
         }
         if (sim_q) sim_q[c * osc + t * ost] = sq;

@@ -32,7 +32,7 @@ template <int EPT> struct QdmCfg {
     static constexpr size_t off_pw = off_bits + (size_t)B::NWAVE * B::BITW * 4;     // per wave: BITW u16 prefix counts
     static constexpr size_t sel_end = off_pw + (size_t)B::NWAVE * B::BITW * 2;
     static constexpr size_t off_gstat = ((B::sort_end > sel_end ? B::sort_end : sel_end) + 15) & ~(size_t)15;
-    static constexpr size_t off_tab = off_gstat + (size_t)GMAX * 3 * 2;             // N, #min, #max per group (u16)
+    static constexpr size_t off_tab = off_gstat + (size_t)GMAX * 3 * 8;             // N, pmin, pmax per group (float64)
     static constexpr size_t off_red = off_tab + (size_t)2 * QMAX * 4 + 32;          // nodes, 1-D table, its metadata
     static constexpr size_t lds_bytes = off_red + 64 * 8;
 };
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0);
     uint16_t *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
     const uint16_t *rank = reinterpret_cast<const uint16_t *>(smem + Cfg::off_rank);
-    uint16_t *gstat = reinterpret_cast<uint16_t *>(smem + QC::off_gstat);
+    double *gstat = reinterpret_cast<double *>(smem + QC::off_gstat);  // per group: N, pmin, pmax of the percent-rank rescaling
     float *qn = reinterpret_cast<float *>(smem + QC::off_tab);  // quantile nodes (grouped) / compacted nodes (1-D)
     float *ty = qn + QC::QMAX;                                  // compacted factors of the 1-D table
     int *tmeta = reinterpret_cast<int *>(ty + QC::QMAX);        // [0] pairs, [1] yfirst, [2] ylast (bit patterns), [3] bad nodes
@@ -82,6 +82,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         auto run_end = [&](float v, int lo, int hi) {
             while (lo < hi) { int mid = (lo + hi) >> 1; if (val(mid) > v) hi = mid; else lo = mid + 1; }
             return lo;
+        };
+        // extreme percent ranks of a group (utils.rank :631-635: mn / mx of rank / N with average ties), once per group
+        auto put_stats = [&](int g, int n, int nmin, int nmax) {
+            const double N = (double)n;
+            gstat[3 * g] = N;
+            gstat[3 * g + 1] = (((double)nmin + 1.0) / 2.0) / N;
+            gstat[3 * g + 2] = ((N - (double)nmax) + ((double)nmax + 1.0) / 2.0) / N;
         };
         for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
@@ -115,9 +122,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 r2buf[sorted[r]] = (uint16_t)(rs + re + 1);
             }
             if (tid == 0 && nvalid) {
-                gstat[0] = (uint16_t)nvalid;
-                gstat[1] = (uint16_t)run_end(val(0), 1, nvalid);
-                gstat[2] = (uint16_t)(nvalid - run_begin(val(nvalid - 1), 0, nvalid - 1));
+                put_stats(0, nvalid, run_end(val(0), 1, nvalid), nvalid - run_begin(val(nvalid - 1), 0, nvalid - 1));
             }
         } else if (nvalid) {
             // ---------------- C. membership bit-vectors of the ranking rows in rank space ----------------
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     if (e0 < nvalid && val(e0) == v0) e0 = run_end(v0, e0 + 1, nvalid);
                     if (s1 > 0 && val(s1 - 1) == v1) s1 = run_begin(v1, 0, s1 - 1);
                     const int nmin = below(e0), nmax = n - below(s1);
-                    if (lane == 0) { gstat[3 * g] = (uint16_t)n; gstat[3 * g + 1] = (uint16_t)nmin; gstat[3 * g + 2] = (uint16_t)nmax; }
+                    if (lane == 0) put_stats(g, n, nmin, nmax);
                 }
                 // average-tie ranks of the elements this row ranks (the exact group)
                 const int *ml = mem_idx + mem_ptr[g];
@@ -227,11 +232,9 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             const float v = from_key(keys[t]);
             double sq = __builtin_nan("");
             if (r2 && g >= 0) {
-                const double N = (double)gstat[3 * g], nmin = (double)gstat[3 * g + 1], nmax = (double)gstat[3 * g + 2];
+                const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
                 const double r = (double)r2 / 2.0;
                 const double pr = r / N;
-                const double pmin = ((nmin + 1.0) / 2.0) / N;
-                const double pmax = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
                 sq = pmax * (pr - pmin) / (pmax - pmin);
             }
             if (sim_q) sim_q[(size_t)c * T + t] = sq;
