@@ -444,6 +444,26 @@ def test_loci_vs_oracle(hip, gname, dtype):
     assert (got[np.isfinite(got)] >= 0).all()
 
 
+@pytest.mark.parametrize("T", [3650, 14000])
+def test_dqm_train_huge_dynamic_range(hip, T):
+    """DQM group means come from running sums in the per-cell kernels; with 1e-20 "numerical drizzle" in one season and
+    1e2 storms in another the running sums would keep nothing of the drizzle: such cells must be redone with fresh sums"""
+    rng = np.random.default_rng(12)
+    C = 3
+    gidx, G, W = GROUPINGS["doy31"](T)
+    doy = gidx.astype(np.float64)
+    wet = (np.cos(2 * np.pi * doy / 365) > 0)[None, :]
+    mk = lambda: np.where(wet, rng.gamma(2.0, 40.0, (C, T)), 1e-20 * (1 + rng.random((C, T)))).astype(np.float32)  # noqa: E731
+    ref, hist = mk(), mk()
+    hist[1] = rng.gamma(2.0, 4.0, T)  # an ordinary cell stays on the fast path
+    q = _nodes(12)
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "*")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, "*")
+    assert_close(sc, esc, rtol=5e-7, what="scaling")
+    assert_close(hq, ehq, rtol=5e-7, what="hist_q")
+    assert_close(af, eaf, rtol=2e-6, what="af")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

@@ -320,7 +320,7 @@ __device__ __forceinline__ void cell_group_quantiles(
         lds_wave_fence();
         const uint32_t *bits_h = half ? bitsB : bitsA;
         double gsumA = 0.0, gsumB = 0.0;
-        double amax = 0.0;  // float64 DQM: largest magnitude that went through the running sums of this wave
+        double amax = 0.0;  // DQM: largest magnitude that went through the running sums of this wave
         // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select.
         // "list r" is the symmetric difference of rows r-1 and r: row r of the padded [G][64] table tog64 (when every
         // list has <= 64 entries, e.g. doy windows: one independent vector load, no pointer chase through SMEM), else
@@ -352,7 +352,7 @@ __device__ __forceinline__ void cell_group_quantiles(
                         uint32_t old = atomicXor(&bits[r >> 5], m);
                         R v = vals.at_time(t);
                         dloc += (old & m) ? -(double)v : (double)v;
-                        if constexpr (sizeof(R) == 8) amax = fmax(amax, fabs((double)v));
+                        amax = fmax(amax, fabs((double)v));
                     } else {
                         (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -420,15 +420,15 @@ __device__ __forceinline__ void cell_group_quantiles(
                 mu = n ? (R)(gs / (double)n) : nan_of<R>();
                 inv = invert<R>(mu, kind);
                 if (vh && n && (!isfinite(mu) || (kind == '*' && !(inv > (R)0 && isfinite(inv))))) flag_cell = true;
-                if constexpr (sizeof(R) == 8) {
-                    // float64 series: the running sums carry a rounding error of about eps * |largest value seen| per
-                    // toggle.  Keep them only while that stays below ~1e-12 of the group sum; otherwise (huge dynamic
-                    // range, or a group mean next to zero) the generic kernel redoes the cell with fresh sums.
-                    double am = amax;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) am = fmax(am, __shfl_xor(am, o, 64));
-                    amax = am;
-                    if (vh && n && !(am <= 200.0 * fabs(gs))) flag_cell = true;
+                {
+                    // The running float64 sums carry a rounding error of about eps * |largest value seen| per toggle.
+                    // Keep them only while that stays below ~1e-12 (float64 series) / ~5e-9 (float32 series) of the
+                    // group sums; otherwise (huge dynamic range, e.g. 1e-20 drizzle next to 1e2 storms, or a group mean
+                    // next to zero) the generic kernel redoes the cell with fresh sums.  Every lane tests the values IT
+                    // pushed through the sums against both streams' sums; the cell flag ORs the lanes.
+                    constexpr double LIM = sizeof(R) == 8 ? 200.0 : 1.0e6;
+                    const double gmin = fmin((vA && nA) ? fabs(gsumA) : __builtin_inf(), (vB && nB) ? fabs(gsumB) : __builtin_inf());
+                    if (!(amax <= LIM * gmin)) flag_cell = true;
                 }
             }
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
