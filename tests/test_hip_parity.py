@@ -464,6 +464,20 @@ def test_dqm_train_huge_dynamic_range(hip, T):
     assert_close(af, eaf, rtol=2e-6, what="af")
 
 
+def test_polydetrend_huge_dynamic_range(hip):
+    """the sliding window sums of the trend kernel are rebuilt when a huge value has just left the window"""
+    rng = np.random.default_rng(13)
+    T, C = 3650, 3
+    gidx, G, W = GROUPINGS["doy31"](T)
+    x = (1e-20 * (1 + rng.random((C, T)))).astype(np.float32)
+    x[:, ::97] = 250.0
+    x[1] = 280 + rng.standard_normal(T)
+    tnum = (np.arange(T, dtype=np.float64) + 12000.0) * 86400e9
+    tr = hip.polydetrend_trend(x, gidx, G, W, tnum, 1)
+    etr = oracle.polydetrend_trend(x, gidx, G, W, tnum, 1)
+    assert_close(tr, etr, rtol=2e-6, atol=1e-24, what="trend")
+
+
 def test_polydetrend_ramp(hip):
     # reference tests/test_detrending.py:18-30: detrending a ramp leaves ~0 and retrending restores it
     T = int(20 * 365.25)

@@ -351,16 +351,22 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         }
         return (R)mv;
     };
-    auto slide = [&](int64_t t, bool first, double &s, int &n) {
+    // `big`: the largest magnitude that went through the running sum since it was last built from scratch.  The sum
+    // carries a rounding error of about eps * big, so once big exceeds 1e6 * |s| (huge dynamic range: 1e-20 drizzle
+    // right after a 1e2 storm left the window) the window is summed afresh.
+    auto slide = [&](int64_t t, bool first, double &s, int &n, double &big) {
+        if (!first) {
+            int64_t tin = t + W - 1 - h, tout = t - 1 - h;
+            if (tin < T) { R v = xs[tin]; if (v == v) { s += (double)v; n++; big = fmax(big, fabs((double)v)); } }
+            if (tout >= 0) { R v = xs[tout]; if (v == v) { s -= (double)v; n--; big = fmax(big, fabs((double)v)); } }
+            first = big > 1.0e6 * fabs(s);
+        }
         if (first) {
+            s = 0; n = 0; big = 0;
             for (int j = 0; j < W; j++) {
                 int64_t tt = t + j - h;
                 if (tt >= 0 && tt < T) { R v = xs[tt]; if (v == v) { s += (double)v; n++; } }
             }
-        } else {
-            int64_t tin = t + W - 1 - h, tout = t - 1 - h;
-            if (tin < T) { R v = xs[tin]; if (v == v) { s += (double)v; n++; } }
-            if (tout >= 0) { R v = xs[tout]; if (v == v) { s -= (double)v; n--; } }
         }
     };
     if (W == 1) {
@@ -368,11 +374,11 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     } else if (inplace) {
         const int64_t t0 = (int64_t)threadIdx.x * CH;
         R mreg[CH];
-        double s = 0; int n = 0;
+        double s = 0, big = 0; int n = 0;
 #pragma unroll
         for (int k = 0; k < CH; k++) {
             mreg[k] = nan_of<R>();
-            if (t0 + k < T) { slide(t0 + k, k == 0, s, n); mreg[k] = mean_of(s, n); }
+            if (t0 + k < T) { slide(t0 + k, k == 0, s, n, big); mreg[k] = mean_of(s, n); }
         }
         __syncthreads();  // every window has been read: the series can be overwritten by its window means
 #pragma unroll
@@ -381,8 +387,8 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     } else {
         const int64_t chunk = (T + blockDim.x - 1) / blockDim.x;
         const int64_t t0 = (int64_t)threadIdx.x * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-        double s = 0; int n = 0;
-        for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n); m[t] = mean_of(s, n); }
+        double s = 0, big = 0; int n = 0;
+        for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n, big); m[t] = mean_of(s, n); }
     }
     __syncthreads();
     // per-group least squares.  Many short groups (day-of-year: 365 groups of ~30 members): one LANE per group, a
