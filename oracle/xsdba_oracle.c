@@ -14,6 +14,12 @@
  * Not restated (returns -3): grouped interp="linear"/"cubic", which the reference routes through
  * scipy.griddata's Qhull triangulation (utils.py:391-396).
  *
+ * Rows added for SURVEY §8f (end of this file): tail_mask, jitter, adapt_freq, group_means / scaling_adjust, loci_train /
+ * loci_adjust.  Their reference bodies are xarray orchestration (and unseeded random draws for jitter / adapt_freq) that
+ * cannot be executed in the build container, so there are no reference-generated vectors for them: PARITY UNPINNED by
+ * golden vectors; they are held to the assertions of the reference's own tests instead (tests/test_oracle_golden.py,
+ * tests/test_processing_gpu.py, tests/test_api_gpu.py cite them).
+ *
  * Conventions shared with include/xsdba_hip.h: series are addressed as x[c*stride_c + t*stride_t]
  * (element strides); tables are [cell][group][quantile] contiguous; group_of_time[t] in [0,G) is the
  * 0-based group of the window CENTRE (coordinate g+1), -1 = no group; dtype 0 = float32, 1 = float64;
