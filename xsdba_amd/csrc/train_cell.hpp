@@ -321,6 +321,16 @@ __device__ __forceinline__ void cell_group_quantiles(
         const uint32_t *bits_h = half ? bitsB : bitsA;
         double gsumA = 0.0, gsumB = 0.0;
         double amax = 0.0;  // DQM: largest magnitude that went through the running sums of this wave
+        if (DQM && kind == '+' && wid == 0 && lane == 0 && nvalid > 1) {
+            // additive kind: the running sums leave an absolute error of ~2e-16 * (largest |value|) on a group mean.
+            // Harmless unless the series holds wild outliers (unmasked fill values, 1e300 ...): compare the extremes
+            // with the interquartile range of the series, both read off the sorted order, once per array.
+            R lo, hi, q1, q3;
+            vals.at_ranks(0, nvalid - 1, lo, hi);
+            vals.at_ranks(nvalid / 4, (3 * nvalid) / 4, q1, q3);
+            constexpr double LIM_ADD = sizeof(R) == 8 ? 1.0e4 : 1.0e8;
+            if (!(fmax(fabs((double)lo), fabs((double)hi)) <= LIM_ADD * ((double)q3 - (double)q1))) flag_cell = true;
+        }
         // software prefetch of the next toggle lists (first 64 entries each): L2 latency hides under the select.
         // "list r" is the symmetric difference of rows r-1 and r: row r of the padded [G][64] table tog64 (when every
         // list has <= 64 entries, e.g. doy windows: one independent vector load, no pointer chase through SMEM), else
@@ -425,10 +435,12 @@ __device__ __forceinline__ void cell_group_quantiles(
                     // Keep them only while that stays below ~1e-12 (float64 series) / ~5e-9 (float32 series) of the
                     // group sums; otherwise (huge dynamic range, e.g. 1e-20 drizzle next to 1e2 storms, or a group mean
                     // next to zero) the generic kernel redoes the cell with fresh sums.  Every lane tests the values IT
-                    // pushed through the sums against both streams' sums; the cell flag ORs the lanes.
+                    // pushed through the sums against both streams' sums; the cell flag ORs the lanes.  Only the
+                    // multiplicative kind divides by the mean; for the additive kind the absolute error of the mean,
+                    // ~1e-17 of the largest value, is far below the data's own resolution whatever the mean is.
                     constexpr double LIM = sizeof(R) == 8 ? 200.0 : 1.0e6;
                     const double gmin = fmin((vA && nA) ? fabs(gsumA) : __builtin_inf(), (vB && nB) ? fabs(gsumB) : __builtin_inf());
-                    if (!(amax <= LIM * gmin)) flag_cell = true;
+                    if (kind == '*' && !(amax <= LIM * gmin)) flag_cell = true;
                 }
             }
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
