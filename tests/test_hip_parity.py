@@ -257,6 +257,31 @@ def test_qdm_long_series_ties_and_gaps(hip, gname, T):
         assert_close(r, oracle.rank_groups(sim, gidx, G, W, True), rtol=0.0, what="rank_groups")
 
 
+@pytest.mark.parametrize("gname", ["time", "doy31", "month"])
+def test_qdm_float64(hip, gname):
+    """k_qdm_cell on float64 series (31-bit range keys: equality decided on the doubles): heavy ties incl. -0.0 == +0.0,
+    clusters of distinct doubles below the key resolution, NaNs; ranks and scen bit-exact vs the oracle"""
+    rng = np.random.default_rng(41)
+    T, C = 6000, 4
+    gidx, G, W = GROUPINGS[gname](T)
+    q = _nodes(15, np.float64)
+    kind = "*"
+    ref, hist, sim = (a.astype(np.float64) * (1 + 1e-9 * rng.random(a.shape)) for a in _synth(rng, C, T, kind, np.float32, nan_frac=0.02))
+    sim[0] = np.round(sim[0] / 4) * 4
+    sim[1, ::3] = 0.0
+    sim[1, 1::6] = -0.0
+    m = rng.random(T) < 0.4
+    sim[2, m] = 50.0 + 1e-13 * rng.permutation(m.sum())   # thousands of equal range keys, all values distinct
+    sim[2, ::11] = 50.0                                    # ... with exact ties in between
+    af, _ = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    for rank_window in (False, True):
+        scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind)
+        escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind)
+        assert_close(sim_q, esim_q, rtol=0.0, what=f"sim_q rw={rank_window}")
+        assert_close(scen, escen, rtol=0.0, what=f"scen rw={rank_window}")
+    assert scen.dtype == np.float64
+
+
 def test_qdm_nan_factors_fall_back(hip):
     """NaN factors break the own-row shortcut of k_qdm_cell: those cells are redone by the generic kernel (2-D nearest
     neighbour across group rows), the others keep the fast result"""

@@ -761,7 +761,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         return check_launch("k_qdm_adjust");
     };
     bool fast = false;
-    if constexpr (std::is_same<R, float>::value) {
+    {
         // sort-based kernel (qdm_cell.hpp): any grouping at O(T log T) per cell instead of O(T * row length)
         const char *force = getenv("XSDBA_HIP_QDM");  // "count" pins the generic kernel (A/B runs, tests)
         fast = pl->simple && T <= 11 * 1024 && T >= 64 && G <= xs::QdmCfg<11>::GMAX && (ranks_only || Q <= xs::QdmCfg<11>::QMAX) &&
@@ -780,13 +780,13 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
                 constexpr int EPT = decltype(cfg)::value;
                 const size_t lds = xs::QdmCfg<EPT>::lds_bytes;
                 int rc2;
-                if ((rc2 = set_lds(xs::k_qdm_cell<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds((xs::k_qdm_cell<EPT, R>), lds, ctx, "the per-cell sort"))) return rc2;
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
                 LaunchScope ls(ctx, "k_qdm_cell");
-                hipLaunchKernelGGL((xs::k_qdm_cell<EPT>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s.dev, T, C, s.sc,
-                                   (const float *)daf, (const float *)dqn, G, Q, pl->d_gidx, use_tog ? pl->d_row_ptr : pl->d_mem_ptr,
+                hipLaunchKernelGGL((xs::k_qdm_cell<EPT, R>), dim3(nblk), dim3(1024), lds, ctx->stream, (const R *)s.dev, T, C, s.sc,
+                                   (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, use_tog ? pl->d_row_ptr : pl->d_mem_ptr,
                                    use_tog ? pl->d_row_sorted : pl->d_mem_idx, pl->d_mem_ptr, pl->d_mem_idx, pl->d_tog_ptr,
-                                   pl->d_tog_idx, pl->d_tog64, use_tog, interp, extrap, (int)kind, (float *)o.kernel_dst,
+                                   pl->d_tog_idx, pl->d_tog64, use_tog, interp, extrap, (int)kind, (R *)o.kernel_dst,
                                    (double *)oq.kernel_dst, flag_count, flag_list);
                 return check_launch("k_qdm_cell");
             };

@@ -1,4 +1,4 @@
-// qdm_cell.hpp — fast QDM adjust / rank kernel: one 1024-thread workgroup per grid cell, float32.
+// qdm_cell.hpp — fast QDM adjust / rank kernel: one 1024-thread workgroup per grid cell, float32 and float64.
 //
 // k_qdm_adjust (kernels.hpp) ranks every element by counting over its ranking row: O(T * row length) per cell,
 // fine for exact day-of-year groups (30 members) and hopeless for coarse groups (group="time": T^2) or windowed
@@ -21,7 +21,7 @@
 // not NaN (any other row is >= 1 away, nodes of one row span <= 1).  Cells where that argument fails (a NaN
 // factor is met, NaN / too widely spread nodes) are appended to `flag_list` and redone by k_qdm_adjust.
 #pragma once
-#include "train_cell.hpp"
+#include "train_cell_f64.hpp"
 
 namespace xs {
 
@@ -33,19 +33,45 @@ template <int EPT> struct QdmCfg {
     static constexpr size_t sel_end = off_pw + (size_t)B::NWAVE * B::BITW * 2;
     static constexpr size_t off_gstat = ((B::sort_end > sel_end ? B::sort_end : sel_end) + 15) & ~(size_t)15;
     static constexpr size_t off_tab = off_gstat + (size_t)GMAX * 3 * 8;             // N, pmin, pmax per group (float64)
-    static constexpr size_t off_red = off_tab + (size_t)2 * QMAX * 4 + 32;          // nodes, 1-D table, its metadata
+    static constexpr size_t off_red = off_tab + (size_t)(2 * QMAX + 2) * 8 + 16;    // nodes, 1-D table, its metadata (float64-sized)
     static constexpr size_t lds_bytes = off_red + 64 * 8;
 };
 
-template <int EPT>
+// How the kernel sees the values of the cell's series after the sort.  float32: the order-preserving keys in LDS ARE the
+// values.  float64: the LDS keys are 31-bit range keys (train_cell_f64.hpp); equal keys do not imply equal values, so
+// equality is decided on the doubles (read from global memory / L2) whenever the keys are within one step of each other
+// (-0.0 and +0.0 are one key step apart but equal), and values are read from the series itself.
+template <typename R> struct QdmSeries;
+template <> struct QdmSeries<float> {
+    const float *x;
+    const uint32_t *keys;
+    const uint16_t *sorted;
+    __device__ __forceinline__ float at_time(int t) const { return from_key(keys[t]); }
+    __device__ __forceinline__ bool eq_ranks(int a, int b) const { return from_key(keys[sorted[a]]) == from_key(keys[sorted[b]]); }
+};
+template <> struct QdmSeries<double> {
+    const double *x;
+    const uint32_t *keys;
+    const uint16_t *sorted;
+    __device__ __forceinline__ double at_time(int t) const { return x[t]; }
+    __device__ __forceinline__ bool eq_ranks(int a, int b) const
+    {
+        const int ta = sorted[a], tb = sorted[b];
+        const uint32_t ka = keys[ta], kb = keys[tb];
+        if (ka != kb && ka + 1u != kb && kb + 1u != ka) return false;
+        return x[ta] == x[tb];
+    }
+};
+
+template <int EPT, typename R = float>
 __global__ __launch_bounds__(1024) void k_qdm_cell(
-    const float *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const float *__restrict__ af,
-    const float *__restrict__ quantiles, int G, int Q, const int *__restrict__ gidx,
+    const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const R *__restrict__ af,
+    const R *__restrict__ quantiles, int G, int Q, const int *__restrict__ gidx,
     const int *__restrict__ grp_ptr, const int *__restrict__ grp_idx,  // ranking rows (windowed rows or exact groups)
     const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,  // exact groups: the elements each row ranks
     const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, const int *__restrict__ tog64,
     int use_tog,  // consecutive ranking rows differ by the toggle lists; 0: rows are the (disjoint) exact groups
-    int interp, int extrap, int kind, float *__restrict__ scen, double *__restrict__ sim_q,
+    int interp, int extrap, int kind, R *__restrict__ scen, double *__restrict__ sim_q,
     int *__restrict__ flag_count, int *__restrict__ flag_list)
 {
     using Cfg = CellCfg<EPT>;
@@ -57,9 +83,10 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     uint16_t *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
     const uint16_t *rank = reinterpret_cast<const uint16_t *>(smem + Cfg::off_rank);
     double *gstat = reinterpret_cast<double *>(smem + QC::off_gstat);  // per group: N, pmin, pmax of the percent-rank rescaling
-    float *qn = reinterpret_cast<float *>(smem + QC::off_tab);  // quantile nodes (grouped) / compacted nodes (1-D)
-    float *ty = qn + QC::QMAX;                                  // compacted factors of the 1-D table
-    int *tmeta = reinterpret_cast<int *>(ty + QC::QMAX);        // [0] pairs, [1] yfirst, [2] ylast (bit patterns), [3] bad nodes
+    R *qn = reinterpret_cast<R *>(smem + QC::off_tab);  // quantile nodes (grouped) / compacted nodes (1-D)
+    R *ty = qn + QC::QMAX;                              // compacted factors of the 1-D table
+    R *tyfl = ty + QC::QMAX;                            // [0] yfirst, [1] ylast of the 1-D table
+    int *tmeta = reinterpret_cast<int *>(tyfl + 2);     // [0] pairs, [3] bad nodes
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + QC::off_red);
 
     const int tid = threadIdx.x, wid = tid >> 6;
@@ -70,18 +97,28 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         int lane = tid & 63;  // opaque per cell: lane-derived addresses are recomputed, not spilled across the sort
         __asm__ volatile("" : "+v"(lane));
         int nvalid;
-        const uint16_t *sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid);
+        const uint16_t *sorted;
+        if constexpr (sizeof(R) == 8) sorted = cell_load_sort_f64<EPT>(sim + c * sc, T, smem, red, nvalid);
+        else sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid);
         uint16_t *r2buf = (sorted == idx1) ? idx0 : idx1;  // 2 * average rank per time step, 0 = no rank
-        auto val = [&](int r) { return from_key(keys[sorted[r]]); };
-        // first rank in [lo, hi] whose value is not below v (v occurs at hi)
-        auto run_begin = [&](float v, int lo, int hi) {
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (val(mid) < v) lo = mid + 1; else hi = mid; }
+        const QdmSeries<R> ser{sim + c * sc, keys, sorted};
+        // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):
+        // first rank in [0, r] whose value equals the one at r ...
+        auto run_begin = [&](int r) {
+            int lo = 0, hi = r;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (ser.eq_ranks(mid, r)) hi = mid; else lo = mid + 1; }
             return lo;
         };
-        // first rank in [lo, hi) whose value is above v, hi if none
-        auto run_end = [&](float v, int lo, int hi) {
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (val(mid) > v) hi = mid; else lo = mid + 1; }
+        // ... and first rank in (r, nvalid] whose value differs (nvalid if none)
+        auto run_end = [&](int r) {
+            int lo = r + 1, hi = nvalid;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (ser.eq_ranks(mid, r)) lo = mid + 1; else hi = mid; }
             return lo;
+        };
+        auto tie_run = [&](int r, int &rs, int &re) {
+            rs = r; re = r + 1;
+            if (r > 0 && ser.eq_ranks(r - 1, r)) rs = run_begin(r);
+            if (re < nvalid && ser.eq_ranks(re, r)) re = run_end(r);
         };
         // extreme percent ranks of a group (utils.rank :631-635: mn / mx of rank / N with average ties), once per group
         auto put_stats = [&](int g, int n, int nmin, int nmax) {
@@ -93,20 +130,20 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
         if (af && wid == 0) {
-            const float xq = lane < Q ? quantiles[lane] : __builtin_nanf("");
+            const R xq = lane < Q ? quantiles[lane] : nan_of<R>();
             if (G > 1) {
                 if (lane < Q) qn[lane] = xq;
                 const unsigned long long bad = __ballot(lane < Q && xq != xq);
-                const float xlo = __shfl(xq, 0, 64), xhi = __shfl(xq, Q - 1, 64);
-                if (lane == 0) tmeta[3] = (bad != 0ull) || !(xhi - xlo <= 1.0f);
+                const R xlo = __shfl(xq, 0, 64), xhi = __shfl(xq, Q - 1, 64);
+                if (lane == 0) tmeta[3] = (bad != 0ull) || !(xhi - xlo <= (R)1);
             } else {
-                const float yq = lane < Q ? af[(size_t)c * Q + lane] : __builtin_nanf("");
+                const R yq = lane < Q ? af[(size_t)c * Q + lane] : nan_of<R>();
                 const unsigned long long bx = __ballot(xq == xq), by = __ballot(yq == yq), bxy = bx & by;
                 const int pos = __popcll(bxy & ((1ull << lane) - 1ull));
                 if ((bxy >> lane) & 1ull) { qn[pos] = xq; ty[pos] = yq; }
-                const float yf = __shfl(yq, by ? __ffsll((long long)by) - 1 : 63, 64);
-                const float yl = __shfl(yq, by ? 63 - __clzll((long long)by) : 63, 64);
-                if (lane == 0) { tmeta[0] = __popcll(bxy); tmeta[1] = __float_as_int(yf); tmeta[2] = __float_as_int(yl); tmeta[3] = 0; }
+                const R yf = __shfl(yq, by ? __ffsll((long long)by) - 1 : 63, 64);
+                const R yl = __shfl(yq, by ? 63 - __clzll((long long)by) : 63, 64);
+                if (lane == 0) { tmeta[0] = __popcll(bxy); tyfl[0] = yf; tyfl[1] = yl; tmeta[3] = 0; }
             }
         }
         __syncthreads();
@@ -115,14 +152,12 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         if (all_time) {
             // ---------------- C0. one group holding every time step: the sorted order is the ranking ----------------
             for (int r = tid; r < nvalid; r += NT) {
-                const float v = val(r);
-                int rs = r, re = r + 1;
-                if (r > 0 && val(r - 1) == v) rs = run_begin(v, 0, r - 1);
-                if (re < nvalid && val(re) == v) re = run_end(v, re + 1, nvalid);
+                int rs, re;
+                tie_run(r, rs, re);
                 r2buf[sorted[r]] = (uint16_t)(rs + re + 1);
             }
             if (tid == 0 && nvalid) {
-                put_stats(0, nvalid, run_end(val(0), 1, nvalid), nvalid - run_begin(val(nvalid - 1), 0, nvalid - 1));
+                put_stats(0, nvalid, run_end(0), nvalid - run_begin(nvalid - 1));
             }
         } else if (nvalid) {
             // ---------------- C. membership bit-vectors of the ranking rows in rank space ----------------
@@ -193,10 +228,9 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     const unsigned long long bm = __ballot(cl > 0);
                     const int p0 = __shfl(myfirst, __ffsll((long long)bm) - 1, 64);
                     const int p1 = __shfl(mylast, 63 - __clzll((long long)bm), 64);
-                    const float v0 = val(p0), v1 = val(p1);
                     int e0 = p0 + 1, s1 = p1;
-                    if (e0 < nvalid && val(e0) == v0) e0 = run_end(v0, e0 + 1, nvalid);
-                    if (s1 > 0 && val(s1 - 1) == v1) s1 = run_begin(v1, 0, s1 - 1);
+                    if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
+                    if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
                     const int nmin = below(e0), nmax = n - below(s1);
                     if (lane == 0) put_stats(g, n, nmin, nmax);
                 }
@@ -208,10 +242,8 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     const int t = i < mlen ? ml[i] : -1;
                     const int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
                     if (r < nvalid) {
-                        const float v = from_key(keys[t]);
-                        int rs = r, re = r + 1;
-                        if (r > 0 && val(r - 1) == v) rs = run_begin(v, 0, r - 1);
-                        if (re < nvalid && val(re) == v) re = run_end(v, re + 1, nvalid);
+                        int rs, re;
+                        tie_run(r, rs, re);
                         r2buf[t] = (uint16_t)(below(rs) + below(re) + 1);
                     }
                 }
@@ -223,13 +255,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         // ---------------- D. percent ranks, interpolation on the quantile axis, apply (coalesced) ----------------
         bool flag_cell = false;
         const int tab_n = tmeta[0];
-        const float tab_yf = __int_as_float(tmeta[1]), tab_yl = __int_as_float(tmeta[2]);
+        const R tab_yf = tyfl[0], tab_yl = tyfl[1];
         const bool bad_nodes = af && G > 1 && tmeta[3];
-        const float *afc = af ? af + (size_t)c * G * Q : nullptr;
+        const R *afc = af ? af + (size_t)c * G * Q : nullptr;
         for (int t = tid; t < (int)T; t += NT) {
             const int g = gidx ? gidx[t] : 0;
             const int r2 = r2buf[t];
-            const float v = from_key(keys[t]);
+            const R v = ser.at_time(t);
             double sq = __builtin_nan("");
             if (r2 && g >= 0) {
                 const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
@@ -239,23 +271,23 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             }
             if (sim_q) sim_q[(size_t)c * T + t] = sq;
             if (af) {
-                float a;
+                R a;
                 if (G == 1) {
                     int nd_unused;
-                    a = interp1d_eval<float>(sq, true, qn, ty, tab_n, tab_yf, tab_yl, interp, extrap, nd_unused);
-                } else if (g < 0 || sq != sq) a = __builtin_nanf("");
+                    a = interp1d_eval<R>(sq, true, qn, ty, tab_n, tab_yf, tab_yl, interp, extrap, nd_unused);
+                } else if (g < 0 || sq != sq) a = nan_of<R>();
                 else {
-                    const float *row = afc + (size_t)g * Q;
-                    if (sq < (double)qn[0]) { a = row[0]; flag_cell |= a != a; if (extrap != 0) a = __builtin_nanf(""); }
-                    else if (sq > (double)qn[Q - 1]) { a = row[Q - 1]; flag_cell |= a != a; if (extrap != 0) a = __builtin_nanf(""); }
+                    const R *row = afc + (size_t)g * Q;
+                    if (sq < (double)qn[0]) { a = row[0]; flag_cell |= a != a; if (extrap != 0) a = nan_of<R>(); }
+                    else if (sq > (double)qn[Q - 1]) { a = row[Q - 1]; flag_cell |= a != a; if (extrap != 0) a = nan_of<R>(); }
                     else {
                         int w;
-                        (void)row_nearest<float, double>(sq, qn, Q, &w);
+                        (void)row_nearest<R, double>(sq, qn, Q, &w);
                         a = row[w];
                         flag_cell |= a != a;
                     }
                 }
-                scen[(size_t)c * T + t] = apply_corr<float>(v, a, kind);
+                scen[(size_t)c * T + t] = apply_corr<R>(v, a, kind);
             }
         }
         // cells whose own-row shortcut does not hold are queued for the generic kernel
