@@ -181,7 +181,7 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
     hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
     scaling = _table(scaling, s.dtype, (s.C, G))
     g = _gidx(gidx, s.T, G)
-    tn = np.ascontiguousarray(time_num, np.float64)
+    tn = time_num if isinstance(time_num, DeviceArray) else np.ascontiguousarray(time_num, np.float64)
     scen = out[0] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
     trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_dqm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),

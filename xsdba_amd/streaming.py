@@ -96,6 +96,8 @@ def train_adjust_streamed(method, ref, hist, sim, gidx, G, W, q, kind="+", *, bl
     d_hq = [c_k.empty((B, G, Q), f32) for _ in range(NS)]
     d_sc = [c_k.empty((B, G), f32) for _ in range(NS)] if method == "dqm" else None
     d_tr = [c_k.empty((B, T), f32) for _ in range(NS)] if method == "dqm" else None
+    if method == "dqm":  # resident once: a host array would make every block's call wait for its own upload
+        time_num = c_k.to_device(np.ascontiguousarray(time_num, np.float64))
     # event slots (per context): s = buffer set; "in": s -> block uploaded; "k": s -> block computed; "out": s -> read back
     pinned = [ref, hist, sim, scen] + ([af_h, hq_h] if keep_tables else [])
     t0 = time.perf_counter()
