@@ -203,8 +203,12 @@ int xsdba_hip_group_means(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t 
                           void *out /* [cell][group] */);
 int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
                              int64_t stride_t, int64_t stride_c, const void *af /* [cell][group] */,
-                             const int32_t *group_of_time, int32_t n_groups, char kind, void *scen,
-                             int64_t out_stride_t, int64_t out_stride_c);
+                             const int32_t *group_of_time, int32_t n_groups, const int32_t *group_hi, const double *frac,
+                             char kind, void *scen, int64_t out_stride_t, int64_t out_stride_c);
+/* group_hi / frac (both NULL: nearest-group broadcast): utils.broadcast with interp="linear" (utils.py:222-246).  The
+ * caller passes, per time step, the lower neighbour in group_of_time, the upper one in group_hi (cyclic, 0-based) and
+ * frac = the fractional group index of Grouper.get_index(interp=True) minus the lower node (base.py:308-320); the factor is
+ * (y_hi - y_lo) * frac + y_lo as scipy's interp1d evaluates it, applied in float64 and rounded once. */
 
 /* ---- f3: LOCI (adjustment.py:933-1009, _adjustment.py:889-939).  loci_train: per (cell, group) block (dims
  * [time, window] pooled) hist_thresh = the value of hist with the same CDF as thresh in ref (utils.map_cdf :40-84:
@@ -216,7 +220,8 @@ int xsdba_hip_loci_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, 
                          int32_t window, double thresh, void *af /* [cell][group] */, void *hist_thresh /* [cell][group] */);
 int xsdba_hip_loci_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
                           int64_t stride_c, const void *af, const void *hist_thresh, const int32_t *group_of_time,
-                          int32_t n_groups, double thresh, void *scen, int64_t out_stride_t, int64_t out_stride_c);
+                          int32_t n_groups, const int32_t *group_hi, const double *frac, double thresh, void *scen,
+                          int64_t out_stride_t, int64_t out_stride_c);
 
 /* ---- a16: PolyDetrend(degree).fit(x).ds.trend (detrending.py:59-88, 165-208) */
 int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,

@@ -228,15 +228,22 @@ def group_means(x, gidx, G, W):
     return out
 
 
-def scaling_adjust(sim, af, gidx, kind="+"):
+def _lin(g_hi, frac):
+    if g_hi is None:
+        return None, None
+    return np.ascontiguousarray(g_hi, np.int32), np.ascontiguousarray(frac, np.float64)
+
+
+def scaling_adjust(sim, af, gidx, kind="+", g_hi=None, frac=None):
     sim = np.ascontiguousarray(sim)
     Cn, T = sim.shape
     af = np.ascontiguousarray(af, sim.dtype)
     G = af.shape[1]
     gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
+    g_hi, frac = _lin(g_hi, frac)
     out = np.empty_like(sim)
     _check(lib().xsdba_oracle_scaling_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(af), _p(gidx), C.c_int(G),
-                                             C.c_char(kind.encode()), _p(out), _i64(1), _i64(T)), "scaling_adjust")
+                                             _p(g_hi), _p(frac), C.c_char(kind.encode()), _p(out), _i64(1), _i64(T)), "scaling_adjust")
     return out
 
 
@@ -252,15 +259,16 @@ def loci_train(ref, hist, gidx, G, W, thresh):
     return af, sth
 
 
-def loci_adjust(sim, af, hist_thresh, gidx, thresh):
+def loci_adjust(sim, af, hist_thresh, gidx, thresh, g_hi=None, frac=None):
     sim = np.ascontiguousarray(sim)
     Cn, T = sim.shape
     af, sth = np.ascontiguousarray(af, sim.dtype), np.ascontiguousarray(hist_thresh, sim.dtype)
     G = af.shape[1]
     gidx = np.ascontiguousarray(gidx if gidx is not None else np.zeros(T, np.int32), np.int32)
     out = np.empty_like(sim)
+    g_hi, frac = _lin(g_hi, frac)
     _check(lib().xsdba_oracle_loci_adjust(_p(sim), _dt(sim), _i64(T), _i64(Cn), _i64(1), _i64(T), _p(af), _p(sth), _p(gidx), C.c_int(G),
-                                          C.c_double(float(thresh)), _p(out), _i64(1), _i64(T)), "loci_adjust")
+                                          _p(g_hi), _p(frac), C.c_double(float(thresh)), _p(out), _i64(1), _i64(T)), "loci_adjust")
     return out
 
 

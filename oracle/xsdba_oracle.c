@@ -516,18 +516,37 @@ API int xsdba_oracle_group_means(const void *x, int dtype, int64_t T, int64_t C,
     return 0;
 }
 
+/* utils.broadcast with interp="linear" (utils.py:222-246): the group table, cyclically extended (add_cyclic_bounds :284-314),
+ * is interpolated at the fractional group index of every time step by xarray interp -> scipy interp1d "linear":
+ * slope = (y_hi - y_lo) / (x_hi - x_lo) with y in the table dtype and unit node spacing, y = slope * (x - x_lo) + y_lo in
+ * float64.  lo / hi / frac come from the caller (0-based cyclic group indexes, frac = x - x_lo). */
+static double group_factor(const void *tab, int dtype, size_t row, int glo, const int32_t *ghi, const double *frac, int64_t t)
+{
+    if (dtype == 0) {
+        const float *f = (const float *)tab + row;
+        if (!frac) return (double)f[glo];
+        return (double)(float)(f[ghi[t]] - f[glo]) * frac[t] + (double)f[glo];
+    }
+    const double *f = (const double *)tab + row;
+    if (!frac) return f[glo];
+    return (f[ghi[t]] - f[glo]) * frac[t] + f[glo];
+}
+
 API int xsdba_oracle_scaling_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
-                                    const int32_t *gidx, int G, char kind, void *scen, int64_t ost, int64_t osc)
+                                    const int32_t *gidx, int G, const int32_t *ghi, const double *frac, char kind, void *scen,
+                                    int64_t ost, int64_t osc)
 {
     for (int64_t c = 0; c < C; c++)
         for (int64_t t = 0; t < T; t++) {
             int g = G > 1 ? gidx[t] : 0;
+            double a = g >= 0 ? group_factor(af, dtype, (size_t)c * G, g, ghi, frac, t) : NAN;
             if (dtype == 0) {
-                float v = ((const float *)sim)[c * sc + t * st], f = g >= 0 ? ((const float *)af)[(size_t)c * G + g] : NAN;
-                ((float *)scen)[c * osc + t * ost] = g < 0 ? NAN : (kind == '+' ? v + f : v * f);
+                float v = ((const float *)sim)[c * sc + t * st];
+                float y = g < 0 ? NAN : (!frac ? (kind == '+' ? v + (float)a : v * (float)a) : (float)(kind == '+' ? (double)v + a : (double)v * a));
+                ((float *)scen)[c * osc + t * ost] = y;
             } else {
-                double v = ((const double *)sim)[c * sc + t * st], f = g >= 0 ? ((const double *)af)[(size_t)c * G + g] : NAN;
-                ((double *)scen)[c * osc + t * ost] = g < 0 ? NAN : (kind == '+' ? v + f : v * f);
+                double v = ((const double *)sim)[c * sc + t * st];
+                ((double *)scen)[c * osc + t * ost] = g < 0 ? NAN : (kind == '+' ? v + a : v * a);
             }
         }
     return 0;
@@ -592,23 +611,29 @@ API int xsdba_oracle_loci_train(const void *ref, const void *hist, int dtype, in
 
 /* loci_adjust (_adjustment.py:922-939): scen = (factor * (sim - sth) + thresh).clip(min=0), nearest-group broadcast */
 API int xsdba_oracle_loci_adjust(const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
-                                 const void *hist_thresh, const int32_t *gidx, int G, double thresh, void *scen, int64_t ost,
-                                 int64_t osc)
+                                 const void *hist_thresh, const int32_t *gidx, int G, const int32_t *ghi, const double *frac,
+                                 double thresh, void *scen, int64_t ost, int64_t osc)
 {
     for (int64_t c = 0; c < C; c++)
         for (int64_t t = 0; t < T; t++) {
             int g = G > 1 ? gidx[t] : 0;
             if (dtype == 0) {
                 float y = NAN;
-                if (g >= 0) {
+                if (g >= 0 && !frac) {
                     y = ((const float *)af)[(size_t)c * G + g] * (((const float *)sim)[c * sc + t * st] - ((const float *)hist_thresh)[(size_t)c * G + g]) + (float)thresh;
                     if (y < 0.0f) y = 0.0f;
+                } else if (g >= 0) {
+                    double fa = group_factor(af, 0, (size_t)c * G, g, ghi, frac, t), th = group_factor(hist_thresh, 0, (size_t)c * G, g, ghi, frac, t);
+                    double yd = fa * ((double)((const float *)sim)[c * sc + t * st] - th) + thresh;
+                    if (yd < 0.0) yd = 0.0;
+                    y = (float)yd;
                 }
                 ((float *)scen)[c * osc + t * ost] = y;
             } else {
                 double y = NAN;
                 if (g >= 0) {
-                    y = ((const double *)af)[(size_t)c * G + g] * (((const double *)sim)[c * sc + t * st] - ((const double *)hist_thresh)[(size_t)c * G + g]) + thresh;
+                    double fa = group_factor(af, 1, (size_t)c * G, g, ghi, frac, t), th = group_factor(hist_thresh, 1, (size_t)c * G, g, ghi, frac, t);
+                    y = fa * (((const double *)sim)[c * sc + t * st] - th) + thresh;
                     if (y < 0.0) y = 0.0;
                 }
                 ((double *)scen)[c * osc + t * ost] = y;

@@ -94,9 +94,7 @@ class TestScaling:
         np.testing.assert_array_almost_equal(scaling.ds.af.values, 2)
         p = scaling.adjust(sim)
         np.testing.assert_array_almost_equal(p.values, ref.values)
-        with pytest.raises(ValueError) as err:
-            scaling.adjust(sim, interp="linear")
-        assert isinstance(err.value.__cause__, NotImplementedError)
+        np.testing.assert_array_equal(scaling.adjust(sim, interp="linear").values, p.values)  # one group: nothing to interpolate
 
     @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
     def test_mon_u(self, kind, units, random):
@@ -111,6 +109,18 @@ class TestScaling:
         p = scaling.adjust(sim)
         np.testing.assert_array_almost_equal(p.values, ref.values, 1)
         assert "Scaling(group=Grouper(name='time.month'), kind=" in scaling.ds.attrs["adj_params"]
+        # interp="linear": the factor of a day is interpolated between the two nearest month centres (cyclic); checked
+        # against a direct numpy evaluation of utils.broadcast's recipe (utils.py:222-246)
+        pl = scaling.adjust(sim, interp="linear")
+        af = scaling.ds.af.values.astype(np.float64)
+        ext = np.concatenate([af[-1:], af, af[:1]])  # coordinates 0 .. 13
+        i = xs.Grouper("time.month").get_index(sim, interp=True).values
+        fac = np.interp(i, np.arange(14), ext)
+        exp = sim.values + fac if kind == ADDITIVE else sim.values * fac
+        np.testing.assert_allclose(pl.values, exp, rtol=1e-12)
+        with pytest.raises(ValueError) as err:
+            scaling.adjust(sim, interp="cubic")
+        assert isinstance(err.value.__cause__, NotImplementedError)
 
 
 class TestQM:

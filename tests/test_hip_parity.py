@@ -403,6 +403,16 @@ def test_scaling_vs_oracle(hip, gname, dtype):
     for kind in "+*":
         got = hip.scaling_adjust(x, af, gidx if G > 1 else None, kind)
         assert_close(got, oracle.scaling_adjust(x, af, gidx if G > 1 else None, kind), rtol=0.0, what=f"scaling_adjust {kind}")
+    if G > 1:  # linear interpolation between neighbouring groups (utils.broadcast interp="linear")
+        g_hi = ((np.maximum(gidx, 0) + 1) % G).astype(np.int32)
+        frac = rng.random(T)
+        frac[::13] = 1.0
+        for kind in "+*":
+            got = hip.scaling_adjust(x, af, gidx, kind, g_hi=g_hi, frac=frac)
+            assert_close(got, oracle.scaling_adjust(x, af, gidx, kind, g_hi=g_hi, frac=frac), rtol=0.0, what=f"scaling linear {kind}")
+        sth = np.abs(rng.standard_normal((C, G))).astype(dtype)
+        got = hip.loci_adjust(np.abs(x), af, sth, gidx, 1.0, g_hi=g_hi, frac=frac)
+        assert_close(got, oracle.loci_adjust(np.abs(x), af, sth, gidx, 1.0, g_hi=g_hi, frac=frac), rtol=0.0, what="loci linear")
 
 
 @pytest.mark.parametrize("gname", ["doy31", "month", "time"])

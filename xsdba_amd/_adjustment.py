@@ -301,15 +301,34 @@ def scaling_train(ds, *, dim, kind) -> Dataset:
     return Dataset({"af": u.get_correction(mhist, mref, kind)})
 
 
+def _group_interp_nodes(group: Grouper, sim: DataArray, gidx, G: int, interp: str):
+    """What utils.broadcast (utils.py:222-246) needs per time step to interpolate a grouped table linearly: the lower and
+    upper neighbouring groups (0-based, cyclic: add_cyclic_bounds :284-314) and the fraction of the way between them, from
+    the fractional group index of Grouper.get_index(interp=True) (base.py:308-320).  scipy's interp1d brackets a point that
+    sits exactly on a node k with (k-1, k], hence ceil.  Returns (g_lo, g_hi, frac) or (gidx, None, None) for 'nearest' / one group."""
+    if interp == "nearest" or G == 1:
+        return gidx, None, None
+    if interp != "linear":
+        raise NotImplementedError(f"interp={interp!r} between group centres is not implemented on the HIP path ('nearest' or 'linear')")
+    i = np.asarray(group.get_index(sim, interp=True).values, np.float64)
+    c0 = 0 if group.prop == "season" else 1  # coordinate of the first group
+    hi = np.ceil(i)
+    lo = hi - 1
+    frac = i - lo
+    g_lo = np.mod(lo - c0, G).astype(np.int32)
+    g_hi = np.mod(hi - c0, G).astype(np.int32)
+    g_lo[gidx < 0] = -1
+    return g_lo, g_hi, frac
+
+
 @map_blocks(reduces=[Grouper.PROP], scen=[])
 def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
     """Scaling: adjust on one block (_adjustment.py:961-974); the factors are broadcast on the group of each time step
-    (utils.broadcast :180-248 with interp="nearest"; interpolation between group centres is not on the device)."""
-    if interp != "nearest":
-        raise NotImplementedError("scaling_adjust on the HIP path broadcasts the factors with interp='nearest' only")
+    (utils.broadcast :180-248), "nearest" or linearly interpolated between group centres."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
+    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
-    scen = hip.scaling_adjust(s2, af, gidx if G > 1 else None, kind)
+    scen = hip.scaling_adjust(s2, af, g_lo if G > 1 else None, kind, g_hi=g_hi, frac=frac)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
 
@@ -324,13 +343,11 @@ def loci_train(ds, *, group, thresh) -> Dataset:
 
 @map_blocks(reduces=[Grouper.PROP], scen=[])
 def loci_adjust(ds, *, group, thresh, interp) -> Dataset:
-    """LOCI: adjust on one block (_adjustment.py:922-939); factors and thresholds of the group of each time step
-    (interp="nearest"; the reference's default "linear" interpolates between group centres, which is not on the device —
-    for a single group both are the same)."""
+    """LOCI: adjust on one block (_adjustment.py:922-939); factors and thresholds of the group of each time step, "nearest"
+    or linearly interpolated between group centres (the reference's default)."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
-    if interp != "nearest" and G > 1:
-        raise NotImplementedError("loci_adjust on the HIP path broadcasts factors and thresholds with interp='nearest' only")
+    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
     sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
-    scen = hip.loci_adjust(s2, af, sth, gidx if G > 1 else None, thresh)
+    scen = hip.loci_adjust(s2, af, sth, g_lo if G > 1 else None, thresh, g_hi=g_hi, frac=frac)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()

@@ -968,17 +968,20 @@ int group_means_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, in
 
 template <typename R>
 int scaling_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
-                        const int32_t *gidx, int G, char kind, void *scen, int64_t ost, int64_t osc)
+                        const int32_t *gidx, int G, const int32_t *ghi, const double *frac, char kind, void *scen, int64_t ost,
+                        int64_t osc)
 {
     if (C <= 0 || !af || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((ghi == nullptr) != (frac == nullptr)) return fail(XSDBA_E_ARG, "group_hi and frac go together");
     if (T > (1ll << 30)) return fail(XSDBA_E_ARG, "series too long");
     int rc;
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
     SeriesIn s;
     if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
-    const void *daf;
+    const void *daf, *dhi = nullptr, *dfr = nullptr;
     if ((rc = stage_in(ctx, S_TAB0, af, (size_t)C * G * sizeof(R), &daf))) return rc;
+    if (frac && ((rc = stage_in(ctx, S_TAB1, ghi, (size_t)T * sizeof(int32_t), &dhi)) || (rc = stage_in(ctx, S_TAB2, frac, (size_t)T * sizeof(double), &dfr)))) return rc;
     SeriesOut o;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     {
@@ -987,7 +990,8 @@ int scaling_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t 
         for (int64_t c0 = 0; c0 < C; c0 += 65535) {
             const int64_t nc = std::min<int64_t>(65535, C - c0);
             hipLaunchKernelGGL(xs::k_scale_groups<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream, (const R *)s.dev + c0 * s.sc,
-                               T, s.sc, (const R *)daf + (size_t)c0 * G, G, pl->d_gidx, (int)kind, (R *)o.kernel_dst + c0 * T, T);
+                               T, s.sc, (const R *)daf + (size_t)c0 * G, G, pl->d_gidx, (const int *)dhi, (const double *)dfr, (int)kind,
+                               (R *)o.kernel_dst + c0 * T, T);
         }
         if ((rc = check_launch("k_scale_groups"))) return rc;
     }
@@ -1033,17 +1037,20 @@ int loci_train_impl(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int64
 
 template <typename R>
 int loci_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
-                     const void *hist_thresh, const int32_t *gidx, int G, double thresh, void *scen, int64_t ost, int64_t osc)
+                     const void *hist_thresh, const int32_t *gidx, int G, const int32_t *ghi, const double *frac, double thresh,
+                     void *scen, int64_t ost, int64_t osc)
 {
     if (C <= 0 || !af || !hist_thresh || !scen) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((ghi == nullptr) != (frac == nullptr)) return fail(XSDBA_E_ARG, "group_hi and frac go together");
     if (T > (1ll << 30)) return fail(XSDBA_E_ARG, "series too long");
     int rc;
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
     SeriesIn s;
     if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
-    const void *daf, *dth;
+    const void *daf, *dth, *dhi = nullptr, *dfr = nullptr;
     if ((rc = stage_in(ctx, S_TAB0, af, (size_t)C * G * sizeof(R), &daf)) || (rc = stage_in(ctx, S_TAB1, hist_thresh, (size_t)C * G * sizeof(R), &dth))) return rc;
+    if (frac && ((rc = stage_in(ctx, S_TAB2, ghi, (size_t)T * sizeof(int32_t), &dhi)) || (rc = stage_in(ctx, S_MISC, frac, (size_t)T * sizeof(double), &dfr)))) return rc;
     SeriesOut o;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     {
@@ -1052,13 +1059,13 @@ int loci_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, 
         for (int64_t c0 = 0; c0 < C; c0 += 65535) {
             const int64_t nc = std::min<int64_t>(65535, C - c0);
             hipLaunchKernelGGL(xs::k_loci_adjust<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream, (const R *)s.dev + c0 * s.sc, T,
-                               s.sc, (const R *)daf + (size_t)c0 * G, (const R *)dth + (size_t)c0 * G, G, pl->d_gidx, (R)thresh,
-                               (R *)o.kernel_dst + c0 * T, T);
+                               s.sc, (const R *)daf + (size_t)c0 * G, (const R *)dth + (size_t)c0 * G, G, pl->d_gidx, (const int *)dhi,
+                               (const double *)dfr, thresh, (R *)o.kernel_dst + c0 * T, T);
         }
         if ((rc = check_launch("k_loci_adjust"))) return rc;
     }
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
-    return sync_if(ctx, o.copy_back || !is_device_ptr(sim));
+    return sync_if(ctx, o.copy_back || !is_device_ptr(sim) || frac != nullptr);
 }
 
 int check_ctx(xsdba_hip_ctx *ctx)
@@ -1410,12 +1417,13 @@ API int xsdba_hip_group_means(xsdba_hip_ctx *ctx, const void *x, int dtype, int6
 }
 
 API int xsdba_hip_scaling_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
-                                 const void *af, const int32_t *gidx, int32_t G, char kind, void *scen, int64_t ost, int64_t osc)
+                                 const void *af, const int32_t *gidx, int32_t G, const int32_t *ghi, const double *frac, char kind,
+                                 void *scen, int64_t ost, int64_t osc)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    return DISPATCH(dtype, (scaling_adjust_impl<float>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)),
-                    (scaling_adjust_impl<double>(ctx, sim, T, C, st, sc, af, gidx, G, kind, scen, ost, osc)));
+    return DISPATCH(dtype, (scaling_adjust_impl<float>(ctx, sim, T, C, st, sc, af, gidx, G, ghi, frac, kind, scen, ost, osc)),
+                    (scaling_adjust_impl<double>(ctx, sim, T, C, st, sc, af, gidx, G, ghi, frac, kind, scen, ost, osc)));
 }
 
 API int xsdba_hip_loci_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int dtype, int64_t T, int64_t C, int64_t st,
@@ -1428,13 +1436,13 @@ API int xsdba_hip_loci_train(xsdba_hip_ctx *ctx, const void *ref, const void *hi
 }
 
 API int xsdba_hip_loci_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
-                              const void *af, const void *hist_thresh, const int32_t *gidx, int32_t G, double thresh, void *scen,
-                              int64_t ost, int64_t osc)
+                              const void *af, const void *hist_thresh, const int32_t *gidx, int32_t G, const int32_t *ghi,
+                              const double *frac, double thresh, void *scen, int64_t ost, int64_t osc)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    return DISPATCH(dtype, (loci_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, thresh, scen, ost, osc)),
-                    (loci_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, thresh, scen, ost, osc)));
+    return DISPATCH(dtype, (loci_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, ghi, frac, thresh, scen, ost, osc)),
+                    (loci_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_thresh, gidx, G, ghi, frac, thresh, scen, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

@@ -244,16 +244,34 @@ __global__ void k_group_mean(const R *__restrict__ x, int64_t sc, const int *__r
     if (threadIdx.x == 0) out[(size_t)c * G + g] = n ? (R)(s / (double)n) : nan_of<R>();
 }
 
+// Factor of time step t: the value of its group (nearest), or — g_hi / frac given — the linear interpolation between two
+// neighbouring groups as xarray's DataArray.interp / scipy interp1d compute it on the cyclically extended table
+// (utils.broadcast :222-246, add_cyclic_bounds :284-314): slope = (y_hi - y_lo) in the table dtype, then
+// slope * frac + y_lo in float64 (the node spacing is 1).
+template <typename R>
+__device__ __forceinline__ double group_factor(const R *f, int g_lo, const int *g_hi, const double *frac, int t)
+{
+    if (!frac) return (double)f[g_lo];
+    const R lo = f[g_lo], hi = f[g_hi[t]];
+    return (double)(R)(hi - lo) * frac[t] + (double)lo;
+}
+
 template <typename R>
 __global__ void k_scale_groups(const R *__restrict__ sim, int64_t T, int64_t sc, const R *__restrict__ af, int G,
-                               const int *__restrict__ gidx, int kind, R *__restrict__ scen, int64_t osc)
+                               const int *__restrict__ gidx, const int *__restrict__ g_hi, const double *__restrict__ frac,
+                               int kind, R *__restrict__ scen, int64_t osc)
 {
     const int64_t c = blockIdx.y;
     const R *x = sim + c * sc, *f = af + (size_t)c * G;
     R *o = scen + c * osc;
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
         const int g = G > 1 ? gidx[t] : 0;
-        o[t] = g >= 0 ? apply_corr<R>(x[t], f[g], kind) : nan_of<R>();
+        R y = nan_of<R>();
+        if (g >= 0) {
+            if (!frac) y = apply_corr<R>(x[t], f[g], kind);
+            else { const double a = group_factor<R>(f, g, g_hi, frac, t); y = (R)(kind == '+' ? (double)x[t] + a : (double)x[t] * a); }
+        }
+        o[t] = y;
     }
 }
 
@@ -344,7 +362,8 @@ __global__ void k_loci_factor(const R *__restrict__ ref, const R *__restrict__ h
 
 template <typename R>
 __global__ void k_loci_adjust(const R *__restrict__ sim, int64_t T, int64_t sc, const R *__restrict__ af,
-                              const R *__restrict__ hist_thresh, int G, const int *__restrict__ gidx, R thresh,
+                              const R *__restrict__ hist_thresh, int G, const int *__restrict__ gidx,
+                              const int *__restrict__ g_hi, const double *__restrict__ frac, double thresh,
                               R *__restrict__ scen, int64_t osc)
 {
     const int64_t c = blockIdx.y;
@@ -353,7 +372,15 @@ __global__ void k_loci_adjust(const R *__restrict__ sim, int64_t T, int64_t sc, 
     for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < (int)T; t += gridDim.x * blockDim.x) {
         const int g = G > 1 ? gidx[t] : 0;
         R y = nan_of<R>();
-        if (g >= 0) { y = f[g] * (x[t] - h[g]) + thresh; if (y < (R)0) y = (R)0; }  // clip(min=0) keeps NaN
+        if (g >= 0) {
+            if (!frac) { y = f[g] * (x[t] - h[g]) + (R)thresh; if (y < (R)0) y = (R)0; }  // clip(min=0) keeps NaN
+            else {
+                const double fa = group_factor<R>(f, g, g_hi, frac, t), th = group_factor<R>(h, g, g_hi, frac, t);
+                double yd = fa * ((double)x[t] - th) + thresh;
+                if (yd < 0.0) yd = 0.0;
+                y = (R)yd;
+            }
+        }
         o[t] = y;
     }
 }

@@ -284,17 +284,28 @@ def group_means(x, gidx, G, W, ctx=None):
     return out
 
 
-def scaling_adjust(sim, af, gidx, kind="+", ctx=None):
-    """scaling_adjust (_adjustment.py:961-974) with the nearest-group broadcast -> scen [C, T]"""
+def _lin(g_hi, frac, T):
+    if g_hi is None and frac is None:
+        return None, None
+    g_hi, frac = np.ascontiguousarray(g_hi, np.int32), np.ascontiguousarray(frac, np.float64)
+    if g_hi.shape != (T,) or frac.shape != (T,):
+        raise ValueError("g_hi and frac must have one entry per time step")
+    return g_hi, frac
+
+
+def scaling_adjust(sim, af, gidx, kind="+", g_hi=None, frac=None, ctx=None):
+    """scaling_adjust (_adjustment.py:961-974) -> scen [C, T]; nearest-group factors, or (``g_hi``, ``frac`` given, ``gidx`` =
+    lower neighbour) their linear interpolation between neighbouring groups"""
     ctx = ctx or default_context()
     s = _Series(sim)
     G = af.shape[1]
     af = _table(af, s.dtype, (s.C, G))
     g = _gidx(gidx, s.T, G)
+    g_hi, frac = _lin(g_hi, frac, s.T)
     scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_scaling_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
-                                          _vp(af), _vp(g), C.c_int(G), C.c_char(kind.encode()), _vp(scen), _i64(1), _i64(s.T)),
-          "scaling_adjust")
+                                          _vp(af), _vp(g), C.c_int(G), _vp(g_hi), _vp(frac), C.c_char(kind.encode()), _vp(scen),
+                                          _i64(1), _i64(s.T)), "scaling_adjust")
     return scen
 
 
@@ -314,17 +325,18 @@ def loci_train(ref, hist, gidx, G, W, thresh, ctx=None):
     return af, sth
 
 
-def loci_adjust(sim, af, hist_thresh, gidx, thresh, ctx=None):
-    """loci_adjust (_adjustment.py:922-939) with the nearest-group broadcast -> scen [C, T]"""
+def loci_adjust(sim, af, hist_thresh, gidx, thresh, g_hi=None, frac=None, ctx=None):
+    """loci_adjust (_adjustment.py:922-939) -> scen [C, T]; nearest-group or linearly interpolated factors / thresholds"""
     ctx = ctx or default_context()
     s = _Series(sim)
     G = af.shape[1]
     af, sth = _table(af, s.dtype, (s.C, G)), _table(hist_thresh, s.dtype, (s.C, G))
     g = _gidx(gidx, s.T, G)
+    g_hi, frac = _lin(g_hi, frac, s.T)
     scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_loci_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
-                                       _vp(af), _vp(sth), _vp(g), C.c_int(G), C.c_double(float(thresh)), _vp(scen), _i64(1), _i64(s.T)),
-          "loci_adjust")
+                                       _vp(af), _vp(sth), _vp(g), C.c_int(G), _vp(g_hi), _vp(frac), C.c_double(float(thresh)),
+                                       _vp(scen), _i64(1), _i64(s.T)), "loci_adjust")
     return scen
 
 

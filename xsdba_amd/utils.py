@@ -139,15 +139,29 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
 
 @parse_group
 def broadcast(grouped, x, *, group: str | Grouper = "time", interp: str = "nearest", sel=None):
-    """Broadcast a grouped array back to the shape of `x` along time (utils.py:180-248), nearest selection."""
+    """Broadcast a grouped array back to the shape of `x` along time (utils.py:180-248): the value of each time step's
+    group ("nearest") or the linear interpolation between the two neighbouring group centres on the cyclically extended
+    table (a small host-side gather on the [.., group] table; the adjust kernels do the same on the device)."""
     grouped, x = as_dataarray(grouped), as_dataarray(x)
-    if interp != "nearest" and group.prop != "group":
-        raise NotImplementedError("broadcast(interp != 'nearest') is not implemented")
+    if interp not in ("nearest", "linear") and group.prop != "group":
+        raise NotImplementedError(f"broadcast(interp={interp!r}) is not implemented ('nearest' or 'linear')")
     if group.prop == "group":
         return grouped.squeeze("group") if "group" in grouped.dims else grouped
-    gidx, _ = group.group_index(x)
+    gidx, G = group.group_index(x)
     ax = grouped.dims.index(group.prop)
-    data = np.take(grouped.values, gidx, axis=ax)
+    if interp == "linear":
+        i = np.asarray(group.get_index(x, interp=True).values, np.float64)
+        c0 = 0 if group.prop == "season" else 1
+        hi = np.ceil(i)
+        lo = hi - 1
+        shape = [1] * grouped.values.ndim
+        shape[ax] = -1
+        frac = (i - lo).reshape(shape)
+        ylo = np.take(grouped.values, np.mod(lo - c0, G).astype(int), axis=ax)
+        yhi = np.take(grouped.values, np.mod(hi - c0, G).astype(int), axis=ax)
+        data = (yhi - ylo).astype(np.float64) * frac + ylo.astype(np.float64)  # scipy interp1d: slope * (x - x_lo) + y_lo
+    else:
+        data = np.take(grouped.values, gidx, axis=ax)
     dims = tuple(group.dim if d == group.prop else d for d in grouped.dims)
     coords = {k: c for k, c in grouped.coords.items() if k != group.prop}
     coords[group.dim] = x.coords[group.dim]
