@@ -920,16 +920,34 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;
     const size_t lds = red_b + std::max((size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t)));
     if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq row sort"))) return rc;
+    // [0] error flag of the pair sort, [1] length of the work list, [2...] the (cell, group) blocks with dP0 > 0
     void *flag;
-    if ((rc = ensure(ctx, S_FLAGS, sizeof(int), &flag))) return rc;
-    HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (ng + 2), &flag))) return rc;
+    HIP_TRY(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
+    int *n_work = (int *)flag + 1, *work_list = (int *)flag + 2;
+    // cheap screening pass per cell (prefix sums over time) when the four prefix arrays fit the LDS
+    const int snt = 512;
+    const size_t slds = (((size_t)8 * (size_t)(T + 1) + 15) & ~(size_t)15) + sizeof(int) * 2 * snt;
+    const bool screened = T < 65535 && slds <= (size_t)ctx->lds_limit;
+    if (screened) {
+        if ((rc = set_lds(xs::k_af_screen<R>, slds, ctx, "the adapt_freq prefix sums"))) return rc;
+        LaunchScope ls(ctx, "k_af_screen");
+        hipLaunchKernelGGL(xs::k_af_screen<R>, dim3((unsigned)std::min<int64_t>(C, 8 * ctx->n_cu)), dim3(snt), slds, ctx->stream,
+                           (const R *)s.dev, ref ? (const R *)r.dev : (const R *)nullptr, T, C, s.sc, ref ? r.sc : (int64_t)0,
+                           pl->d_mem_ptr, pl->d_mem_idx, G, W, thresh, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
+                           ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
+                           (double *)o3.dev, work_list, n_work);
+        if ((rc = check_launch("k_af_screen"))) return rc;
+    }
     {
         LaunchScope ls(ctx, "k_adapt_freq");
-        hipLaunchKernelGGL(xs::k_adapt_freq<R>, dim3((unsigned)ng), dim3(NT), lds, ctx->stream, (const R *)s.dev,
+        const unsigned grid = screened ? (unsigned)std::min<size_t>(ng, (size_t)32 * ctx->n_cu) : (unsigned)ng;
+        hipLaunchKernelGGL(xs::k_adapt_freq<R>, dim3(grid), dim3(NT), lds, ctx->stream, (const R *)s.dev,
                            ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
                            pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
                            ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
-                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, (int *)flag);
+                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, (int *)flag, screened ? work_list : (const int *)nullptr,
+                           screened ? n_work : (const int *)nullptr, (int64_t)ng);
         if ((rc = check_launch("k_adapt_freq"))) return rc;
     }
     int too_many = 0;

@@ -80,11 +80,11 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 // sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
 // ---------------------------------------------------------------------------------------------
 template <typename R>
-__global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
+__device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag)
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag, int64_t block_id)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -92,8 +92,8 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
     const int nw = (blockDim.x + 63) >> 6;
     U *keys = reinterpret_cast<U *>(red + 2 * nw + 2);
     uint32_t *tags = reinterpret_cast<uint32_t *>(keys + (P_max < P_sub_cap ? P_max : P_sub_cap));
-    const int64_t c = blockIdx.x / G;
-    const int g = blockIdx.x % G;
+    const int64_t c = block_id / G;
+    const int g = (int)(block_id % G);
     const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
     int P = 2;
     while (P < L) P <<= 1;
@@ -217,6 +217,96 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
     for (int p = threadIdx.x; p < n0; p += blockDim.x) {
         const int tt = row_idx[p0 + (int)(tags[p] & 0xFFFFu)];
         if (gidx[tt] == g) replace_if_in_band(p + 1, tt);  // only the block's centre elements reach the time series
+    }
+}
+
+
+// k_af_screen: the cheap first half of adapt_freq for a whole cell at once.  #valid and #(<= thresh) of every windowed
+// group block come from prefix sums over time (a block of group g is the union, with multiplicity, of the windows of g's
+// time steps: two prefix lookups per time step), i.e. O(T) per series instead of O(T * window).  Writes P0_sim -> P0_hist,
+// P0_ref, dP0 and pth = NaN (training), and queues the blocks with dP0 > 0 — the only ones k_adapt_freq has to sort.
+// Typical model precipitation has too FEW dry days (the drizzle effect): dP0 <= 0 almost everywhere and the queue is short.
+// dynamic LDS: [4 prefix arrays of (T + 1) u16: valid / below-threshold counts of sim and ref][NT + 1 ints]
+template <typename R>
+__global__ void k_af_screen(const R *__restrict__ sim, const R *__restrict__ ref, int64_t T, int64_t C, int64_t sc, int64_t rsc,
+                            const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx, int G, int W, double thresh, int train,
+                            double *__restrict__ P0_ref, double *__restrict__ P0_hist, R *__restrict__ pth,
+                            double *__restrict__ dP0_out, int *__restrict__ work_list, int *__restrict__ n_work)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int Ti = (int)T, NT = blockDim.x;
+    uint16_t *pv[2], *pl[2];
+    for (int a = 0; a < 2; a++) { pv[a] = reinterpret_cast<uint16_t *>(smem) + (size_t)(2 * a) * (Ti + 1); pl[a] = pv[a] + (Ti + 1); }
+    int *tot = reinterpret_cast<int *>(smem + (((size_t)8 * (Ti + 1) + 15) & ~(size_t)15));  // [2][NT] chunk totals
+    const int chunk = (Ti + NT - 1) / NT, t0 = min(Ti, (int)threadIdx.x * chunk), t1 = min(Ti, t0 + chunk);
+    const int h = W / 2;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        for (int a = 0; a < (train ? 2 : 1); a++) {
+            const R *x = (a ? ref + c * rsc : sim + c * sc);
+            int nv = 0, nl = 0;
+            for (int t = t0; t < t1; t++) { const R v = x[t]; if (v == v) { nv++; if ((double)v <= thresh) nl++; } }
+            tot[threadIdx.x] = nv; tot[NT + threadIdx.x] = nl;
+            __syncthreads();
+            if (threadIdx.x < 128) {  // exclusive scan of the chunk totals: wave 0 scans the valid counts, wave 1 the others
+                int *tt = tot + (threadIdx.x >> 6) * NT;
+                const int ln = threadIdx.x & 63, per = (NT + 63) / 64, i0 = ln * per, i1 = min(NT, i0 + per);
+                int run = 0;
+                for (int i = i0; i < i1; i++) run += tt[i];
+                int incl = run;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (ln >= o) incl += up; }
+                int pre = incl - run;
+                for (int i = i0; i < i1; i++) { const int v = tt[i]; tt[i] = pre; pre += v; }
+            }
+            __syncthreads();
+            nv = tot[threadIdx.x]; nl = tot[NT + threadIdx.x];
+            for (int t = t0; t < t1; t++) {
+                pv[a][t] = (uint16_t)nv; pl[a][t] = (uint16_t)nl;
+                const R v = x[t];
+                if (v == v) { nv++; if ((double)v <= thresh) nl++; }
+            }
+            if (t1 == Ti && t0 < Ti) { pv[a][Ti] = (uint16_t)nv; pl[a][Ti] = (uint16_t)nl; }
+            if (Ti == 0 && threadIdx.x == 0) { pv[a][0] = 0; pl[a][0] = 0; }
+            __syncthreads();
+        }
+        for (int g = threadIdx.x; g < G; g += NT) {
+            int64_t cnt[4] = {0, 0, 0, 0};  // sim valid, sim below, ref valid, ref below
+            for (int p = mem_ptr[g]; p < mem_ptr[g + 1]; p++) {
+                const int t = mem_idx[p];
+                const int lo = max(0, t - h), hi = min(Ti - 1, t - h + W - 1) + 1;
+                cnt[0] += pv[0][hi] - pv[0][lo]; cnt[1] += pl[0][hi] - pl[0][lo];
+                if (train) { cnt[2] += pv[1][hi] - pv[1][lo]; cnt[3] += pl[1][hi] - pl[1][lo]; }
+            }
+            const size_t og = (size_t)c * G + g;
+            const double P0_sim = cnt[0] ? (double)cnt[1] / (double)cnt[0] : __builtin_nan("");
+            double p0r, p0h;
+            if (train) {
+                p0r = cnt[2] ? (double)cnt[3] / (double)cnt[2] : __builtin_nan("");
+                p0h = P0_sim;
+                P0_ref[og] = p0r; P0_hist[og] = p0h; pth[og] = nan_of<R>();
+            } else { p0r = P0_ref[og]; p0h = P0_hist[og]; }
+            const double d = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
+            if (dP0_out) dP0_out[og] = d;
+            if (d > 0.0) work_list[atomicAdd(n_work, 1)] = (int)og;
+        }
+        __syncthreads();  // the prefix arrays are rebuilt for the next cell
+    }
+}
+
+template <typename R>
+__global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
+                             const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
+                             double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
+                             double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag,
+                             const int *__restrict__ work_list, const int *__restrict__ n_work, int64_t n_all)
+{
+    // work_list (from k_af_screen: the (cell, group) blocks with dP0 > 0, count read on the device) or every block
+    const int64_t n_items = work_list ? (int64_t)*n_work : n_all;
+    for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        adapt_freq_block<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
+                            sim_ad, osc, P_max, P_sub_cap, err_flag, work_list ? (int64_t)work_list[item] : item);
+        __syncthreads();  // the LDS is reused by the next block of work
     }
 }
 
