@@ -303,6 +303,115 @@ def test_max_tail_factor(random, cls, group):
     assert "max_tail_factor=10" in adj.ds.attrs["adj_params"]
 
 
+def _cannon_2015_rvs(n, random=True, rng=None):
+    """testing/helpers.py:23-35 (Cannon et al. 2015): ref ~ gamma(4, 7.5), hist ~ gamma(8.15, 3.68), sim ~ gamma(16, 2.63)"""
+    from scipy.stats import gamma
+
+    fd = (gamma(4, scale=7.5), gamma(8.15, scale=3.68), gamma(16, scale=2.63))
+    if random:
+        r = [d.rvs(n, random_state=rng) for d in fd]
+    else:
+        uu = u.equally_spaced_nodes(n, None)
+        r = [d.ppf(uu) for d in fd]
+    return [timelonlatseries(x, attrs={"units": "kg/m/m/s"}) for x in r]
+
+
+class TestMoreReferenceCases:
+    """the remaining cases of the reference's TestDQM / TestQDM / TestQM / TestBaseAdjustment that lie on this path"""
+
+    @pytest.mark.parametrize("kind,units", [(ADDITIVE, "K"), (MULTIPLICATIVE, "kg m-2 s-1")])
+    def test_dqm_mon_u(self, kind, units, random):
+        """tests/test_adjustment.py:386-432 (without add_dims): hist U, ref U + monthly cycle, a trend on sim"""
+        n = 5000
+        uu = random.random(n)
+        x = uniform(loc=2, scale=0.1).ppf(uu)
+        y = uniform(loc=4, scale=0.1).ppf(uu) + uniform(loc=0, scale=1e-7).ppf(uu)
+        attrs = {"units": units, "kind": kind}
+        hist, ref = timelonlatseries(x, attrs=attrs), mon_timelonlatseries(y, attrs=attrs)
+        trend = np.linspace(-0.2, 0.2, n) + int(kind == MULTIPLICATIVE)
+        ref_t = mon_timelonlatseries(apply_correction(y, trend, kind), attrs=attrs)
+        sim = timelonlatseries(apply_correction(x, trend, kind), attrs=attrs)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # DQM with a non-dayofyear grouping warns like the reference (adjustment.py:608-609)
+            DQM = xs.DetrendedQuantileMapping.train(ref, hist, kind=kind, group="time.month", nquantiles=5)
+            p = DQM.adjust(sim)
+        mqm = DQM.ds.af.values.mean(axis=-1)
+        np.testing.assert_array_almost_equal(mqm, int(kind == MULTIPLICATIVE), 1)
+        np.testing.assert_allclose(p.values, ref_t.values, rtol=0.1, atol=0.5)
+
+    def test_dqm_cannon_and_from_ds(self, random):
+        """tests/test_adjustment.py:434-452"""
+        ref, hist, sim = _cannon_2015_rvs(15000, rng=random)
+        dqm = xs.DetrendedQuantileMapping.train(ref, hist, kind="*", group="time")
+        p = dqm.adjust(sim)
+        np.testing.assert_almost_equal(p.values.mean(), 41.6, 0)
+        np.testing.assert_almost_equal(p.values.std(), 15.0, 0)
+        dqm2 = xs.DetrendedQuantileMapping.from_dataset(dqm.ds)
+        for name in dqm.ds.data_vars:
+            np.testing.assert_array_equal(dqm.ds[name].values, dqm2.ds[name].values)
+        np.testing.assert_array_equal(p.values, dqm2.adjust(sim).values)
+
+    def test_qdm_mon_u(self, random):
+        """tests/test_adjustment.py:749-802, the multiplicative branch (interp="nearest"; the additive one asks for the
+        grouped linear interpolation that goes through Qhull in the reference)"""
+        kind, units = MULTIPLICATIVE, "kg m-2 s-1"
+        uu = random.random(10000)
+        xd, yd = uniform(loc=1, scale=1), uniform(loc=2, scale=2)
+        x = xd.ppf(uu)
+        y = yd.ppf(uu) + uniform(loc=0, scale=1e-7).ppf(uu)
+        attrs = {"units": units, "kind": kind}
+        ref = mon_timelonlatseries(y, attrs=attrs)
+        hist = sim = timelonlatseries(x, attrs=attrs)
+        QDM = xs.QuantileDeltaMapping.train(ref, hist, kind=kind, group="time.month", nquantiles=40)
+        p = QDM.adjust(sim, interp="nearest")
+        q = QDM.ds.coords["quantiles"].values
+        expected = get_correction(xd.ppf(q), yd.ppf(q), kind)
+        expected = apply_correction(MON_TRI[:, np.newaxis], expected[np.newaxis, :], kind)
+        np.testing.assert_array_almost_equal(QDM.ds.af.values, expected, 1)
+        np.testing.assert_allclose(p.values, ref.values, rtol=0.1, atol=0.2)
+
+    def test_qdm_cannon_and_diagnostics(self):
+        """tests/test_adjustment.py:836-859"""
+        ref, hist, sim = _cannon_2015_rvs(15000, random=False)
+        with xs.set_options(extra_output=True):
+            QDM = xs.QuantileDeltaMapping.train(ref, hist, kind="*", group="time", nquantiles=50)
+            scends = QDM.adjust(sim)
+        assert isinstance(scends, xs.Dataset) and {"scen", "sim_q"} <= set(scends.data_vars)
+        np.testing.assert_almost_equal(scends["scen"].values.mean(), 41.5, 1)
+        np.testing.assert_almost_equal(scends["scen"].values.std(), 16.7, 0)
+
+    def test_eqm_different_times_training(self, random):
+        """tests/test_adjustment.py:1072-1083"""
+        n = 10
+        uu, u2 = random.random(n), random.random(n)
+        ref = timelonlatseries(uu, start="2000-01-01", attrs={"units": "K"})
+        hist = timelonlatseries(u2, start="2000-01-01", attrs={"units": "K"})
+        hist_fut = timelonlatseries(u2, start="2001-01-01", attrs={"units": "K"})
+        ds = xs.EmpiricalQuantileMapping.train(ref, hist).ds
+        with pytest.raises(ValueError):
+            xs.EmpiricalQuantileMapping.train(ref, hist_fut)
+        xs.EmpiricalQuantileMapping._allow_diff_training_times = True
+        try:
+            ds_fut = xs.EmpiricalQuantileMapping.train(ref, hist_fut).ds
+        finally:
+            xs.EmpiricalQuantileMapping._allow_diff_training_times = False
+        np.testing.assert_array_equal(ds.af.values, ds_fut.af.values)
+
+    def test_base_matching_times_and_units(self, random):
+        """tests/test_adjustment.py:61-116: units are required and must agree; ref / hist time axes must match"""
+        n = 10
+        uu = random.random(n)
+        da = timelonlatseries(uu, attrs={"units": "K"})
+        da2 = timelonlatseries(uu, attrs={"units": "degC"})
+        with pytest.raises((ValueError, NotImplementedError)):
+            xs.EmpiricalQuantileMapping.train(da, da2)  # unit conversion (pint) is outside this path: refused, not guessed
+        with pytest.raises(ValueError, match="units"):
+            xs.EmpiricalQuantileMapping.train(da, timelonlatseries(uu))
+        short = timelonlatseries(uu[:-1], attrs={"units": "K"})
+        with pytest.raises(ValueError):
+            xs.EmpiricalQuantileMapping.train(da, short)
+
+
 @pytest.mark.parametrize("interp,expi", [("nearest", 2.9), ("linear", 2.95)])
 @pytest.mark.parametrize("extrap,expe", [("constant", 4.4), ("nan", np.nan)])
 def test_interp_on_quantiles_constant(interp, expi, extrap, expe):
