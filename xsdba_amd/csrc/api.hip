@@ -733,30 +733,40 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     SeriesOut o, oq;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     if ((rc = series_out_begin<double>(ctx, S_OUT1, S_CM2, sim_q, T, C, ost, osc, &oq))) return rc;
-    const size_t tab = ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15);
-    const size_t base = ((sizeof(double) * 3 * (size_t)G + 15) & ~(size_t)15) + (size_t)T * sizeof(R);
+    const size_t tab = ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15);            // full layout (global scratch)
+    const size_t tab_sh = ranks_only ? 0 : ((xs::tab_lds_bytes<R>(G, Q, true) + 15) & ~(size_t)15);   // shared abscissa row (LDS)
     const bool rw = rank_window && W > 1;
     const int *gp = rw ? pl->d_row_ptr : pl->d_mem_ptr, *gi = rw ? pl->d_row_idx : pl->d_mem_idx;
-    // generic kernel (ranks by counting over the ranking row); `cells`: only the listed cells, count read on the device
+    // short ranking rows (exact day-of-year groups) are sorted once per cell instead of counted per element
+    const int max_rank_row = rw ? pl->max_row : pl->max_mem;
+    int sort_w = getenv("XSDBA_HIP_QDM_NOSORT") ? 0 : (max_rank_row <= 32 ? 32 : (max_rank_row <= 64 ? 64 : 0));
+    auto base_bytes = [&](int sw) {
+        return ((sizeof(double) * 3 * (size_t)G + 15) & ~(size_t)15) + (((size_t)T * sizeof(R) + 15) & ~(size_t)15) +
+               (sw ? (size_t)G * (sw + 1) * sizeof(typename xs::KeyOf<R>::U) : 0);
+    };
+    if (sort_w && base_bytes(sort_w) > (size_t)ctx->lds_limit) sort_w = 0;  // the sorted rows do not fit next to the series
+    const size_t base = base_bytes(sort_w);
+    // generic kernel; `cells`: only the listed cells, count read on the device.  Every block owns a slice of global
+    // scratch for a full-layout table (cells with NaN factors; all cells when the LDS cannot hold the table).
     auto launch_generic = [&](const int *cells, const int *n_cells_dev, int64_t n_blocks) -> int {
         int rc2;
-        if (base + tab <= (size_t)ctx->lds_limit) {
-            if ((rc2 = set_lds(xs::k_qdm_adjust<R, true>, base + tab, ctx, "the ranking series + factor table"))) return rc2;
+        const unsigned nblk = (unsigned)std::min<int64_t>(n_blocks, 1024);
+        void *scratch = nullptr;
+        if (tab && (rc2 = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc2;
+        if (base + tab_sh <= (size_t)ctx->lds_limit) {
+            if ((rc2 = set_lds(xs::k_qdm_adjust<R, true>, base + tab_sh, ctx, "the ranking series + factor table"))) return rc2;
             LaunchScope ls(ctx, "k_qdm_adjust");
-            hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3((unsigned)n_blocks), dim3(qdm_threads()), base + tab, ctx->stream,
+            hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3(nblk), dim3(qdm_threads()), base + tab_sh, ctx->stream,
                                (const R *)s.dev, T, C, s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp,
                                extrap, (int)kind, (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T,
-                               (unsigned char *)nullptr, (size_t)0, cells, n_cells_dev);
+                               (unsigned char *)scratch, tab, cells, n_cells_dev, sort_w);
         } else {
             if ((rc2 = set_lds(xs::k_qdm_adjust<R, false>, base, ctx, "the ranking series"))) return rc2;
-            const unsigned nblk = (unsigned)std::min<int64_t>(n_blocks, 1024);
-            void *scratch;
-            if ((rc2 = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc2;
             LaunchScope ls(ctx, "k_qdm_adjust");
             hipLaunchKernelGGL((xs::k_qdm_adjust<R, false>), dim3(nblk), dim3(qdm_threads()), base, ctx->stream, (const R *)s.dev, T, C,
                                s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap, (int)kind,
                                (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)scratch, tab, cells,
-                               n_cells_dev);
+                               n_cells_dev, sort_w);
         }
         return check_launch("k_qdm_adjust");
     };

@@ -100,12 +100,13 @@ template <typename R, typename Load> __device__ __forceinline__ R vecquantile_so
 // extension rows 0 and G+1 (utils.py:284-314, 489-490) are the same storage seen through ext_row().
 // ---------------------------------------------------------------------------------------------
 template <typename R> struct CellTab {
-    const R *xs;        // [G][Q] compacted abscissae (hist_q, or the quantile nodes for QDM)
+    const R *xs;        // [G][xstride] compacted abscissae (hist_q), or ONE row shared by all groups (xstride == 0:
+                        // the quantile nodes of QDM when the cell's factors hold no NaN)
     const R *ys;        // [G][Q] compacted factors
     const int *rn;      // [G] valid pairs per row
     const double *xfirst, *xlast;  // [G] first/last non-NaN abscissa (NaN if none) — nbutils.py:380-389
     const R *yfirst, *ylast;       // [G] first/last non-NaN factor
-    int G, Q, any_valid;
+    int G, Q, any_valid, xstride;
 };
 
 __device__ __forceinline__ int ext_row(int rr, int G) { return rr == 0 ? G - 1 : (rr == G + 1 ? 0 : rr - 1); }
@@ -174,7 +175,7 @@ __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct
         const int n = ct.rn[g0];
         if (n) {
             int w;
-            best = row_nearest<R, XF>(x, ct.xs + (size_t)g0 * Q, n, &w);
+            best = row_nearest<R, XF>(x, ct.xs + (size_t)g0 * ct.xstride, n, &w);
             val = ct.ys[(size_t)g0 * Q + w];
             node = r * Q + w;
         }
@@ -190,7 +191,7 @@ __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct
             int n = ct.rn[g];
             if (n == 0) continue;
             int w;
-            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * Q, n, &w) + d2r;
+            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
             if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
         }
     }

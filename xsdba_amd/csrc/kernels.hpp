@@ -155,6 +155,9 @@ __global__ void k_train_rows(const R *__restrict__ x0, const R *__restrict__ x1,
 // table staging shared by the adjust kernels: copies a cell's [G][Q] (xq, yq) into LDS, compacts the
 // NaN pairs of every row in place and fills the row metadata (nbutils._first_and_last_nonnull).
 // xq_row_stride == 0 broadcasts one abscissa row to all groups (QDM: the quantile nodes).
+// A table carved with shared_x keeps that ONE row instead of G copies (half the LDS); it can only hold cells whose
+// factors are NaN-free (no per-row compaction) — tab_stage answers any_valid == -1 otherwise and the caller stages
+// the cell into a full-layout table.
 // ---------------------------------------------------------------------------------------------
 template <typename R> struct TabLds {
     R *xs, *ys;
@@ -162,21 +165,24 @@ template <typename R> struct TabLds {
     double *xfirst, *xlast;
     R *yfirst, *ylast;
     int *any;
+    int xstride;  // Q, or 0 for the shared abscissa row
 };
 
-template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q)
+template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q, bool shared_x = false)
 {
     size_t n = (size_t)G * Q;
-    return 2 * sizeof(double) * (size_t)G + 2 * sizeof(R) * n + 2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16;
+    return 2 * sizeof(double) * (size_t)G + sizeof(R) * (n + (shared_x ? (size_t)Q : n)) + 2 * sizeof(R) * (size_t)G +
+           sizeof(int) * ((size_t)G + 2) + 16;
 }
 
-template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q)
+template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q, bool shared_x = false)
 {
     TabLds<R> t;
     size_t n = (size_t)G * Q;
+    t.xstride = shared_x ? 0 : Q;
     t.xfirst = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
     t.xlast = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
-    t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * n;
+    t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * (shared_x ? (size_t)Q : n);
     t.ys = reinterpret_cast<R *>(p); p += sizeof(R) * n;
     t.yfirst = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
     t.ylast = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
@@ -192,6 +198,21 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     const int n = G * Q;
     if (threadIdx.x == 0) *t.any = 0;
     bool has_nan = false;
+    if (t.xstride == 0) {  // one shared abscissa row (xq_row_stride == 0)
+        for (int i = threadIdx.x; i < Q; i += blockDim.x) { const R xv = xq[i]; t.xs[i] = xv; has_nan |= xv != xv; }
+        for (int i = threadIdx.x; i < n; i += blockDim.x) { const R yv = yq[i]; t.ys[i] = yv; has_nan |= yv != yv; }
+        CellTab<R> ct;
+        ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
+        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.xstride = 0;
+        if (__syncthreads_or(has_nan ? 1 : 0)) { ct.any_valid = -1; return ct; }
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            const R *yr = t.ys + (size_t)g * Q;
+            t.rn[g] = Q; t.xfirst[g] = (double)t.xs[0]; t.xlast[g] = (double)t.xs[Q - 1]; t.yfirst[g] = yr[0]; t.ylast[g] = yr[Q - 1];
+        }
+        __syncthreads();
+        ct.any_valid = 1;
+        return ct;
+    }
     if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             const R xv = xq[i], yv = yq[i];
@@ -218,7 +239,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         __syncthreads();
         CellTab<R> ct;
         ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
-        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1;
+        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1; ct.xstride = Q;
         return ct;
     }
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -239,7 +260,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     __syncthreads();
     CellTab<R> ct;
     ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
-    ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any;
+    ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any; ct.xstride = Q;
     return ct;
 }
 
@@ -460,7 +481,12 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 // K4: qdm_adjust (_adjustment.py:783-886): percent ranks of sim within its group (utils.rank, utils.py:573-638;
 // average ties, NaN -> NaN, p = r/N rescaled with the extreme ranks) + interpolation of af on the quantile
 // axis + apply.  af == nullptr -> ranks only (utils.rank through Grouper.apply).
-// One block per cell; dynamic LDS: [table (if af)][gstat: 3*G doubles][xs: T * sizeof(R)]
+// One block per cell; dynamic LDS: [table (if af; shared abscissa row)][gstat: 3*G doubles][xs: T * sizeof(R)]
+// [gs: G * (sort_w + 1) keys]; cells whose factors hold NaN (and every cell when !TAB_LDS) use a full-layout table in the
+// block's slice of gscratch.
+// sort_w (0, 32 or 64): ranking rows of at most sort_w values (exact day-of-year groups: 30 members) are SORTED once —
+// one row per sort_w lanes, bitonic network on the cross-lane path — and every element then finds its rank by two
+// bisections in its row; sort_w == 0 ranks by counting over the row (any length).
 // ---------------------------------------------------------------------------------------------
 template <typename R, bool TAB_LDS>
 __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
@@ -468,27 +494,87 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
                              const int *__restrict__ gidx, const int *__restrict__ grp_ptr,
                              const int *__restrict__ grp_idx, int interp, int extrap, int kind, R *__restrict__ scen,
                              double *__restrict__ sim_q, int64_t ost, int64_t osc, unsigned char *__restrict__ gscratch,
-                             size_t gstride, const int *__restrict__ cell_list, const int *__restrict__ n_list_dev)
+                             size_t gstride, const int *__restrict__ cell_list, const int *__restrict__ n_list_dev, int sort_w)
 {
+    using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *p = smem;
-    TabLds<R> tl;
+    TabLds<R> tl, tlg;
     if (af) {
-        tl = tab_carve<R>(TAB_LDS ? p : gscratch + (size_t)blockIdx.x * gstride, G, Q);
-        if (TAB_LDS) p += (tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
+        tlg = tab_carve<R>(gscratch + (size_t)blockIdx.x * gstride, G, Q);
+        if (TAB_LDS) {
+            tl = tab_carve<R>(p, G, Q, true);
+            p += (tab_lds_bytes<R>(G, Q, true) + 15) & ~(size_t)15;
+        }
     }
     double *gstat = reinterpret_cast<double *>(p);  // per group: N valid, pmin, pmax of the percent-rank rescaling
     p += ((sizeof(double) * 3 * (size_t)G) + 15) & ~(size_t)15;
     R *xs = reinterpret_cast<R *>(p);
+    p += (((size_t)T * sizeof(R)) + 15) & ~(size_t)15;
+    U *gs = reinterpret_cast<U *>(p);  // sorted keys of every ranking row, row stride sort_w + 1 (odd: no bank conflicts)
+    const int gstr = sort_w + 1;
   // cell_list (device list of *n_list_dev cell ids): redo only those cells (the fallback of k_qdm_cell)
   const int64_t n_cells = cell_list ? (int64_t)*n_list_dev : C;
   for (int64_t ci = blockIdx.x; ci < n_cells; ci += gridDim.x) {
     const int64_t c = cell_list ? (int64_t)cell_list[ci] : ci;
-    CellTab<R> ct;
-    if (af) ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
+    CellTab<R> ct, ctg;
+    bool tab_global = !TAB_LDS;
+    if (af) {
+        if (TAB_LDS) {
+            ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
+            tab_global = ct.any_valid < 0;
+        }
+        if (tab_global) ctg = tab_stage<R>(tlg, quantiles, 0, af + (size_t)c * G * Q, G, Q);
+    }
     const R *x = sim + c * sc;
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t * st];
     __syncthreads();
+    if (sort_w) {
+        // sorted ranking rows: sort_w lanes per row, 64 / sort_w rows per wave; UNR independent rows per lane keep the
+        // cross-lane latency of the bitonic network covered
+        constexpr int UNR = 4;
+        const int lane = threadIdx.x & 63, sub = lane / sort_w, hl = lane % sort_w, rpw = 64 / sort_w;
+        const int per_round = (blockDim.x >> 6) * rpw * UNR;
+        const unsigned long long rowmask = sort_w == 64 ? ~0ull : (((1ull << sort_w) - 1ull) << (sub * sort_w));
+        for (int g0 = 0; g0 < G; g0 += per_round) {
+            int g[UNR];
+            U k[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                g[u] = g0 + (((int)(threadIdx.x >> 6)) * UNR + u) * rpw + sub;
+                const bool gv = g[u] < G;
+                const int p0 = gv ? grp_ptr[g[u]] : 0, len = gv ? grp_ptr[g[u] + 1] - p0 : 0;
+                k[u] = KeyOf<R>::MAXK;
+                if (hl < len) { const R v = xs[grp_idx[p0 + hl]]; if (v == v) k[u] = to_key(v + (R)0); }  // -0.0 ranks as +0.0
+            }
+            for (int kk = 2; kk <= sort_w; kk <<= 1)
+                for (int j = kk >> 1; j > 0; j >>= 1) {
+                    const bool up = (hl & kk) == 0, lower = (hl & j) == 0;
+#pragma unroll
+                    for (int u = 0; u < UNR; u++) {
+                        const U o = __shfl_xor(k[u], j, 64);  // the partner stays inside the row: j < sort_w
+                        k[u] = (lower == up) ? (k[u] < o ? k[u] : o) : (k[u] > o ? k[u] : o);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                const unsigned long long valid = __ballot(k[u] != KeyOf<R>::MAXK);
+                const int N = __popcll(valid & rowmask);
+                const U kfirst = __shfl(k[u], sub * sort_w, 64), klast = __shfl(k[u], sub * sort_w + (N > 0 ? N - 1 : 0), 64);
+                const int nmin = __popcll(__ballot(k[u] == kfirst && k[u] != KeyOf<R>::MAXK) & rowmask);
+                const int nmax = __popcll(__ballot(k[u] == klast && k[u] != KeyOf<R>::MAXK) & rowmask);
+                if (g[u] < G) {
+                    gs[(size_t)g[u] * gstr + hl] = k[u];
+                    if (hl == 0) {
+                        const double Nd = (double)N;
+                        gstat[3 * g[u]] = Nd;
+                        gstat[3 * g[u] + 1] = (((double)nmin + 1.0) / 2.0) / Nd;
+                        gstat[3 * g[u] + 2] = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
+                    }
+                }
+            }
+        }
+    } else
     // per-group statistics over the ranking row (grp_* = windowed rows when rank_window, else the exact groups)
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
         int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
@@ -506,13 +592,76 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         gstat[3 * g + 2] = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
     }
     __syncthreads();
+    // (a lambda so that the LDS table and the global one each get their own copy of the loop, with LDS loads in the
+    // first; the table argument is unused when af == nullptr)
+    auto elements = [&](const CellTab<R> &tab) __attribute__((always_inline)) {
+    if (sort_w) {
+        // two elements per thread and round: their four bisections (first key >= key(v), first key > key(v), fixed
+        // step count over the row padded with MAXK) are independent chains of LDS reads
+        constexpr int EU = 2;
+        for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)EU * blockDim.x) {
+            R v[EU];
+            int g[EU], lo[EU], hi[EU];
+            bool ok[EU];
+            U kv[EU];
+            const U *row[EU];
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                const int64_t t = t0 + (int64_t)e * blockDim.x;
+                const bool in = t < T;
+                v[e] = in ? xs[t] : nan_of<R>();
+                g[e] = in ? gidx[t] : -1;
+                ok[e] = v[e] == v[e] && g[e] >= 0;
+                row[e] = gs + (size_t)(ok[e] ? g[e] : 0) * gstr;
+                kv[e] = ok[e] ? to_key(v[e] + (R)0) : (U)0;
+                lo[e] = 0;
+                hi[e] = 0;
+            }
+            for (int step = sort_w >> 1; step > 0; step >>= 1) {
+#pragma unroll
+                for (int e = 0; e < EU; e++) {
+                    const U a = row[e][lo[e] + step - 1], b = row[e][hi[e] + step - 1];
+                    lo[e] += a < kv[e] ? step : 0;
+                    hi[e] += b <= kv[e] ? step : 0;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                lo[e] += row[e][lo[e]] < kv[e] ? 1 : 0;
+                hi[e] += row[e][hi[e]] <= kv[e] ? 1 : 0;
+            }
+            double sq[EU];
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                sq[e] = __builtin_nan("");
+                if (ok[e]) {
+                    const double N = gstat[3 * g[e]], pmin = gstat[3 * g[e] + 1], pmax = gstat[3 * g[e] + 2];
+                    const double r = (double)lo[e] + (double)(hi[e] - lo[e] + 1) / 2.0;
+                    const double pr = r / N;
+                    sq[e] = pmax * (pr - pmin) / (pmax - pmin);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                const int64_t t = t0 + (int64_t)e * blockDim.x;
+                if (t < T) {
+                    if (sim_q) sim_q[c * osc + t * ost] = sq[e];
+                    if (af) {
+                        int nd_unused;
+                        R a = celltab_eval<R>(tab, sq[e], true, G > 1 ? g[e] : 0, interp, extrap, nd_unused);
+                        scen[c * osc + t * ost] = apply_corr<R>(v[e], a, kind);
+                    }
+                }
+            }
+        }
+    } else
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
         R v = xs[t];
         int g = gidx[t];
         double sq = __builtin_nan("");
         if (v == v && g >= 0) {
-            int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
             int less = 0, eq = 0;
+            const int p0 = grp_ptr[g], p1 = grp_ptr[g + 1];
             for (int i = p0; i < p1; i++) { R u = xs[grp_idx[i]]; less += (u < v); eq += (u == v); }
             const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
             double r = (double)less + (double)(eq + 1) / 2.0;
@@ -522,10 +671,13 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         if (sim_q) sim_q[c * osc + t * ost] = sq;
         if (af) {
             int nd_unused;
-            R a = celltab_eval<R>(ct, sq, true, G > 1 ? g : 0, interp, extrap, nd_unused);
+            R a = celltab_eval<R>(tab, sq, true, G > 1 ? g : 0, interp, extrap, nd_unused);
             scen[c * osc + t * ost] = apply_corr<R>(v, a, kind);
         }
     }
+    };
+    if (tab_global) elements(ctg);
+    else elements(ct);
     __syncthreads();  // series / table are reused by the next cell
   }
 }
