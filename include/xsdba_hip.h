@@ -46,6 +46,8 @@ extern "C" {
 enum { XSDBA_F32 = 0, XSDBA_F64 = 1 };
 enum { XSDBA_INTERP_NEAREST = 0, XSDBA_INTERP_LINEAR = 1 };
 enum { XSDBA_EXTRAP_CONSTANT = 0, XSDBA_EXTRAP_NAN = 1 };
+/* `degree` of xsdba_hip_dqm_adjust: the trend was fitted by the caller and `trend` is an INPUT */
+enum { XSDBA_TREND_GIVEN = -1 };
 
 enum {
     XSDBA_E_ARG = -1,          /* bad argument (null pointer, size, dtype, kind, group index out of range) */
@@ -141,7 +143,10 @@ int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t 
 /* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
  * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`
  * (detrending.py:165-208; float64 abscissa, e.g. ns since 1970 as xarray.polyfit uses), quantile
- * mapping of the detrended series, retrend.  trend (nullable) has the layout of scen. */
+ * mapping of the detrended series, retrend.  trend (nullable) has the layout of scen.
+ * degree == XSDBA_TREND_GIVEN: `trend` is read instead of fitted (contiguous [cell][time]; time_num may be null) — the
+ * pooled fit of Grouper(add_dims=...), where one trend from the mean over the pooled members (detrending.py:196-199)
+ * serves all of them. */
 int xsdba_hip_dqm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
                          int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q,
                          const void *scaling, int32_t n_groups, int32_t nq, const int32_t *group_of_time,

@@ -4,7 +4,13 @@ qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` 
 body is ONE call into the HIP library that covers every group of every cell of the block.
 
 Not yet on the device path (rows "next" of SURVEY §8f; they raise NotImplementedError instead of running
-anything on the CPU): ``add_dims``, grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+anything on the CPU): grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+
+``Grouper(add_dims=...)`` (base.py:413: the extra dimensions are pooled into every group's sample at training, and into
+the windowed ranks / the detrending fit at adjustment) needs no kernel of its own: the P pooled members of a cell are
+laid end to end as ONE series of P * (T + window // 2) steps, the gaps filled with NaN and given no group, so that a
+window never reaches from one member into the next; every training kernel then sees the pooled sample as the group's
+row (NaN-skipping, like the out-of-range window slots of the reference's rolling.construct).
 On the device since round 1: ``max_tail_factor`` (``hist_q_raw`` at training, ``hip.tail_mask`` after the adjustment),
 ``jitter_*`` and ``adapt_freq_thresh`` (``hip.jitter`` / ``hip.adapt_freq`` in front of the training kernels, the
 frequency adaptation of ``sim`` with the trained ``P0_ref, P0_hist, pth`` in front of the adjust kernels).
@@ -33,8 +39,61 @@ def _unsupported(**opts):
 
 
 def _check_group(group: Grouper, ds):
-    if group.add_dims:
-        raise NotImplementedError("Grouper(add_dims=...) is not implemented on the HIP path yet")
+    if group.add_dims:  # base.py:628-629
+        if "sim" in ds and "af" in ds:  # adjust: sim need not carry the pooled dims
+            return
+        have = set()
+        for name in ("ref", "hist", "sim"):
+            if name in ds:
+                have |= set(as_dataarray(ds[name]).dims)
+        if not set(group.add_dims).issubset(have):
+            raise ValueError("`add_dims` argument needs to be a dimension in one of the input datasets.")
+
+
+class _Members:
+    """[cell, member, time] view of an array whose ``group.add_dims`` dimensions are pooled (members) and whose other
+    non-time dimensions are cells."""
+
+    def __init__(self, da: DataArray, group: Grouper, dt):
+        pooled = tuple(d for d in group.add_dims if d in da.dims)
+        self.cell_dims = tuple(d for d in da.dims if d != group.dim and d not in pooled)
+        self.pooled = pooled
+        self.da = da.transpose(*self.cell_dims, *pooled, group.dim)
+        v = np.asarray(self.da.values, dt)
+        k = len(self.cell_dims)
+        self.cell_shape = v.shape[:k]
+        self.pool_shape = v.shape[k:-1]
+        self.P = int(np.prod(self.pool_shape, dtype=np.int64)) if pooled else 1
+        self.T = v.shape[-1]
+        self.x3 = v.reshape(-1, self.P, self.T)
+
+    def flat(self):
+        """members as cells: [cell * member, time]"""
+        return self.x3.reshape(-1, self.T)
+
+    def folded(self, gidx, W):
+        """the pooled series [cell, P * (T + W // 2)] and the group of each of its steps (-1 in the gaps)"""
+        return _fold(self.x3, gidx, W)
+
+
+def _fold(x3, gidx, W):
+    C, P, T = x3.shape
+    if P == 1:
+        return x3.reshape(C, T), np.asarray(gidx, np.int32)
+    h = W // 2
+    out = np.full((C, P, T + h), np.nan, x3.dtype)
+    out[:, :, :T] = x3
+    g = np.full((P, T + h), -1, np.int32)
+    g[:, :T] = gidx
+    return out.reshape(C, -1), g.reshape(-1)
+
+
+def _unfold(y2, P, T):
+    """inverse of _fold for a result series: [cell, P * (T + h)] -> [cell * member, T]"""
+    C = y2.shape[0]
+    if P == 1:
+        return y2
+    return np.ascontiguousarray(y2.reshape(C, P, -1)[:, :, :T]).reshape(C * P, T)
 
 
 def _common_dtype(*arrays):
@@ -60,18 +119,41 @@ def _train_dataset(ref: DataArray, group: Grouper, quantiles, cell_dims, cell_sh
     return Dataset(out)
 
 
+class _TrainBlock:
+    """ref and hist of one training call as [cell, time'] series blocks (pooled members folded into time')"""
+
+
 def _prep_train(ds, group):
     _check_group(group, ds)
     ref, hist = as_dataarray(ds["ref"]), as_dataarray(ds["hist"])
     dt = _common_dtype(ref.values, hist.values)
-    hist = hist.transpose(*ref.dims)
-    r2, cell_dims, cell_shape = cell_time_view(ref.astype(dt) if ref.dtype != dt else ref, group.dim)
-    h2, _, _ = cell_time_view(hist.astype(dt) if hist.dtype != dt else hist, group.dim)
     gidx, G = group.group_index(ref)
-    return ref, r2, h2, gidx, G, cell_dims, cell_shape, dt
+    tb = _TrainBlock()
+    if not group.add_dims:
+        hist = hist.transpose(*ref.dims)
+        tb.r2, cell_dims, cell_shape = cell_time_view(ref.astype(dt) if ref.dtype != dt else ref, group.dim)
+        tb.h2, _, _ = cell_time_view(hist.astype(dt) if hist.dtype != dt else hist, group.dim)
+        tb.gidx_r = tb.gidx_h = gidx
+        tb.same = True
+        return ref, tb, gidx, G, cell_dims, cell_shape, dt
+    mr, mh = _Members(ref, group, dt), _Members(hist, group, dt)
+    if set(mr.cell_dims) != set(mh.cell_dims):
+        raise ValueError(f"ref and hist must share their non-pooled dimensions, got {mr.cell_dims} and {mh.cell_dims}")
+    if mh.cell_dims != mr.cell_dims:
+        mh = _Members(hist.transpose(*mr.cell_dims, *mh.pooled, group.dim), group, dt)
+    tb.r2, tb.gidx_r = mr.folded(gidx, group.window)
+    tb.h2, tb.gidx_h = mh.folded(gidx, group.window)
+    tb.same = mr.P == mh.P  # one fused training call needs ref and hist on the same (folded) time axis
+    return mr.da, tb, tb.gidx_h, G, mr.cell_dims, mr.cell_shape, dt
 
 
-def _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value, jitter_over_thresh_value,
+def _corr(x, y, kind):
+    """utils.get_correction (:130-146) on trained tables (not series): the factor that takes x to y"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return (y - x if kind == u.ADDITIVE else y / x).astype(x.dtype, copy=False)
+
+
+def _preprocess_hist(ref, tb, G, group, adapt_freq_thresh, jitter_under_thresh_value, jitter_over_thresh_value,
                      jitter_over_thresh_upper_bnd):
     """_adjustment._preprocess_dataset (:48-83) on the [cell, time] block of hist: jitter under / over, then the
     frequency adaptation against ref over the windowed group blocks.  Returns (hist block, extra tables or None)."""
@@ -79,6 +161,7 @@ def _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_unde
 
     if (jitter_over_thresh_value is None) ^ (jitter_over_thresh_upper_bnd is None):
         raise ValueError("`jitter_over_thresh_value` and `jitter_over_thresh_upper_bnd` must both be specified or both be `None` (default)")
+    h2 = tb.h2
     if jitter_under_thresh_value:
         h2 = hip.jitter(h2, lower=quantity_to_float(jitter_under_thresh_value, ref, "jitter_under_thresh_value"), seed=_draw_seed())
     if jitter_over_thresh_value:
@@ -86,20 +169,27 @@ def _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_unde
                         maximum=quantity_to_float(jitter_over_thresh_upper_bnd, ref, "jitter_over_thresh_upper_bnd"), seed=_draw_seed())
     extra = None
     if adapt_freq_thresh:
+        if not tb.same:
+            raise NotImplementedError("adapt_freq_thresh with `add_dims` present in only one of ref / hist is not implemented "
+                                      "on the HIP path (the kernel walks ref and hist on one time axis)")
         th = quantity_to_float(adapt_freq_thresh, ref, "adapt_freq_thresh")
-        h2, pth, _, P0_ref, P0_hist = hip.adapt_freq(h2, r2, gidx, G, group.window, th, seed=_draw_seed())
+        h2, pth, _, P0_ref, P0_hist = hip.adapt_freq(h2, tb.r2, tb.gidx_h, G, group.window, th, seed=_draw_seed())
         extra = {"P0_ref": P0_ref.astype(h2.dtype), "P0_hist": P0_hist.astype(h2.dtype), "pth": pth}
     return h2, extra
 
 
 def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
-    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    ref, tb, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
-    h_raw = h2
-    h2, extra = _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value,
+    h_raw = tb.h2
+    h2, extra = _preprocess_hist(ref, tb, G, group, adapt_freq_thresh, jitter_under_thresh_value,
                                  jitter_over_thresh_value, jitter_over_thresh_upper_bnd)
-    af, hq = hip.eqm_train(r2, h2, gidx, G, group.window, q, kind)
+    if tb.same:
+        af, hq = hip.eqm_train(tb.r2, h2, gidx, G, group.window, q, kind)
+    else:  # differently pooled ref / hist: each on its own time axis, the factors from the two tables
+        hq = hip.quantile_groups(h2, tb.gidx_h, G, group.window, q)
+        af = _corr(hq, hip.quantile_groups(tb.r2, tb.gidx_r, G, group.window, q), kind)
     # hist_q_raw = quantiles of hist BEFORE the pre-processing steps (:254-256); a NaN dummy unless max_tail_factor (:273-275)
     if max_tail_factor is None:
         hq_raw = np.full_like(hq, np.nan)
@@ -112,12 +202,19 @@ def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitt
 
 def _fused_dqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitter_under_thresh_value=None,
                      jitter_over_thresh_value=None, jitter_over_thresh_upper_bnd=None, max_tail_factor=None):
-    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    ref, tb, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
     q = np.asarray(quantiles, dt)
-    h_raw = h2
-    h2, extra = _preprocess_hist(ref, r2, h2, gidx, G, group, adapt_freq_thresh, jitter_under_thresh_value,
+    h_raw = tb.h2
+    h2, extra = _preprocess_hist(ref, tb, G, group, adapt_freq_thresh, jitter_under_thresh_value,
                                  jitter_over_thresh_value, jitter_over_thresh_upper_bnd)
-    af, hq, sc = hip.dqm_train(r2, h2, gidx, G, group.window, q, kind)
+    if tb.same:
+        af, hq, sc = hip.dqm_train(tb.r2, h2, gidx, G, group.window, q, kind)
+    else:  # differently pooled ref / hist: normalised quantiles and group means of each on its own time axis
+        _, hq, _ = hip.dqm_train(h2, h2, tb.gidx_h, G, group.window, q, kind)
+        _, rq, _ = hip.dqm_train(tb.r2, tb.r2, tb.gidx_r, G, group.window, q, kind)
+        af = _corr(hq, rq, kind)
+        sc = _corr(hip.group_means(h2, tb.gidx_h, G, group.window).astype(dt, copy=False),
+                   hip.group_means(tb.r2, tb.gidx_r, G, group.window).astype(dt, copy=False), kind)
     # hist_q_raw: quantiles of the raw (not pre-processed, not normalised) hist (:151-153)
     hq_raw = hip.quantile_groups(h_raw, gidx, G, group.window, q) if max_tail_factor is not None else np.full_like(hq, np.nan)
     out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, scaling=sc,
@@ -184,12 +281,20 @@ def _prep_adjust(ds, group: Grouper, interp: str):
         )
     sim = as_dataarray(ds["sim"])
     dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
+    pooled = [d for d in group.add_dims if d in sim.dims]
+    if pooled:  # the pooled members become cells of their own, next to each other (the tables are broadcast over them)
+        sim = sim.transpose(*[d for d in sim.dims if d != group.dim and d not in pooled], *pooled, group.dim)
     s2, cell_dims, cell_shape = cell_time_view(sim.astype(dt) if sim.dtype != dt else sim, group.dim)
     gidx, G = group.group_index(sim)
     return sim, s2, gidx, G, cell_dims, cell_shape, dt
 
 
-def _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh):
+def _n_pooled(group: Grouper, cell_dims, cell_shape):
+    """number of pooled members per cell in the [cell * member, time] block of _prep_adjust"""
+    return int(np.prod([n for d, n in zip(cell_dims, cell_shape) if d in group.add_dims], dtype=np.int64))
+
+
+def _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape=None):
     """_adapt_freq_preprocess on the adjust side (_adjustment.py:32-46, 639-645): the frequency adaptation of sim with the
     trained P0_ref / P0_hist / pth, on the groups WITHOUT window (Grouper(group.name))."""
     if not adapt_freq_thresh:
@@ -197,18 +302,18 @@ def _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thres
     from .processing import _draw_seed, quantity_to_float
 
     th = quantity_to_float(adapt_freq_thresh, sim, "adapt_freq_thresh")
-    tabs = [table_view(as_dataarray(ds[k]), cell_dims, group.prop, last=None) for k in ("P0_ref", "P0_hist", "pth")]
+    tabs = [table_view(as_dataarray(ds[k]), cell_dims, group.prop, last=None, cell_shape=cell_shape) for k in ("P0_ref", "P0_hist", "pth")]
     out = hip.adapt_freq(s2, None, gidx, G, 1, th, seed=_draw_seed(), P0_ref=tabs[0].astype(np.float64),
                          P0_hist=tabs[1].astype(np.float64), pth=tabs[2].astype(dt, copy=False))
     return out[0]
 
 
-def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor):
+def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape=None):
     """mask no bias adjustment where sim is larger than n times the largest raw hist quantile (_adjustment.py:648-658,
     672-673); the group broadcast of the reference is "nearest" for every grouping this path accepts"""
     if max_tail_factor is None:
         return scen
-    hq_raw = table_view(as_dataarray(ds["hist_q_raw"]), cell_dims, group.prop).astype(dt, copy=False)
+    hq_raw = table_view(as_dataarray(ds["hist_q_raw"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     return hip.tail_mask(s2, np.ascontiguousarray(scen), hq_raw, gidx if G > 1 else None, max_tail_factor)
 
 
@@ -221,12 +326,28 @@ def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=No
 def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """QM (DQM and EQM): adjust step on one block (_adjustment.py:594-676)."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
-    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
-    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
-    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
+    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
+
+
+def _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P):
+    """The detrending fit with pooled members (detrending.py:196-203): ONE trend per cell, fitted on the mean of the scaled
+    series over the pooled members (and the window); every member is detrended / retrended with it.
+    s2, sc: [cell * member, time] / [cell * member, group] blocks; returns the trend repeated per member."""
+    CP, T = s2.shape
+    if group.window > 1 and np.isnan(s2).any():
+        raise NotImplementedError("dqm_adjust with `add_dims`, a window and missing values in sim is not implemented on the HIP "
+                                  "path (the pooled window mean is formed as the window mean of the member means)")
+    scaled = hip.scaling_adjust(s2, sc, gidx if G > 1 else None, kind)
+    # mean over the members of every (cell, time): series of P values with one group
+    by_time = np.ascontiguousarray(scaled.reshape(CP // P, P, T).transpose(0, 2, 1)).reshape(-1, P)
+    mean = hip.group_means(by_time, None, 1, 1).reshape(CP // P, T).astype(s2.dtype, copy=False)
+    trend = hip.polydetrend_trend(mean, gidx, G, group.window, tnum, degree)
+    return np.ascontiguousarray(np.repeat(trend, P, axis=0))
 
 
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], trend=[])
@@ -244,13 +365,18 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     if degree not in (0, 1):
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0 or 1)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
-    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
-    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
-    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop).astype(dt, copy=False)
-    sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
+    hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
+    sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     tnum = group._time_index(sim).numeric_ns
-    scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
+    P = _n_pooled(group, cell_dims, cell_shape)
+    if P > 1:
+        trend_in = _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P)
+        scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
+    else:
+        scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "trend": _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")})
 
@@ -273,19 +399,28 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
                 stacklevel=2,
             )
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
-    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh)
-    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop).astype(dt, copy=False)
+    s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     quantiles = np.asarray(ds["quantiles"].values, dt)
-    scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor)
+    P = _n_pooled(group, cell_dims, cell_shape)
+    if P > 1 and rank_window:
+        # ranks over (time, window, pooled members) (_adjustment.py:873: main_only = not rank_window): the members of a
+        # cell laid end to end as one series, like at training; the table of the cell serves all of them
+        T = s2.shape[1]
+        f2, gf = _fold(s2.reshape(-1, P, T), gidx, group.window)
+        scen, sim_q = hip.qdm_adjust(f2, np.ascontiguousarray(af[::P]), quantiles, gf, group.window, True, interp, extrapolation, kind)
+        scen, sim_q = _unfold(scen, P, T), _unfold(sim_q, P, T)
+    else:
+        scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})
 
 
 def _fused_scaling_train(ds, *, group, kind):
-    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
-    mhist = hip.group_means(h2, gidx, G, group.window)
-    mref = hip.group_means(r2, gidx, G, group.window)
+    ref, tb, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    mhist = hip.group_means(tb.h2, tb.gidx_h, G, group.window)
+    mref = hip.group_means(tb.r2, tb.gidx_r, G, group.window)
     af = mref - mhist if kind == u.ADDITIVE else mref / mhist  # utils.get_correction(mhist, mref, kind) :130-146
     out = _train_dataset(ref, group, [], cell_dims, cell_shape, af=af.astype(dt, copy=False))
     out = Dataset({"af": out["af"]})
@@ -327,7 +462,7 @@ def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
     (utils.broadcast :180-248), "nearest" or linearly interpolated between group centres."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
     g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
-    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     scen = hip.scaling_adjust(s2, af, g_lo if G > 1 else None, kind, g_hi=g_hi, frac=frac)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
@@ -335,8 +470,10 @@ def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
 @map_blocks(reduces=[Grouper.ADD_DIMS, Grouper.DIM], af=[Grouper.PROP], hist_thresh=[Grouper.PROP])
 def loci_train(ds, *, group, thresh) -> Dataset:
     """LOCI: train on one block (_adjustment.py:889-919), every group at once on the device."""
-    ref, r2, h2, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
-    af, sth = hip.loci_train(r2, h2, gidx, G, group.window, thresh)
+    ref, tb, gidx, G, cell_dims, cell_shape, dt = _prep_train(ds, group)
+    if not tb.same:
+        raise NotImplementedError("LOCI with `add_dims` present in only one of ref / hist is not implemented on the HIP path")
+    af, sth = hip.loci_train(tb.r2, tb.h2, gidx, G, group.window, thresh)
     out = _train_dataset(ref, group, [], cell_dims, cell_shape, af=af, hist_thresh=sth)
     return Dataset({"af": out["af"], "hist_thresh": out["hist_thresh"]})
 
@@ -347,7 +484,7 @@ def loci_adjust(ds, *, group, thresh, interp) -> Dataset:
     or linearly interpolated between group centres (the reference's default)."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
     g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
-    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
-    sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None).astype(dt, copy=False)
+    af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
+    sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     scen = hip.loci_adjust(s2, af, sth, g_lo if G > 1 else None, thresh, g_hi=g_hi, frac=frac)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()

@@ -371,7 +371,11 @@ def map_blocks(reduces=None, **out_vars):
             if {Grouper.PROP, Grouper.DIM, Grouper.ADD_DIMS}.intersection(out_dims + red_dims) and group is None:
                 raise ValueError("Missing required `group` argument.")
             placeholders = {Grouper.PROP: [group.prop], Grouper.DIM: [group.dim], Grouper.ADD_DIMS: group.add_dims} if group is not None else {}
-            if group is not None and group.add_dims and not set(group.add_dims).issubset(set(ds.dims)):
+            all_in = set(ds.sizes) if isinstance(ds, Dataset) else set(ds.dims)
+            # (an adjust call may see none of the pooled dims: sim need not have them, and unlike the reference's the trained
+            # tables here never carry them — its P0_ref / P0_hist / pth dummies do, base.py:52-58)
+            adjusting = isinstance(ds, Dataset) and "sim" in ds and "af" in ds
+            if group is not None and group.add_dims and not adjusting and not set(group.add_dims).issubset(all_in):
                 raise ValueError("`add_dims` argument needs to be a dimension in one of the input datasets.")
             new_dims, reduced_dims = [], []
             for dim in out_dims:

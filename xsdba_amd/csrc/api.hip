@@ -666,8 +666,10 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
                     const void *hq, const void *scaling, int G, int Q, const int32_t *gidx, int W, const double *tnum,
                     int degree, int interp, int extrap, char kind, void *scen, void *trend, int64_t ost, int64_t osc)
 {
-    if (C <= 0 || Q <= 0 || !af || !hq || !scaling || !scen || !tnum) return fail(XSDBA_E_ARG, "null/empty argument");
-    if (degree < 0 || degree > 1) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    const bool trend_given = degree == XSDBA_TREND_GIVEN;  // `trend` is an input: the fit was done by the caller
+    if (C <= 0 || Q <= 0 || !af || !hq || !scaling || !scen || (!tnum && !trend_given)) return fail(XSDBA_E_ARG, "null/empty argument");
+    if (!trend_given && (degree < 0 || degree > 1)) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    if (trend_given && (!trend || ost != 1 || osc != T)) return fail(XSDBA_E_ARG, "a given trend must be a contiguous [cell][time] array");
     if (G > 1 && interp != XSDBA_INTERP_NEAREST) return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented");
     int rc;
     Plan *pl;
@@ -677,19 +679,27 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
     size_t tab = (size_t)C * G * Q * sizeof(R);
     const void *daf, *dhq, *dsc, *dtn;
     if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq)) ||
-        (rc = stage_in(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &dsc)) ||
-        (rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
+        (rc = stage_in(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &dsc))) return rc;
+    if (!trend_given && (rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
     SeriesOut o, otr;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
-    // the trend is always needed on device in cell-major form
-    if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
-    else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
-    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+    const R *trend_cm;
+    if (trend_given) {
+        const void *dtr;
+        if ((rc = stage_in(ctx, S_OUT1, trend, (size_t)T * C * sizeof(R), &dtr))) return rc;
+        trend_cm = (const R *)dtr;
+    } else {
+        // the trend is always needed on device in cell-major form
+        if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
+        else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
+        if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+        trend_cm = (const R *)otr.kernel_dst;
+    }
     if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
-                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, (const R *)otr.kernel_dst))) return rc;
+                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, trend_cm))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
-    if (trend && (rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
-    return sync_if(ctx, o.copy_back || otr.copy_back || !is_device_ptr(sim) || !is_device_ptr(tnum));
+    if (!trend_given && trend && (rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
+    return sync_if(ctx, o.copy_back || otr.copy_back || !is_device_ptr(sim) || (tnum && !is_device_ptr(tnum)) || (trend_given && !is_device_ptr(trend)));
 }
 
 template <typename R>

@@ -172,8 +172,9 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
 
 
 def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
-               ctx=None, out=None):
-    """_adjustment.dqm_adjust -> (scen, trend) each [C, T]"""
+               ctx=None, out=None, trend_in=None):
+    """_adjustment.dqm_adjust -> (scen, trend) each [C, T].  ``trend_in`` ([C, T]): use this trend instead of fitting one
+    (``degree`` and ``time_num`` are then ignored)."""
     ctx = ctx or default_context()
     s = _Series(sim)
     G, Q = (af.shape[1], af.shape[2])
@@ -181,9 +182,15 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
     hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
     scaling = _table(scaling, s.dtype, (s.C, G))
     g = _gidx(gidx, s.T, G)
-    tn = time_num if isinstance(time_num, DeviceArray) else np.ascontiguousarray(time_num, np.float64)
     scen = out[0] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
-    trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    if trend_in is not None:
+        trend = trend_in if isinstance(trend_in, DeviceArray) else np.ascontiguousarray(trend_in, s.dtype)
+        if tuple(trend.shape) != (s.C, s.T):
+            raise ValueError(f"trend_in must have shape {(s.C, s.T)}")
+        tn, degree = None, -1  # XSDBA_TREND_GIVEN
+    else:
+        tn = time_num if isinstance(time_num, DeviceArray) else np.ascontiguousarray(time_num, np.float64)
+        trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_dqm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
                                       _vp(af), _vp(hist_q), _vp(scaling), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
                                       _vp(tn), C.c_int(degree), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),

@@ -82,14 +82,22 @@ def cell_time_view(da: DataArray, dim: str = "time"):
     return v.reshape(-1, v.shape[-1]), cell_dims, cell_shape
 
 
-def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantiles"):
-    """[cell, group(, quantile)] contiguous view of a trained table with the cells ordered like `cell_dims`."""
+def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantiles", cell_shape=None):
+    """[cell, group(, quantile)] contiguous view of a trained table with the cells ordered like `cell_dims`.
+    Cell dimensions the table does not have (the members pooled by ``Grouper(add_dims=...)`` at training) are broadcast,
+    their sizes taken from `cell_shape`."""
     tail = [prop] + ([last] if last else [])
     missing = [d for d in cell_dims if d not in tab.dims]
-    if missing:
+    if missing and cell_shape is None:
         raise ValueError(f"trained table lacks dimension(s) {missing} present on the data")
-    t = tab.transpose(*cell_dims, *tail)
-    return np.ascontiguousarray(t.values).reshape((-1,) + t.shape[len(cell_dims):])
+    have = [d for d in cell_dims if d in tab.dims]
+    t = tab.transpose(*have, *tail)
+    v = np.asarray(t.values)
+    if missing:
+        shape = [n if d in have else 1 for d, n in zip(cell_dims, cell_shape)] + list(v.shape[len(have):])
+        full = [n for n in cell_shape] + list(v.shape[len(have):])
+        v = np.broadcast_to(v.reshape(shape), full)
+    return np.ascontiguousarray(v).reshape((-1,) + tuple(v.shape[len(cell_dims):]))
 
 
 @parse_group
