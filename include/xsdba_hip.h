@@ -140,6 +140,19 @@ int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t 
                         int32_t nq, const int32_t *group_of_time, int interp, int extrap, char kind, void *scen,
                         int64_t out_stride_t, int64_t out_stride_c, int32_t *node_index);
 
+/* ---- a12-a14 with grouped interp="linear": qm_adjust (_adjustment.py:594-676) through utils.interp_on_quantiles ->
+ * _interp_on_quantiles_2d (utils.py:380-400, 476-513): scipy.griddata(method="linear") = Delaunay triangulation of the
+ * (hist_q value, group coordinate) nodes of the cell's table wrapped with its cyclic rows (add_cyclic_bounds :284-314) and
+ * the piecewise-linear interpolant on it, then nbutils._extrapolate_on_quantiles (nbutils.py:397-416).
+ * group_coord [n_groups + 2]: coordinates of the wrapped rows (month: 0..13); new_group [n_time]: fractional group
+ * coordinate of every time step (Grouper.get_index(interp=True), base.py:308-320).  trend (nullable, contiguous
+ * [cell][time]): the series is detrended with it before the mapping and retrended after (the DQM variant; the caller
+ * passes the scaled series).  Tied quantiles: of exactly repeated nodes one is kept (Qhull's own choice is undefined). */
+int xsdba_hip_qm_adjust_linear2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                                 int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q, int32_t n_groups,
+                                 int32_t nq, const double *group_coord, const double *new_group, int extrap, char kind,
+                                 const void *trend, void *scen, int64_t out_stride_t, int64_t out_stride_c);
+
 /* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
  * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`
  * (detrending.py:165-208; float64 abscissa, e.g. ns since 1970 as xarray.polyfit uses), quantile

@@ -306,3 +306,40 @@ def vecquantiles(x, rnk):
     _check(lib().xsdba_oracle_vecquantiles(_p(x), _dt(x), _i64(T), _i64(Cn), _i64(st), _i64(sc), _p(r), _p(out)),
            "vecquantiles")
     return out
+
+
+def interp_on_quantiles_2d(newx, newg, oldx, oldy, oldg, method="linear", extrap="constant"):
+    """utils._interp_on_quantiles_2d (utils.py:380-400) + nbutils._extrapolate_on_quantiles (nbutils.py:397-416) for ONE
+    cell, with scipy.interpolate.griddata itself (the third-party routine the reference calls, scipy >= 1.11; 1.15 here):
+    oldx, oldy, oldg are the [G + 2, Q] table rows wrapped with the cyclic ones and their group coordinates, newx / newg the
+    series and the (fractional) group coordinate of every time step.  Output in the dtype of oldy, like the reference."""
+    from scipy.interpolate import griddata
+
+    newx, newg = np.asarray(newx), np.asarray(newg, np.float64)
+    oldx, oldy, oldg = np.asarray(oldx), np.asarray(oldy), np.asarray(oldg, np.float64)
+    mask_new = np.isnan(newx) | np.isnan(newg)
+    mask_old = np.isnan(oldy) | np.isnan(oldx) | np.isnan(oldg)
+    out = np.full(newx.shape, np.nan, oldy.dtype)
+    if mask_new.all() or mask_old.all():
+        return out
+    out[~mask_new] = griddata((oldx[~mask_old], oldg[~mask_old]), oldy[~mask_old], (newx[~mask_new], newg[~mask_new]), method=method)
+    if method == "nearest" or extrap != "nan":
+        def first_last(arr):
+            fl = np.full((arr.shape[0], 2), np.nan)
+            for i, row in enumerate(arr):
+                ok = np.nonzero(~np.isnan(row))[0]
+                if ok.size:
+                    fl[i] = row[ok[[0, -1]]]
+            return fl
+
+        bnds, xp = first_last(oldx), oldg[:, 0]
+        toolow = newx < np.interp(newg, xp, bnds[:, 0])
+        toohigh = newx > np.interp(newg, xp, bnds[:, 1])
+        if extrap == "constant":
+            cst = first_last(oldy)
+            out[toolow] = np.interp(newg, xp, cst[:, 0])[toolow]
+            out[toohigh] = np.interp(newg, xp, cst[:, 1])[toohigh]
+        else:
+            out[toolow] = np.nan
+            out[toohigh] = np.nan
+    return out

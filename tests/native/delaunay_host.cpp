@@ -1,0 +1,26 @@
+// Host build of xsdba_amd/csrc/delaunay.hpp for tests/test_delaunay_host.py (checked against scipy there).
+// Test infrastructure only: the product runs this header on the GPU (k_lin2d_build / k_lin2d_adjust).
+#include <math.h>
+#include <stdint.h>
+#include <vector>
+#define XS_HD inline
+#include "../../xsdba_amd/csrc/delaunay.hpp"
+
+extern "C" int dt_host_build(int n, const double *px, const double *py, uint16_t *tv, uint16_t *tn)
+{
+    std::vector<uint16_t> hn(n), hp(n), ht(n);
+    xs::Tri2D d{px, py, tv, tn, hn.data(), hp.data(), ht.data(), n, 0};
+    return xs::dt_build(d);
+}
+
+extern "C" void dt_host_eval(int n, const double *px, const double *py, const double *val, int ntri, uint16_t *tv,
+                             uint16_t *tn, int nq, const double *qx, const double *qy, double *out)
+{
+    xs::Tri2D d{px, py, tv, tn, nullptr, nullptr, nullptr, n, ntri};
+    int t = 0;
+    for (int i = 0; i < nq; i++) {
+        const int f = xs::dt_locate(d, qx[i], qy[i], t);
+        out[i] = f < 0 ? NAN : xs::dt_eval(d, val, f, qx[i], qy[i]);
+        if (f >= 0) t = f;
+    }
+}

@@ -270,14 +270,17 @@ def eqm_train(ds, *, dim, kind, quantiles, adapt_freq_thresh=None, jitter_under_
     return Dataset({"af": af, "hist_q": hist_q, "hist_q_raw": hist_q_raw})
 
 
-def _prep_adjust(ds, group: Grouper, interp: str):
+def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     _check_group(group, ds)
     if interp not in ("nearest", "linear", "cubic"):
         raise ValueError(f"interp must be 'nearest', 'linear' or 'cubic', got {interp!r}")
-    if interp == "cubic" or (interp != "nearest" and group.prop != "group"):
+    if interp == "cubic" or (interp != "nearest" and group.prop != "group" and not grouped_linear):
         raise NotImplementedError(
-            f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path: the reference routes it "
-            "through scipy.griddata's Qhull triangulation (utils.py:391-396); use interp='nearest' (its default)"
+            f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path"
+            + (": on the regular (quantile, group) grid of QDM every cell of the grid is a cocircular quadruple, so the "
+               "Qhull triangulation behind scipy.griddata (utils.py:391-396) picks its diagonals arbitrarily and the "
+               "reference's values are not reproducible; use interp='nearest' (its default)" if interp == "linear" else
+               ": the reference routes it through scipy.griddata's Clough-Tocher interpolant (utils.py:391-396); use 'nearest' or 'linear'")
         )
     sim = as_dataarray(ds["sim"])
     dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
@@ -287,6 +290,19 @@ def _prep_adjust(ds, group: Grouper, interp: str):
     s2, cell_dims, cell_shape = cell_time_view(sim.astype(dt) if sim.dtype != dt else sim, group.dim)
     gidx, G = group.group_index(sim)
     return sim, s2, gidx, G, cell_dims, cell_shape, dt
+
+
+def _linear_group_coords(group: Grouper, sim: DataArray):
+    """What utils.interp_on_quantiles (utils.py:476-489) hands to griddata next to the values: the coordinates of the table
+    rows wrapped with add_cyclic_bounds(cyclic_coords=False) (:284-314; seasons as 0..3, :403-405) and the fractional group
+    coordinate of every time step, Grouper.get_index(interp=True) (base.py:308-320)."""
+    crd = np.asarray(group.get_coordinate(sim).values)
+    if group.prop == "season":
+        crd = np.arange(4)
+    crd = crd.astype(np.float64)
+    gcoord = np.concatenate([[crd[0] - (crd[1] - crd[0])], crd, [crd[-1] + (crd[-1] - crd[-2])]])
+    newg = np.asarray(group.get_index(sim, interp=True).values, np.float64)
+    return gcoord, newg
 
 
 def _n_pooled(group: Grouper, cell_dims, cell_shape):
@@ -317,6 +333,12 @@ def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cel
     return hip.tail_mask(s2, np.ascontiguousarray(scen), hq_raw, gidx if G > 1 else None, max_tail_factor)
 
 
+def _no_linear_tail_mask(group, max_tail_factor):
+    if max_tail_factor is not None and group.prop != "dayofyear":
+        raise NotImplementedError("max_tail_factor with a grouped interp='linear' is not implemented on the HIP path (the "
+                                  "reference then broadcasts the last raw quantile linearly between groups, _adjustment.py:650-657)")
+
+
 def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=None):
     coords = {k: c for k, c in sim.coords.items() if k in cell_dims or k == dim}
     return DataArray(arr.reshape(cell_shape + (arr.shape[-1],)), cell_dims + (dim,), coords, attrs or {}, name)
@@ -325,11 +347,16 @@ def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=No
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[])
 def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """QM (DQM and EQM): adjust step on one block (_adjustment.py:594-676)."""
-    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
-    scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
+    if interp == "linear" and G > 1:
+        _no_linear_tail_mask(group, max_tail_factor)
+        gcoord, newg = _linear_group_coords(group, sim)
+        scen = hip.qm_adjust_linear2d(s2, af, hq, gcoord, newg, extrapolation, kind)
+    else:
+        scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
@@ -364,14 +391,25 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
         raise NotImplementedError("dqm_adjust on the HIP path supports polynomial detrending (an int degree) only")
     if degree not in (0, 1):
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0 or 1)")
-    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     tnum = group._time_index(sim).numeric_ns
     P = _n_pooled(group, cell_dims, cell_shape)
-    if P > 1:
+    if interp == "linear" and G > 1:
+        # the scaling is broadcast linearly between the group centres too, except on day-of-year groups (:748-757); then
+        # fit / detrend / grouped-linear mapping / retrend (:759-773) as separate device steps
+        _no_linear_tail_mask(group, max_tail_factor)
+        if P > 1:
+            raise NotImplementedError("dqm_adjust with `add_dims` and a grouped interp='linear' is not implemented on the HIP path")
+        g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, "linear" if group.prop != "dayofyear" else "nearest")
+        scaled = hip.scaling_adjust(s2, sc, g_lo, kind, g_hi=g_hi, frac=frac)
+        trend = hip.polydetrend_trend(scaled, gidx, G, group.window, tnum, degree)
+        gcoord, newg = _linear_group_coords(group, sim)
+        scen = hip.qm_adjust_linear2d(scaled, af, hq, gcoord, newg, extrapolation, kind, trend=trend)
+    elif P > 1:
         trend_in = _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
     else:

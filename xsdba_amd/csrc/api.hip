@@ -16,6 +16,7 @@
 
 #include "../../include/xsdba_hip.h"
 #include "kernels.hpp"
+#include "lin2d.hpp"
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
 #include "train_long.hpp"
@@ -631,6 +632,59 @@ int qm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, in
                                   (R *)o.kernel_dst, (int *)on.dev, nullptr, nullptr))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C)) || (rc = finish_out(ctx, &on))) return rc;
     return sync_if(ctx, o.copy_back || on.copy_back || !is_device_ptr(sim));
+}
+
+// grouped interp="linear": Delaunay triangulation of every cell's table nodes + piecewise-linear evaluation (lin2d.hpp)
+template <typename R>
+int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
+                            const void *hq, int G, int Q, const double *gcoord, const double *newg, int extrap, char kind,
+                            const void *trend, void *scen, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || T <= 0 || Q <= 0 || G < 2 || !af || !hq || !scen || !gcoord || !newg) return fail(XSDBA_E_ARG, "null/empty argument");
+    if ((int64_t)(G + 2) * Q > 32000) return fail(XSDBA_E_UNSUPPORTED, "more than 32000 table nodes per cell (%d groups x %d quantiles)", G, Q);
+    int rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
+    const size_t tab = (size_t)C * G * Q * sizeof(R);
+    const void *daf, *dhq, *dgc, *dng, *dtr = nullptr;
+    if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq)) ||
+        (rc = stage_in(ctx, S_Q, gcoord, sizeof(double) * (size_t)(G + 2), &dgc)) ||
+        (rc = stage_in(ctx, S_TAB2, newg, sizeof(double) * (size_t)T, &dng))) return rc;
+    if (trend && (rc = stage_in(ctx, S_OUT1, trend, (size_t)T * C * sizeof(R), &dtr))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
+    const xs::Lin2DLayout L = xs::lin2d_layout(G, Q);
+    // cells in chunks so that the triangulations of a chunk take at most ~2 GiB of scratch
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(C, (int64_t)((2ull << 30) / L.total)));
+    void *scratch;
+    if ((rc = ensure(ctx, S_SCR, L.total * (size_t)chunk, &scratch))) return rc;
+    const int use_lds = L.staged <= 64 * 1024 ? 1 : 0;
+    if (use_lds && (rc = set_lds(xs::k_lin2d_adjust<R, true>, L.staged, ctx, "the triangulated table"))) return rc;
+    for (int64_t c0 = 0; c0 < C; c0 += chunk) {
+        const int64_t nc = std::min<int64_t>(chunk, C - c0);
+        {
+            LaunchScope ls(ctx, "k_lin2d_build");
+            hipLaunchKernelGGL(xs::k_lin2d_build<R>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream,
+                               (const R *)dhq + (size_t)c0 * G * Q, (const R *)daf + (size_t)c0 * G * Q, (const double *)dgc, G, Q, nc,
+                               (unsigned char *)scratch, L.total);
+        }
+        if ((rc = check_launch("k_lin2d_build"))) return rc;
+        {
+            LaunchScope ls(ctx, "k_lin2d_adjust");
+            const unsigned nblk = (unsigned)std::min<int64_t>(nc, 8 * ctx->n_cu);
+            auto launch = [&](auto k, size_t lds) {
+                hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, ctx->stream, (const R *)s.dev + c0 * s.sc, T, nc, s.sc,
+                                   (const double *)dng, (const double *)dgc, G, Q, (const unsigned char *)scratch, L.total, extrap,
+                                   (int)kind, dtr ? (const R *)dtr + (size_t)c0 * T : (const R *)nullptr,
+                                   (R *)o.kernel_dst + (size_t)c0 * T, T);
+            };
+            if (use_lds) launch(xs::k_lin2d_adjust<R, true>, L.staged);
+            else launch(xs::k_lin2d_adjust<R, false>, 0);
+        }
+        if ((rc = check_launch("k_lin2d_adjust"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, true);
 }
 
 template <typename R>
@@ -1380,6 +1434,17 @@ API int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int6
     if (rc || (rc = check_kind(kind, true))) return rc;
     return DISPATCH(dtype, (qm_adjust_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, gidx, interp, extrap, kind, scen, ost, osc, node_index)),
                     (qm_adjust_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, gidx, interp, extrap, kind, scen, ost, osc, node_index)));
+}
+
+API int xsdba_hip_qm_adjust_linear2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                     const void *af, const void *hist_q, int32_t G, int32_t Q, const double *group_coord,
+                                     const double *new_group, int extrap, char kind, const void *trend, void *scen, int64_t ost,
+                                     int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, trend == nullptr))) return rc;
+    return DISPATCH(dtype, (qm_adjust_linear2d_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, scen, ost, osc)),
+                    (qm_adjust_linear2d_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, scen, ost, osc)));
 }
 
 API int xsdba_hip_dqm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

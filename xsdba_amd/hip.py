@@ -171,6 +171,31 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
     return (scen, node) if return_nodes else scen
 
 
+def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, ctx=None):
+    """qm_adjust with grouped interp="linear" (utils._interp_on_quantiles_2d through scipy.griddata, utils.py:380-400) -> scen
+    [C, T].  ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the
+    fractional group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping."""
+    ctx = ctx or default_context()
+    s = _Series(sim)
+    G, Q = (af.shape[1], af.shape[2])
+    af = _table(af, s.dtype, (s.C, G, Q))
+    hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
+    gc = np.ascontiguousarray(group_coord, np.float64)
+    ng = np.ascontiguousarray(new_group, np.float64)
+    if gc.shape != (G + 2,) or ng.shape != (s.T,):
+        raise ValueError(f"group_coord must have shape ({G + 2},) and new_group ({s.T},)")
+    if trend is not None:
+        trend = trend if isinstance(trend, DeviceArray) else np.ascontiguousarray(trend, s.dtype)
+        if tuple(trend.shape) != (s.C, s.T):
+            raise ValueError(f"trend must have shape {(s.C, s.T)}")
+    scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_qm_adjust_linear2d(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                              _vp(af), _vp(hist_q), C.c_int(G), C.c_int(Q), _vp(gc), _vp(ng), C.c_int(EXTRAP[extrap]),
+                                              C.c_char(kind.encode() if kind else b"\0"), _vp(trend), _vp(scen), _i64(1), _i64(s.T)),
+          "qm_adjust_linear2d")
+    return scen
+
+
 def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
                ctx=None, out=None, trend_in=None):
     """_adjustment.dqm_adjust -> (scen, trend) each [C, T].  ``trend_in`` ([C, T]): use this trend instead of fitting one
@@ -372,5 +397,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "loci_train", "loci_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "qm_adjust_linear2d", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "loci_train", "loci_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]

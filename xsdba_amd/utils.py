@@ -105,9 +105,9 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
                         extrapolation: str = "constant"):
     """Interpolate values of yq on new values of x (utils.py:408-513).
 
-    Ungrouped: 1-D scipy-interp1d semantics ('nearest' | 'linear').  Grouped: the reference's 2-D griddata
-    path; only ``method="nearest"`` (true 2-D nearest neighbour) is implemented on the device — 'linear' /
-    'cubic' go through a Qhull triangulation in the reference and raise NotImplementedError here.
+    Ungrouped: 1-D scipy-interp1d semantics ('nearest' | 'linear').  Grouped: the reference's 2-D griddata path:
+    ``method="nearest"`` (true 2-D nearest neighbour) and ``"linear"`` (Delaunay triangulation of every cell's nodes +
+    piecewise-linear interpolant, csrc/lin2d.hpp); 'cubic' (Clough-Tocher in the reference) raises NotImplementedError.
     """
     newx, xq, yq = as_dataarray(newx), as_dataarray(xq), as_dataarray(yq)
     dim, prop = group.dim, group.prop
@@ -123,9 +123,6 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
         yt = table_view(yq.expand_dims(group=[1]), cell_dims, "group")
         gidx = None
     else:
-        if method != "nearest":
-            raise NotImplementedError("grouped interp_on_quantiles is implemented for method='nearest' only "
-                                      "(the reference's 'linear'/'cubic' use scipy.griddata's Qhull triangulation)")
         crd = group.get_coordinate(newx)
         if prop not in xq.dims:
             xq = xq.expand_dims({prop: crd.values})
@@ -139,6 +136,15 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
         xt, yt = table_view(xq, cell_dims, prop), table_view(yq, cell_dims, prop)
         gidx, _ = group.group_index(newx)
     dt = np.result_type(yt.dtype, np.float32)
+    if gidx is not None and method == "linear":
+        # the reference's griddata path: Delaunay triangulation of the (xq, group coordinate) nodes per cell (csrc/lin2d.hpp)
+        c = (np.arange(4) if prop == "season" else np.asarray(crd.values)).astype(np.float64)
+        gcoord = np.concatenate([[c[0] - (c[1] - c[0])], c, [c[-1] + (c[-1] - c[-2])]])
+        newg = np.asarray(group.get_index(newx, interp=True).values, np.float64)
+        out = hip.qm_adjust_linear2d(x2.astype(dt, copy=False), yt.astype(dt, copy=False), xt.astype(dt, copy=False), gcoord, newg,
+                                     extrapolation, kind=None)
+        coords = {k: c_ for k, c_ in newx.coords.items() if k in cell_dims or k == dim}
+        return DataArray(out.reshape(cell_shape + (out.shape[-1],)), cell_dims + (dim,), coords)
     out = hip.qm_adjust(x2.astype(dt, copy=False), yt.astype(dt, copy=False), xt.astype(dt, copy=False), gidx, method,
                         extrapolation, kind=None)
     coords = {k: c for k, c in newx.coords.items() if k in cell_dims or k == dim}
