@@ -6,11 +6,18 @@
 #define XS_HD inline
 #include "../../xsdba_amd/csrc/delaunay.hpp"
 
-extern "C" int dt_host_build(int n, const double *px, const double *py, uint16_t *tv, uint16_t *tn)
+extern "C" int dt_host_build(int n, const double *px, const double *py, uint16_t *tv, uint16_t *tn, int row_order)
 {
-    std::vector<uint16_t> hn(n), hp(n), ht(n);
+    std::vector<uint16_t> hn(n), hp(n), ht(n), ord(n);
     xs::Tri2D d{px, py, tv, tn, hn.data(), hp.data(), ht.data(), n, 0};
-    return xs::dt_build(d);
+    if (row_order) {  // the storage order (row by row) is a valid sweep too
+        for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
+    } else {
+        xs::dt_sort_order(d, ord.data());
+        for (int i = 0; i + 1 < n; i++)
+            if (xs::dt_before(d, ord[i + 1], ord[i])) return -1;  // the order must ascend
+    }
+    return xs::dt_build(d, ord.data());
 }
 
 extern "C" void dt_host_eval(int n, const double *px, const double *py, const double *val, int ntri, uint16_t *tv,

@@ -22,12 +22,12 @@ def lib(tmp_path_factory):
     return C.CDLL(str(out))
 
 
-def build(lib, px, py):
+def build(lib, px, py, row_order=0):
     n = len(px)
     tv = np.zeros(6 * n, np.uint16)
     tn = np.zeros(6 * n, np.uint16)
     nt = lib.dt_host_build(C.c_int(n), px.ctypes.data_as(C.c_void_p), py.ctypes.data_as(C.c_void_p), tv.ctypes.data_as(C.c_void_p),
-                           tn.ctypes.data_as(C.c_void_p))
+                           tn.ctypes.data_as(C.c_void_p), C.c_int(row_order))
     return nt, tv, tn
 
 
@@ -41,12 +41,13 @@ def table_nodes(rng, rows, Q, spread=1.0, dtype=np.float32):
     return np.concatenate(xs_), np.concatenate(ys_)
 
 
+@pytest.mark.parametrize("row_order", [0, 1])
 @pytest.mark.parametrize("rows,Q,spread", [(14, 20, 1.0), (14, 50, 0.2), (6, 15, 3.0), (3, 4, 1.0), (40, 20, 1.0), (14, 1, 1.0), (2, 5, 1.0)])
-def test_triangles_match_qhull(lib, rows, Q, spread):
+def test_triangles_match_qhull(lib, rows, Q, spread, row_order):
     rng = np.random.default_rng(rows * 100 + Q)
     for rep in range(5):
         px, py = table_nodes(rng, rows, Q, spread)
-        nt, tv, tn = build(lib, px, py)
+        nt, tv, tn = build(lib, px, py, row_order)
         pts = np.c_[px, py]
         if rows >= 2 and len(px) >= 3 and len(np.unique(py)) > 1:
             ref = Delaunay(pts)

@@ -5,9 +5,8 @@
 // position is unique, so any exact construction gives Qhull's triangles; cocircular quadruples (where Qhull's choice is
 // arbitrary) differ at most in which diagonal splits the quad.
 //
-// Construction: the nodes arrive sorted by (row, x) — rows are the group coordinate, x ascending inside a row (quantiles)
-// — so every new node lies outside the hull of the earlier ones: sweep-hull insertion (fan to the visible hull edges)
-// followed by Lawson flips.  One thread builds one cell; all loops are bounded.  Plain C++ (no HIP constructs beyond the
+// Construction: the nodes are inserted in (x, y) order, so every new node lies outside the hull of the earlier ones:
+// sweep-hull insertion (fan to the visible hull edges) followed by Lawson flips.  One thread builds one cell; all loops are bounded.  Plain C++ (no HIP constructs beyond the
 // XS_HD qualifier) so that the same source is exercised on the CPU by tests/test_delaunay_host.py against scipy.
 #pragma once
 #include <math.h>
@@ -23,7 +22,7 @@ constexpr uint16_t DT_NONE = 0xFFFFu;
 
 // storage of one cell's triangulation (caller-provided; n nodes, at most 2 n triangles)
 struct Tri2D {
-    const double *px, *py;  // [n] node coordinates, sorted by (py, px), no exact duplicates
+    const double *px, *py;  // [n] node coordinates, no exact duplicates (stored row by row; inserted in (x, y) order)
     uint16_t *tv;           // [3 * 2n] triangle vertices, counter-clockwise
     uint16_t *tn;           // [3 * 2n] neighbour across the edge opposite each vertex (DT_NONE on the hull)
     uint16_t *hnext, *hprev, *htri;  // [n] hull as a counter-clockwise ring of vertices; htri[v]: triangle on edge v -> hnext[v]
@@ -92,38 +91,67 @@ XS_HD void dt_legalize(Tri2D &d, int t0, int i0, int &flip_budget)
     }
 }
 
-// Build the triangulation.  Returns the number of triangles (0: fewer than 3 nodes or all collinear).
-XS_HD int dt_build(Tri2D &d)
+// insertion order: the nodes sorted by (x, y) — an in-place heapsort of the index array (one thread, no recursion)
+XS_HD bool dt_before(const Tri2D &d, int a, int b) { return d.px[a] < d.px[b] || (d.px[a] == d.px[b] && d.py[a] < d.py[b]); }
+
+XS_HD void dt_sort_order(const Tri2D &d, uint16_t *ord)
+{
+    const int n = d.n;
+    for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
+    auto sift = [&](int root, int end) {
+        const uint16_t v = ord[root];
+        for (;;) {
+            int child = 2 * root + 1;
+            if (child >= end) break;
+            if (child + 1 < end && dt_before(d, ord[child], ord[child + 1])) child++;
+            if (!dt_before(d, v, ord[child])) break;
+            ord[root] = ord[child];
+            root = child;
+        }
+        ord[root] = v;
+    };
+    for (int i = n / 2 - 1; i >= 0; i--) sift(i, n);
+    for (int end = n - 1; end > 0; end--) {
+        const uint16_t t = ord[0]; ord[0] = ord[end]; ord[end] = t;
+        sift(0, end);
+    }
+}
+
+// Build the triangulation, inserting the nodes in the order `ord` (sorted by (x, y): every node then lies outside the hull
+// of the earlier ones, and sees only a few edges of its right-hand side — sweeping row by row instead would fan every
+// first node of a row to the whole row below, O(Q^2) flips per row).  Returns the number of triangles (0: fewer than 3
+// nodes or all collinear).
+XS_HD int dt_build(Tri2D &d, const uint16_t *ord)
 {
     const int n = d.n;
     d.ntri = 0;
     if (n < 3) return 0;
-    // ---- the collinear prefix
+    // ---- the collinear prefix c_0 .. c_{m-1} = ord[0 .. m)
     int m = 2;
-    while (m < n && dt_orient(d, 0, 1, m) == 0.0) m++;
+    while (m < n && dt_orient(d, ord[0], ord[1], ord[m]) == 0.0) m++;
     if (m == n) return 0;
-    const int p0 = m;  // first node off the line
-    const bool left = dt_orient(d, 0, m - 1, p0) > 0.0;
+    const int p0 = ord[m];  // first node off the line
+    const bool left = dt_orient(d, ord[0], ord[m - 1], p0) > 0.0;
     for (int i = 0; i + 1 < m; i++) {
         const int nb_next = i + 2 < m ? i + 1 : DT_NONE, nb_prev = i > 0 ? i - 1 : DT_NONE;
-        if (left) dt_set(d, i, i, i + 1, p0, nb_next, nb_prev, DT_NONE);       // (c_i, c_i+1, p): opp c_i = edge (c_i+1, p)
-        else dt_set(d, i, i + 1, i, p0, nb_prev, nb_next, DT_NONE);            // (c_i+1, c_i, p): opp c_i+1 = edge (c_i, p)
+        if (left) dt_set(d, i, ord[i], ord[i + 1], p0, nb_next, nb_prev, DT_NONE);  // (c_i, c_i+1, p): opp c_i = edge (c_i+1, p)
+        else dt_set(d, i, ord[i + 1], ord[i], p0, nb_prev, nb_next, DT_NONE);       // (c_i+1, c_i, p): opp c_i+1 = edge (c_i, p)
     }
     d.ntri = m - 1;
     if (left) {  // ring c0 -> c1 -> ... -> c_{m-1} -> p -> c0
-        for (int i = 0; i + 1 < m; i++) { d.hnext[i] = (uint16_t)(i + 1); d.hprev[i + 1] = (uint16_t)i; d.htri[i] = (uint16_t)i; }
-        d.hnext[m - 1] = (uint16_t)p0; d.hprev[p0] = (uint16_t)(m - 1); d.htri[m - 1] = (uint16_t)(m - 2);
-        d.hnext[p0] = 0; d.hprev[0] = (uint16_t)p0; d.htri[p0] = 0;
+        for (int i = 0; i + 1 < m; i++) { d.hnext[ord[i]] = ord[i + 1]; d.hprev[ord[i + 1]] = ord[i]; d.htri[ord[i]] = (uint16_t)i; }
+        d.hnext[ord[m - 1]] = (uint16_t)p0; d.hprev[p0] = ord[m - 1]; d.htri[ord[m - 1]] = (uint16_t)(m - 2);
+        d.hnext[p0] = ord[0]; d.hprev[ord[0]] = (uint16_t)p0; d.htri[p0] = 0;
     } else {     // ring c_{m-1} -> ... -> c0 -> p -> c_{m-1}
-        for (int i = m - 1; i > 0; i--) { d.hnext[i] = (uint16_t)(i - 1); d.hprev[i - 1] = (uint16_t)i; d.htri[i] = (uint16_t)(i - 1); }
-        d.hnext[0] = (uint16_t)p0; d.hprev[p0] = 0; d.htri[0] = 0;
-        d.hnext[p0] = (uint16_t)(m - 1); d.hprev[m - 1] = (uint16_t)p0; d.htri[p0] = (uint16_t)(m - 2);
+        for (int i = m - 1; i > 0; i--) { d.hnext[ord[i]] = ord[i - 1]; d.hprev[ord[i - 1]] = ord[i]; d.htri[ord[i]] = (uint16_t)(i - 1); }
+        d.hnext[ord[0]] = (uint16_t)p0; d.hprev[p0] = ord[0]; d.htri[ord[0]] = 0;
+        d.hnext[p0] = ord[m - 1]; d.hprev[ord[m - 1]] = (uint16_t)p0; d.htri[p0] = (uint16_t)(m - 2);
     }
     int flip_budget = 32 * n;
-    for (int i = 0; i + 1 < m; i++) dt_legalize(d, i, 2, flip_budget);  // nothing to flip yet; keeps the invariant explicit
     int last = p0;
     // ---- sweep: every further node is outside the hull of the earlier ones
-    for (int p = p0 + 1; p < n; p++) {
+    for (int k = m + 1; k < n; k++) {
+        const int p = ord[k];
         // a visible hull edge (p strictly to its right), searching from the previous node
         int a = last, steps = 0;
         bool found = false;
@@ -137,7 +165,7 @@ XS_HD int dt_build(Tri2D &d)
             a = d.hnext[a];
             steps++;
         }
-        if (!found) { last = p; d.hnext[p] = (uint16_t)p; d.hprev[p] = (uint16_t)p; d.htri[p] = DT_NONE; continue; }  // cannot happen for sorted input
+        if (!found) continue;  // cannot happen for sorted, duplicate-free input; the node is then left out
         // extend the visible chain backwards and forwards
         int first = a;
         for (steps = 0; steps <= n; steps++) {
@@ -163,9 +191,9 @@ XS_HD int dt_build(Tri2D &d)
             if (prev_t != DT_NONE) d.tn[3 * prev_t + 1] = (uint16_t)t;
             if (old != DT_NONE) {
                 // in `old` the edge v -> w is the one without a neighbour among those containing v and w
-                for (int k = 0; k < 3; k++) {
-                    const int o1 = d.tv[3 * old + (k + 1) % 3], o2 = d.tv[3 * old + (k + 2) % 3];
-                    if (o1 == v && o2 == w) d.tn[3 * old + k] = (uint16_t)t;
+                for (int kk = 0; kk < 3; kk++) {
+                    const int o1 = d.tv[3 * old + (kk + 1) % 3], o2 = d.tv[3 * old + (kk + 2) % 3];
+                    if (o1 == v && o2 == w) d.tn[3 * old + kk] = (uint16_t)t;
                 }
             }
             prev_t = t;

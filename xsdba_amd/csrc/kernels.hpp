@@ -293,28 +293,43 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
         const R *scal = DQM ? scaling + (size_t)c * G : nullptr;
         const R *trc = DQM ? trend + (size_t)c * T : nullptr;
         int *ndc = node ? node + (size_t)c * T : nullptr;
-        for (int t = threadIdx.x; t < Ti; t += blockDim.x) {
-            R v = x[t];
-            const int g0 = (GROUPED || DQM) ? gidx[t] : 0;
-            R tr = (R)0;
-            if constexpr (DQM) {
-                R s = g0 >= 0 ? scal[g0] : nan_of<R>();
-                v = apply_corr<R>(v, s, kind);
-                tr = trc[t];
-                v = apply_corr<R>(v, invert<R>(tr, kind), kind);
+        // EU elements per thread and round: their table searches are independent chains of LDS reads
+        constexpr int EU = DQM ? 1 : 4;
+        for (int t0 = threadIdx.x; t0 < Ti; t0 += EU * blockDim.x) {
+            R v[EU], tr[EU], a[EU];
+            int g0[EU], nd[EU];
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                const int t = min(t0 + e * (int)blockDim.x, Ti - 1);
+                v[e] = x[t];
+                g0[e] = (GROUPED || DQM) ? gidx[t] : 0;
+                tr[e] = (R)0;
+                if constexpr (DQM) {
+                    R s = g0[e] >= 0 ? scal[g0[e]] : nan_of<R>();
+                    v[e] = apply_corr<R>(v[e], s, kind);
+                    tr[e] = trc[t];
+                    v[e] = apply_corr<R>(v[e], invert<R>(tr[e], kind), kind);
+                }
             }
-            int nd;
-            R a;
-            if constexpr (GROUPED) {
-                if (g0 < 0) { nd = -1; a = nan_of<R>(); }
-                else a = interp2d_nearest<R, R>(v, g0, ct, extrap, nd);
-            } else {
-                a = interp1d_eval<R>((double)v, false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd);
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                if constexpr (GROUPED) {
+                    if (g0[e] < 0) { nd[e] = -1; a[e] = nan_of<R>(); }
+                    else a[e] = interp2d_nearest<R, R>(v[e], g0[e], ct, extrap, nd[e]);
+                } else {
+                    a[e] = interp1d_eval<R>((double)v[e], false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd[e]);
+                }
             }
-            R y = kind ? apply_corr<R>(v, a, kind) : a;
-            if constexpr (DQM) y = apply_corr<R>(y, tr, kind);
-            o[t] = y;
-            if (ndc) ndc[t] = nd;
+#pragma unroll
+            for (int e = 0; e < EU; e++) {
+                const int t = t0 + e * (int)blockDim.x;
+                if (t < Ti) {
+                    R y = kind ? apply_corr<R>(v[e], a[e], kind) : a[e];
+                    if constexpr (DQM) y = apply_corr<R>(y, tr[e], kind);
+                    o[t] = y;
+                    if (ndc) ndc[t] = nd[e];
+                }
+            }
         }
         __syncthreads();  // everyone is done with the table before the next cell overwrites it
     }

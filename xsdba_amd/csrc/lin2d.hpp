@@ -34,7 +34,7 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
     L.rowb = o; o += sizeof(int) * (size_t)(G + 3);            // first node of every cyclic row
     o = (o + 7) & ~(size_t)7;
     L.staged = o;
-    L.hull = o; o += sizeof(uint16_t) * 3 * N;
+    L.hull = o; o += sizeof(uint16_t) * 4 * N;  // hull ring (3N) + insertion order (N): build only
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -85,7 +85,12 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     d.ntri = 0;
     rowb[G + 2] = n;
     hdr[0] = n;
-    const int ntri = dt_build(d);
+    uint16_t *ord = d.htri + (size_t)(G + 2) * Q;
+    // insertion order: by (x, y) for short tables (monthly, seasonal: 28.7 vs 74 ms per 64800 cells); row by row — the storage
+    // order, also a valid sweep — for tall ones (day-of-year: 367 rows make the x-sweep's front long; 0.58 vs 2.3 s per 8192)
+    if (G + 2 <= 32) dt_sort_order(d, ord);
+    else for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
+    const int ntri = dt_build(d, ord);
     hdr[1] = ntri;
     uint16_t *vt = reinterpret_cast<uint16_t *>(base + L.vt);
     for (int i = 0; i < n; i++) vt[i] = 0;
