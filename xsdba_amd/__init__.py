@@ -28,3 +28,4 @@ from .calendar import TimeIndex, date_range  # noqa: E402,F401
 from .detrending import PolyDetrend  # noqa: E402,F401
 from .labeled import DataArray, Dataset, as_dataarray  # noqa: E402,F401
 from .options import set_options  # noqa: E402,F401
+from .io import open_dataset, to_netcdf  # noqa: E402,F401

@@ -222,6 +222,12 @@ class DataArray:
             return DataArray(self.values, dims, coords, self.attrs, self.name)
         return DataArray(self.values, self.dims, self.coords, self.attrs, name)
 
+    def to_netcdf(self, path):
+        """NetCDF-3 file readable by xarray (xsdba_amd/io.py)"""
+        from .io import to_netcdf
+
+        to_netcdf(self, path)
+
     def to_dataset(self, name=None):
         nm = name or self.name
         if nm is None:
@@ -449,6 +455,12 @@ class Dataset:
     @property
     def chunks(self):
         return None
+
+    def to_netcdf(self, path):
+        """NetCDF-3 file readable by xarray (xsdba_amd/io.py); the reference's ``obj.ds.to_netcdf(file)``"""
+        from .io import to_netcdf
+
+        to_netcdf(self, path)
 
     def assign(self, variables=None, **kw):
         out = Dataset(self.data_vars, self.coords, self.attrs)
