@@ -46,14 +46,16 @@ extern "C" {
 enum { XSDBA_F32 = 0, XSDBA_F64 = 1 };
 enum { XSDBA_INTERP_NEAREST = 0, XSDBA_INTERP_LINEAR = 1 };
 enum { XSDBA_EXTRAP_CONSTANT = 0, XSDBA_EXTRAP_NAN = 1 };
-/* `degree` of xsdba_hip_dqm_adjust: the trend was fitted by the caller and `trend` is an INPUT */
-enum { XSDBA_TREND_GIVEN = -1 };
+/* `degree` of xsdba_hip_dqm_adjust: the trend was fitted by the caller and `trend` is an INPUT; detrended / retrended with
+ * the kind of the call, or with the detrending object's own kind (detrending.py:102-120), the last one with
+ * mult_skip_zeros (values whose trend is 0 are not divided, :112-113) */
+enum { XSDBA_TREND_GIVEN = -1, XSDBA_TREND_GIVEN_ADD = -2, XSDBA_TREND_GIVEN_MUL = -3, XSDBA_TREND_GIVEN_MUL_SKIP_ZEROS = -4 };
 
 enum {
     XSDBA_E_ARG = -1,          /* bad argument (null pointer, size, dtype, kind, group index out of range) */
     XSDBA_E_NOMEM = -2,        /* host allocation failed */
     XSDBA_E_UNSUPPORTED = -3,  /* e.g. grouped interp="linear"/"cubic" (Qhull in the reference, utils.py:391-396) */
-    XSDBA_E_DEGREE = -4,       /* PolyDetrend degree other than 0 or 1 */
+    XSDBA_E_DEGREE = -4,       /* PolyDetrend degree outside 0..6 */
     XSDBA_E_ROW_TOO_LONG = -5, /* a group row does not fit the LDS sort (see DESIGN.md limits) */
     XSDBA_E_NO_DEVICE = -6     /* no usable gfx950 device / kernel image */
 };
@@ -246,6 +248,15 @@ int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype, in
                                 int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
                                 int32_t window, const double *time_num, int32_t degree, void *trend,
                                 int64_t out_stride_t, int64_t out_stride_c);
+
+/* the same with the remaining options of PolyDetrend: degree 0..6 (least squares per group in the scaled variable
+ * (x - x_mid) / x_halfrange; xarray.polyfit scales the Vandermonde columns and uses LAPACK's SVD — the fitted values agree
+ * to the conditioning error of that route, ~1e-9 relative) and preserve_mean (detrending.py:204-205: the trend of every
+ * group has its mean removed ('+') or divided out ('*')) */
+int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                              int64_t stride_c, const int32_t *group_of_time, int32_t n_groups, int32_t window,
+                              const double *time_num, int32_t degree, int preserve_mean, char kind, void *trend,
+                              int64_t out_stride_t, int64_t out_stride_c);
 
 /* ---- bench / test utility: fill a DEVICE series block with the synthetic cubes of SURVEY §8d.
  * generator 0 = seasonal temperature-like, 1 = gamma precipitation-like; array_id 0/1/2 = ref/hist/sim;

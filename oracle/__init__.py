@@ -343,3 +343,47 @@ def interp_on_quantiles_2d(newx, newg, oldx, oldy, oldg, method="linear", extrap
             out[toolow] = np.nan
             out[toohigh] = np.nan
     return out
+
+
+def polyfit_trend(x, gidx, G, W, time_num, degree, preserve_mean=False, kind="+"):
+    """detrending._polydetrend_get_trend (detrending.py:196-208) for any degree, restated with numpy exactly as
+    xarray.DataArray.polyfit / xr.polyval do it (xarray/core/dataset.py polyfit: Vandermonde matrix of the float64 time axis,
+    columns scaled by their 2-norm, numpy.linalg.lstsq with rcond = n * eps on the non-NaN rows, coefficients / scale;
+    polyval: Horner on the same axis): x [C, T] -> trend [C, T] in x's dtype.  Window means: NaN-skipping mean of the
+    centred window of every time step (rolling.construct + mean(skipna), base.py:261-262)."""
+    x = np.asarray(x)
+    gidx = np.asarray(gidx)
+    tn = np.asarray(time_num, np.float64)
+    C, T = x.shape
+    h = W // 2
+    out = np.full((C, T), np.nan, np.float64)
+    for c in range(C):
+        if W > 1:
+            pad = np.concatenate([np.full(h, np.nan), x[c].astype(np.float64), np.full(h, np.nan)])
+            win = np.lib.stride_tricks.sliding_window_view(pad, W)
+            with np.errstate(invalid="ignore"):
+                cnt = (~np.isnan(win)).sum(1)
+                m = np.where(cnt > 0, np.nansum(win, 1) / np.maximum(cnt, 1), np.nan)
+            m = m.astype(x.dtype).astype(np.float64)  # the mean comes back in the data dtype
+        else:
+            m = x[c].astype(np.float64)
+        for g in range(G):
+            idx = np.nonzero(gidx == g)[0]
+            if idx.size == 0:
+                continue
+            xs_, ys_ = tn[idx], m[idx]
+            ok = ~np.isnan(ys_)
+            if ok.sum() == 0:
+                continue
+            lhs = np.vander(xs_, degree + 1)
+            scale = np.sqrt((lhs * lhs).sum(axis=0))
+            lhs = lhs / scale
+            coef, *_ = np.linalg.lstsq(lhs[ok], ys_[ok], rcond=xs_.shape[0] * np.finfo(np.float64).eps)
+            coef = coef / scale
+            tr = np.zeros(idx.size)
+            for k in range(degree + 1):  # Horner, highest power first (np.vander order)
+                tr = tr * xs_ + coef[k]
+            if preserve_mean:
+                tr = tr - tr.mean() if kind == "+" else tr / tr.mean()
+            out[c, idx] = tr
+    return out.astype(x.dtype)

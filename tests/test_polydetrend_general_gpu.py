@@ -1,0 +1,130 @@
+"""PolyDetrend beyond degree 1 and with its options (detrending.py:165-208 — degree, preserve_mean,
+mult_skip_zeros, a group and kind of its own) against oracle.polyfit_trend, a numpy restatement of xarray's polyfit /
+polyval (scaled Vandermonde + numpy.linalg.lstsq, Horner on the ns-since-1970 axis).  That route loses ~cond * eps to the
+conditioning of the monomial basis, hence the 1e-7 relative tolerance on float64 data."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+import xsdba_amd as xs
+from xsdba_amd import hip
+from xsdba_amd.detrending import PolyDetrend
+from xsdba_amd.labeled import DataArray
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    hip.default_context(0)
+
+
+def cube(values, dims, units="K", calendar="noleap", start="2000-01-01"):
+    values = np.asarray(values)
+    coords = {"time": xs.date_range(start, values.shape[dims.index("time")], calendar).values}
+    for d, n in zip(dims, values.shape):
+        if d != "time":
+            coords[d] = np.arange(n)
+    return DataArray(values, dims, coords, {"units": units})
+
+
+def data(rng, C, T, dtype, nan_frac=0.0):
+    t = np.arange(T) / T
+    x = (280 + 6 * t - 9 * t**2 + 5 * t**3 + 3 * np.cos(2 * np.pi * np.arange(T) / 365) + rng.standard_normal((C, T))).astype(dtype)
+    if nan_frac:
+        x[rng.random((C, T)) < nan_frac] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("group,window", [("time", 1), ("time.dayofyear", 31), ("time.month", 1)])
+@pytest.mark.parametrize("degree", [2, 3, 4, 6])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_trend_matches_xarray_polyfit(group, window, degree, dtype):
+    rng = np.random.default_rng(degree)
+    C, T = 3, 8 * 365
+    x = data(rng, C, T, dtype, nan_frac=0.01)
+    da = cube(x, ("lat", "time"))
+    det = PolyDetrend(group=xs.Grouper(group, window), degree=degree).fit(da)
+    got = det.ds.trend.transpose("lat", "time").values
+    gr = xs.Grouper(group, window)
+    gidx, G = gr.group_index(da)
+    exp = oracle.polyfit_trend(x, gidx, G, window, gr._time_index(da).numeric_ns, degree)
+    assert got.dtype == dtype
+    np.testing.assert_allclose(got, exp, rtol=2e-6 if dtype == np.float32 else 1e-7)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("degree", [1, 3])
+def test_preserve_mean(kind, degree):
+    rng = np.random.default_rng(7)
+    x = data(rng, 2, 6 * 365, np.float64)
+    da = cube(x, ("lat", "time"))
+    gr = xs.Grouper("time.month")
+    det = PolyDetrend(group=gr, degree=degree, kind=kind, preserve_mean=True).fit(da)
+    gidx, G = gr.group_index(da)
+    exp = oracle.polyfit_trend(x, gidx, G, 1, gr._time_index(da).numeric_ns, degree, preserve_mean=True, kind=kind)
+    np.testing.assert_allclose(det.ds.trend.transpose("lat", "time").values, exp, rtol=1e-7, atol=1e-9)
+    # detrending then keeps the mean of the series (the point of the option)
+    dx = det.detrend(da)
+    np.testing.assert_allclose(dx.values.mean(), x.mean(), rtol=2e-3)
+
+
+def test_reference_mult_skip_zeros_case():
+    """reference tests/test_adjustment.py:649-694: sim all zeros, kind="*": the default detrending gives NaN everywhere;
+    detrend=PolyDetrend(mult_skip_zeros=True) — degree 4, group "time", kind "+" by default — returns the zeros"""
+    rng = np.random.default_rng(3)
+    T = 6 * 365
+    mk = lambda a, s: cube(a.astype(np.float64), ("time", "lat"), "mm d-1", "standard", s)  # noqa: E731
+    ref = mk(rng.uniform(0.001, 20, (T, 3)), "1990-01-01")
+    hist = mk(rng.uniform(0.001, 10, (T, 3)), "1990-01-01")
+    sim = mk(np.zeros((T, 3)), "2021-01-01")
+    dqm = xs.DetrendedQuantileMapping.train(ref, hist, kind="*", group="time")
+    assert np.isnan(dqm.adjust(sim).values).all()
+    with pytest.warns(UserWarning, match="mult_skip_zeros is only used"):
+        scen = dqm.adjust(sim, detrend=PolyDetrend(mult_skip_zeros=True))
+    assert (scen.transpose("time", "lat").values == sim.values).all()
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_adjust_with_a_detrender_of_its_own(kind):
+    """detrend=PolyDetrend(group="time", degree=3, kind=...) inside a day-of-year DQM: scaling (DQM kind), fit + detrend
+    (detrender's kind), mapping, retrend — composed here from the oracle's pieces"""
+    rng = np.random.default_rng(4)
+    C, T, Q = 2, 6 * 365, 12
+    base = 10 + np.abs(data(rng, C, T, np.float32) - 270)
+    ref, hist, sim = base, (base * 1.1 + 1).astype(np.float32), (base * 1.2 + np.linspace(0, 3, T)[None]).astype(np.float32)
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.dayofyear", 31)
+    dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, kind="*", nquantiles=Q)
+    det = PolyDetrend(group="time", degree=3, kind=kind, mult_skip_zeros=(kind == "*"))
+    got = dqm.adjust(cube(sim, dims), detrend=det).transpose(*dims).values
+    gidx, G = gr.group_index(cube(sim, dims))
+    af = np.ascontiguousarray(dqm.ds.af.transpose("lat", "dayofyear", "quantiles").values)
+    hq = np.ascontiguousarray(dqm.ds.hist_q.transpose("lat", "dayofyear", "quantiles").values)
+    sc = np.ascontiguousarray(dqm.ds.scaling.transpose("lat", "dayofyear").values)
+    scaled = oracle.scaling_adjust(sim, sc, gidx, "*")
+    tnum = gr._time_index(cube(sim, dims)).numeric_ns
+    trend = oracle.polyfit_trend(scaled, np.zeros(T, np.int32), 1, 1, tnum, 3).astype(np.float32)
+    detr = scaled - trend if kind == "+" else scaled * (np.float32(1) / trend)
+    a = oracle.qm_adjust(detr, af, hq, gidx, "nearest", "constant", "*")
+    exp = a + trend if kind == "+" else a * trend
+    np.testing.assert_allclose(got, exp, rtol=3e-5, atol=3e-4)
+
+
+def test_int_degree_above_one_in_dqm():
+    rng = np.random.default_rng(5)
+    C, T = 2, 5 * 365
+    ref, hist, sim = (data(rng, C, T, np.float32) for _ in range(3))
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.dayofyear", 31)
+    dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=10)
+    from xsdba_amd._adjustment import dqm_adjust
+
+    out = dqm_adjust(dqm.ds.assign(sim=cube(sim, dims)), group=gr, interp="nearest", kind="+", extrapolation="constant", detrend=3)
+    gidx, G = gr.group_index(cube(sim, dims))
+    sc = np.ascontiguousarray(dqm.ds.scaling.transpose("lat", "dayofyear").values)
+    scaled = oracle.scaling_adjust(sim, sc, gidx, "+")
+    exp = oracle.polyfit_trend(scaled, gidx, G, 31, gr._time_index(cube(sim, dims)).numeric_ns, 3)
+    np.testing.assert_allclose(out.trend.transpose(*dims).values, exp, rtol=3e-6)

@@ -381,16 +381,18 @@ def _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P):
 def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
     means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device."""
+    own = None  # a PolyDetrend with a group / kind / options of its own: its trend is fitted first and handed to the mapping
     if isinstance(detrend, PolyDetrend):
-        if detrend.group.name != group.name or detrend.group.window != group.window or detrend.kind != kind or detrend.preserve_mean or detrend.mult_skip_zeros:
-            raise NotImplementedError("dqm_adjust on the HIP path takes detrend=<int> or a PolyDetrend on the same group/kind")
         degree = int(detrend.degree)
+        if (detrend.group.name != group.name or detrend.group.window != group.window or detrend.group.add_dims != group.add_dims
+                or detrend.kind != kind or detrend.preserve_mean or detrend.mult_skip_zeros):
+            own = detrend
     elif isinstance(detrend, (int, np.integer)):
         degree = int(detrend)
     else:
-        raise NotImplementedError("dqm_adjust on the HIP path supports polynomial detrending (an int degree) only")
-    if degree not in (0, 1):
-        raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0 or 1)")
+        raise NotImplementedError("dqm_adjust on the HIP path supports polynomial detrending (an int degree or a PolyDetrend) only")
+    if not 0 <= degree <= 6:
+        raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0..6)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
@@ -398,7 +400,19 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     sc = table_view(as_dataarray(ds["scaling"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     tnum = group._time_index(sim).numeric_ns
     P = _n_pooled(group, cell_dims, cell_shape)
-    if interp == "linear" and G > 1:
+    if own is not None:
+        if (interp == "linear" and G > 1) or P > 1 or own.group.add_dims:
+            raise NotImplementedError("a PolyDetrend with its own group / kind / options together with `add_dims` or a grouped "
+                                      "interp='linear' is not implemented on the HIP path")
+        if own.mult_skip_zeros and own.kind != "*":  # detrending.py:107-110
+            warnings.warn(f"mult_skip_zeros is only used for kind='*'. Your kind is {own.kind}. mult_skip_zeros will be ignored.",
+                          UserWarning, stacklevel=2)
+        gidx_d, G_d = own.group.group_index(sim)
+        scaled = hip.scaling_adjust(s2, sc, gidx if G > 1 else None, kind)
+        trend_in = hip.polydetrend_trend(scaled, gidx_d, G_d, own.group.window, tnum, degree, bool(own.preserve_mean), own.kind)
+        scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in,
+                                     trend_kind=own.kind, mult_skip_zeros=bool(own.mult_skip_zeros) and own.kind == "*")
+    elif interp == "linear" and G > 1:
         # the scaling is broadcast linearly between the group centres too, except on day-of-year groups (:748-757); then
         # fit / detrend / grouped-linear mapping / retrend (:759-773) as separate device steps
         _no_linear_tail_mask(group, max_tail_factor)

@@ -576,8 +576,9 @@ inline unsigned trend_threads()
 template <typename R>
 int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *af, const R *hq, int G, int Q,
                      const int *d_gidx, int interp, int extrap, char kind, R *scen_cm, int *node, const R *scaling,
-                     const R *trend_cm)
+                     const R *trend_cm, int tkind = 0, int skip0 = 0)
 {
+    if (!tkind) tkind = (int)kind;
     const size_t tab = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
     const char *name = scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust";
     if (s.st != 1) return fail(XSDBA_E_ARG, "internal: the adjust kernels expect time-contiguous rows");
@@ -590,7 +591,7 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
             LaunchScope ls(ctx, name);
             hipLaunchKernelGGL((xs::k_qm_adjust<R, true, GROUPED, DQM>), dim3((unsigned)C), dim3(adj_threads()), tab, ctx->stream,
                                (const R *)s.dev, T, C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node,
-                               scaling, trend_cm, (unsigned char *)nullptr, (size_t)0);
+                               scaling, trend_cm, (unsigned char *)nullptr, (size_t)0, tkind, skip0);
         } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
             const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
             void *scratch;
@@ -598,7 +599,7 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
             LaunchScope ls(ctx, name);
             hipLaunchKernelGGL((xs::k_qm_adjust<R, false, GROUPED, DQM>), dim3(nblk), dim3(256), 0, ctx->stream, (const R *)s.dev, T,
                                C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node, scaling, trend_cm,
-                               (unsigned char *)scratch, tab);
+                               (unsigned char *)scratch, tab, tkind, skip0);
         }
         return check_launch("k_qm_adjust");
     };
@@ -689,9 +690,10 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
 
 template <typename R>
 int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *scaling, Plan *pl, char kind,
-                 const double *d_tnum, int degree, R *trend_cm)
+                 const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0)
 {
-    const size_t lds1 = sizeof(double) * (3 * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
+    const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
+    const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
     const bool m_lds = getenv("XSDBA_HIP_TREND_MLDS") != nullptr;  // window means in LDS: measured slower (occupancy)
     int rc;
@@ -704,13 +706,13 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean);
     }
     return check_launch("k_group_trend");
 }
@@ -720,9 +722,12 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
                     const void *hq, const void *scaling, int G, int Q, const int32_t *gidx, int W, const double *tnum,
                     int degree, int interp, int extrap, char kind, void *scen, void *trend, int64_t ost, int64_t osc)
 {
-    const bool trend_given = degree == XSDBA_TREND_GIVEN;  // `trend` is an input: the fit was done by the caller
+    // `trend` is an input: the fit was done by the caller (optionally with a kind of its own / mult_skip_zeros)
+    const bool trend_given = degree <= XSDBA_TREND_GIVEN && degree >= XSDBA_TREND_GIVEN_MUL_SKIP_ZEROS;
+    const int tkind = degree == XSDBA_TREND_GIVEN_ADD ? '+' : (degree == XSDBA_TREND_GIVEN_MUL || degree == XSDBA_TREND_GIVEN_MUL_SKIP_ZEROS) ? '*' : (int)kind;
+    const int skip0 = degree == XSDBA_TREND_GIVEN_MUL_SKIP_ZEROS;
     if (C <= 0 || Q <= 0 || !af || !hq || !scaling || !scen || (!tnum && !trend_given)) return fail(XSDBA_E_ARG, "null/empty argument");
-    if (!trend_given && (degree < 0 || degree > 1)) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    if (!trend_given && (degree < 0 || degree > xs::POLY_MAX_DEG)) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0..%d)", degree, xs::POLY_MAX_DEG);
     if (trend_given && (!trend || ost != 1 || osc != T)) return fail(XSDBA_E_ARG, "a given trend must be a contiguous [cell][time] array");
     if (G > 1 && interp != XSDBA_INTERP_NEAREST) return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented");
     int rc;
@@ -750,7 +755,7 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         trend_cm = (const R *)otr.kernel_dst;
     }
     if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
-                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, trend_cm))) return rc;
+                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, trend_cm, tkind, skip0))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
     if (!trend_given && trend && (rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
     return sync_if(ctx, o.copy_back || otr.copy_back || !is_device_ptr(sim) || (tnum && !is_device_ptr(tnum)) || (trend_given && !is_device_ptr(trend)));
@@ -758,10 +763,10 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
 
 template <typename R>
 int trend_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, const int32_t *gidx, int G,
-               int W, const double *tnum, int degree, void *trend, int64_t ost, int64_t osc)
+               int W, const double *tnum, int degree, int preserve_mean, char kind, void *trend, int64_t ost, int64_t osc)
 {
     if (C <= 0 || !trend || !tnum) return fail(XSDBA_E_ARG, "null/empty argument");
-    if (degree < 0 || degree > 1) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0 or 1)", degree);
+    if (degree < 0 || degree > xs::POLY_MAX_DEG) return fail(XSDBA_E_DEGREE, "PolyDetrend degree %d not implemented (0..%d)", degree, xs::POLY_MAX_DEG);
     int rc;
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
@@ -771,7 +776,7 @@ int trend_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t 
     if ((rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
     SeriesOut otr;
     if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc;
-    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, '+', (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, preserve_mean))) return rc;
     if ((rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
     return sync_if(ctx, true);
 }
@@ -1554,8 +1559,18 @@ API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)),
-                    (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, trend, ost, osc)));
+    return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, 0, '+', trend, ost, osc)),
+                    (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, 0, '+', trend, ost, osc)));
+}
+
+API int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                  const int32_t *gidx, int32_t G, int32_t W, const double *time_num, int32_t degree,
+                                  int preserve_mean, char kind, void *trend, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, preserve_mean ? 1 : 0, kind, trend, ost, osc)),
+                    (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, preserve_mean ? 1 : 0, kind, trend, ost, osc)));
 }
 
 API int xsdba_hip_synth_series(xsdba_hip_ctx *ctx, void *dst, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

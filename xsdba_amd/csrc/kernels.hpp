@@ -280,8 +280,11 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                             const R *__restrict__ af, const R *__restrict__ hist_q, int G, int Q,
                             const int *__restrict__ gidx, int interp, int extrap, int kind, R *__restrict__ scen,
                             int64_t osc, int *__restrict__ node, const R *__restrict__ scaling,
-                            const R *__restrict__ trend, unsigned char *__restrict__ gscratch, size_t gstride)
+                            const R *__restrict__ trend, unsigned char *__restrict__ gscratch, size_t gstride, int tkind,
+                            int skip0)
 {
+    // tkind: the kind of the detrending (PolyDetrend has one of its own, detrending.py:102-120); skip0: mult_skip_zeros —
+    // where the trend is 0 the value is kept instead of divided (:112-113)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *tabmem = TAB_LDS ? smem : gscratch + (size_t)blockIdx.x * gstride;
     TabLds<R> tl = tab_carve<R>(tabmem, G, Q);
@@ -308,7 +311,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                     R s = g0[e] >= 0 ? scal[g0[e]] : nan_of<R>();
                     v[e] = apply_corr<R>(v[e], s, kind);
                     tr[e] = trc[t];
-                    v[e] = apply_corr<R>(v[e], invert<R>(tr[e], kind), kind);
+                    if (!(skip0 && tr[e] == (R)0)) v[e] = apply_corr<R>(v[e], invert<R>(tr[e], tkind), tkind);
                 }
             }
 #pragma unroll
@@ -325,7 +328,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                 const int t = t0 + e * (int)blockDim.x;
                 if (t < Ti) {
                     R y = kind ? apply_corr<R>(v[e], a[e], kind) : a[e];
-                    if constexpr (DQM) y = apply_corr<R>(y, tr[e], kind);
+                    if constexpr (DQM) y = apply_corr<R>(y, tr[e], tkind);
                     o[t] = y;
                     if (ndc) ndc[t] = nd[e];
                 }
@@ -340,19 +343,57 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
 // One block per cell: series in LDS -> NaN-skipping centred window means (partial at the ends) ->
 // per-group least squares in float64 against time_num -> trend written cell-major.  The window means
 // are parked in the trend buffer itself between the two phases.
-// dynamic LDS: [coef: 3*G doubles][xs: T * sizeof(R)]
+// dynamic LDS: [coef: ncoef*G doubles][rcp: W+1 doubles][xs: T * sizeof(R)]
+// degree 0 / 1 (ncoef = 3): closed-form mean / slope.  degree 2..POLY_MAX_DEG or preserve_mean (ncoef = degree + 4): least
+// squares through the normal equations in the variable u = (x - x_mid) / x_halfrange of the group, which keeps them well
+// conditioned (xarray's polyfit scales the columns of the Vandermonde matrix in x = ns since 1970 and goes through
+// LAPACK's SVD; the fitted values agree to ~1e-9 relative, the conditioning error of that route), Horner in u.
+// preserve_mean (detrending.py:204-205): the group's trend has its own mean over the group's time steps removed ('+') or
+// divided out ('*'), in float64 before the cast.
 // ---------------------------------------------------------------------------------------------
+constexpr int POLY_MAX_DEG = 6;
+
+// least squares of degree d from the moments S_k = sum u^k (k <= 2d), B_k = sum u^k y (k <= d): c[0..d] ascending, NaN if singular
+__device__ __forceinline__ void poly_solve(const double *S, const double *B, int d, double *c)
+{
+    double A[POLY_MAX_DEG + 1][POLY_MAX_DEG + 2];
+    const int n = d + 1;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) A[i][j] = S[i + j];
+        A[i][n] = B[i];
+    }
+    bool ok = true;
+    for (int k = 0; k < n; k++) {
+        int piv = k;
+        for (int i = k + 1; i < n; i++) if (fabs(A[i][k]) > fabs(A[piv][k])) piv = i;
+        if (!(fabs(A[piv][k]) > 1e-300)) { ok = false; break; }
+        if (piv != k) for (int j = k; j <= n; j++) { const double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+        for (int i = k + 1; i < n; i++) {
+            const double f = A[i][k] / A[k][k];
+            for (int j = k; j <= n; j++) A[i][j] -= f * A[k][j];
+        }
+    }
+    for (int k = n - 1; k >= 0; k--) {
+        double v = A[k][n];
+        for (int j = k + 1; j < n; j++) v -= A[k][j] * c[j];
+        c[k] = ok ? v / A[k][k] : __builtin_nan("");
+    }
+}
+
 // M_LDS: the window means live in a second LDS array (T * sizeof(R) more) instead of the trend buffer — the
 // normal case for float32; float64 series that do not fit keep them in global memory.
 template <typename R, bool M_LDS>
 __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
-                              const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group)
+                              const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
+                              int preserve_mean)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool general = degree >= 2 || preserve_mean;
+    const int ncoef = general ? degree + 4 : 3;
     double *coef = reinterpret_cast<double *>(smem);
-    double *rcp = coef + 3 * (size_t)G;  // [W+1] correctly rounded reciprocals of the possible window counts
+    double *rcp = coef + (size_t)ncoef * G;  // [W+1] correctly rounded reciprocals of the possible window counts
     R *xs = reinterpret_cast<R *>(rcp + W + 1);
     const int64_t c = blockIdx.x;
     const R *x = sim + c * sc;
@@ -427,6 +468,59 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n, big); m[t] = mean_of(s, n); }
     }
     __syncthreads();
+    if (general) {
+        // general degree / preserve_mean: one lane per group, serial over its members (moments, solve, mean of the fit)
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
+            double *cg = coef + (size_t)ncoef * g;
+            double S[2 * POLY_MAX_DEG + 1], B[POLY_MAX_DEG + 1], cc[POLY_MAX_DEG + 1];
+            for (int k = 0; k <= 2 * degree; k++) S[k] = 0.0;
+            for (int k = 0; k <= degree; k++) B[k] = 0.0;
+            const double xa = p1 > p0 ? tnum[mem_idx[p0]] : 0.0, xb = p1 > p0 ? tnum[mem_idx[p1 - 1]] : 0.0;
+            const double xm = 0.5 * (xa + xb), hs = xb > xa ? 0.5 * (xb - xa) : 1.0;
+            int n = 0;
+            for (int p = p0; p < p1; p++) {
+                const int t = mem_idx[p];
+                const R v = m[t];
+                if (v == v) {
+                    const double u = (tnum[t] - xm) / hs;
+                    double pw = 1.0;
+                    for (int k = 0; k <= 2 * degree; k++) { S[k] += pw; if (k <= degree) B[k] += pw * (double)v; pw *= u; }
+                    n++;
+                }
+            }
+            if (n > degree) poly_solve(S, B, degree, cc);
+            else for (int k = 0; k <= degree; k++) cc[k] = __builtin_nan("");
+            double adj = kind == '+' ? 0.0 : 1.0;
+            if (preserve_mean) {
+                double sm = 0.0;
+                for (int p = p0; p < p1; p++) {
+                    const double u = (tnum[mem_idx[p]] - xm) / hs;
+                    double y = cc[degree];
+                    for (int k = degree - 1; k >= 0; k--) y = y * u + cc[k];
+                    sm += y;
+                }
+                adj = p1 > p0 ? sm / (double)(p1 - p0) : __builtin_nan("");
+            }
+            cg[0] = xm; cg[1] = hs; cg[2] = adj;
+            for (int k = 0; k <= degree; k++) cg[3 + k] = cc[k];
+        }
+        __syncthreads();
+        for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
+            const int g = gidx[t];
+            R out = nan_of<R>();
+            if (g >= 0) {
+                const double *cg = coef + (size_t)ncoef * g;
+                const double u = (tnum[t] - cg[0]) / cg[1];
+                double y = cg[3 + degree];
+                for (int k = degree - 1; k >= 0; k--) y = y * u + cg[3 + k];
+                if (preserve_mean) y = kind == '+' ? y - cg[2] : y / cg[2];
+                out = (R)y;
+            }
+            tr_out[t] = out;
+        }
+        return;
+    }
     // per-group least squares.  Many short groups (day-of-year: 365 groups of ~30 members): one LANE per group, a
     // serial loop over its members and no cross-lane reduction at all.
     if (lane_per_group) {

@@ -1,7 +1,7 @@
 """Detrending objects of the hot path (xsdba.detrending, detrending.py:17-131 BaseDetrend, :165-208 PolyDetrend).
 
-``PolyDetrend(degree 0 | 1)`` is computed by the HIP group-trend kernel (NaN-skipping centred window means per
-time step, per-group least squares against the float64 time axis); other detrenders of the reference
+``PolyDetrend(degree 0..6, preserve_mean)`` is computed by the HIP group-trend kernel (NaN-skipping centred window means
+per time step, per-group least squares against the float64 time axis); other detrenders of the reference
 (Loess, RollingMean, Mean, No) are outside the accelerated path."""
 from __future__ import annotations
 
@@ -73,14 +73,14 @@ class PolyDetrend(BaseDetrend):
 
     def _get_trend(self, da: DataArray) -> DataArray:
         group: Grouper = self.group
-        if self.degree not in (0, 1):
-            raise NotImplementedError(f"PolyDetrend(degree={self.degree}) is not implemented on the HIP path (0 or 1)")
-        if self.preserve_mean:
-            raise NotImplementedError("PolyDetrend(preserve_mean=True) is not implemented on the HIP path")
+        if not 0 <= int(self.degree) <= 6:
+            raise NotImplementedError(f"PolyDetrend(degree={self.degree}) is not implemented on the HIP path (0..6)")
+        if group.add_dims:
+            raise NotImplementedError("PolyDetrend with `add_dims` is only available through dqm_adjust on the HIP path")
         x2, cell_dims, cell_shape = cell_time_view(da, group.dim)
         gidx, G = group.group_index(da)
         tnum = group._time_index(da).numeric_ns
-        tr = hip.polydetrend_trend(x2, gidx, G, group.window, tnum, int(self.degree))
+        tr = hip.polydetrend_trend(x2, gidx, G, group.window, tnum, int(self.degree), bool(self.preserve_mean), self.kind)
         coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == group.dim}
         return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
 

@@ -197,9 +197,10 @@ def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant
 
 
 def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
-               ctx=None, out=None, trend_in=None):
+               ctx=None, out=None, trend_in=None, trend_kind=None, mult_skip_zeros=False):
     """_adjustment.dqm_adjust -> (scen, trend) each [C, T].  ``trend_in`` ([C, T]): use this trend instead of fitting one
-    (``degree`` and ``time_num`` are then ignored)."""
+    (``degree`` and ``time_num`` are then ignored); ``trend_kind`` / ``mult_skip_zeros``: the detrending object's own kind
+    and option (detrending.py:102-120), default: the kind of the adjustment."""
     ctx = ctx or default_context()
     s = _Series(sim)
     G, Q = (af.shape[1], af.shape[2])
@@ -212,7 +213,9 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
         trend = trend_in if isinstance(trend_in, DeviceArray) else np.ascontiguousarray(trend_in, s.dtype)
         if tuple(trend.shape) != (s.C, s.T):
             raise ValueError(f"trend_in must have shape {(s.C, s.T)}")
-        tn, degree = None, -1  # XSDBA_TREND_GIVEN
+        tk = trend_kind or kind
+        # XSDBA_TREND_GIVEN / _ADD / _MUL / _MUL_SKIP_ZEROS
+        tn, degree = None, (-1 if tk == kind and not mult_skip_zeros else (-2 if tk == "+" else (-4 if mult_skip_zeros else -3)))
     else:
         tn = time_num if isinstance(time_num, DeviceArray) else np.ascontiguousarray(time_num, np.float64)
         trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
@@ -384,16 +387,17 @@ def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
     return out
 
 
-def polydetrend_trend(x, gidx, G, W, time_num, degree=1, ctx=None):
-    """PolyDetrend(degree).fit(x).ds.trend -> [C, T]"""
+def polydetrend_trend(x, gidx, G, W, time_num, degree=1, preserve_mean=False, kind="+", ctx=None):
+    """PolyDetrend(degree, preserve_mean, kind).fit(x).ds.trend -> [C, T]"""
     ctx = ctx or default_context()
     s = _Series(x)
     g = _gidx(gidx, s.T, G)
     tn = np.ascontiguousarray(time_num, np.float64)
     out = _out(ctx, s.dev, (s.C, s.T), s.dtype)
-    check(load().xsdba_hip_polydetrend_trend(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st),
-                                             _i64(s.sc), _vp(g), C.c_int(G), C.c_int(W), _vp(tn), C.c_int(degree), _vp(out),
-                                             _i64(1), _i64(s.T)), "polydetrend_trend")
+    check(load().xsdba_hip_polydetrend_fit(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st),
+                                           _i64(s.sc), _vp(g), C.c_int(G), C.c_int(W), _vp(tn), C.c_int(degree),
+                                           C.c_int(int(bool(preserve_mean))), C.c_char(kind.encode()), _vp(out),
+                                           _i64(1), _i64(s.T)), "polydetrend_fit")
     return out
 
 
