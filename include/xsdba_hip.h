@@ -44,7 +44,7 @@ extern "C" {
 #define XSDBA_HIP_ABI_VERSION 1
 
 enum { XSDBA_F32 = 0, XSDBA_F64 = 1 };
-enum { XSDBA_INTERP_NEAREST = 0, XSDBA_INTERP_LINEAR = 1 };
+enum { XSDBA_INTERP_NEAREST = 0, XSDBA_INTERP_LINEAR = 1, XSDBA_INTERP_CUBIC = 2 /* one group only: scipy interp1d(kind="cubic"), utils.py:370-376 */ };
 enum { XSDBA_EXTRAP_CONSTANT = 0, XSDBA_EXTRAP_NAN = 1 };
 /* `degree` of xsdba_hip_dqm_adjust: the trend was fitted by the caller and `trend` is an INPUT; detrended / retrended with
  * the kind of the call, or with the detrending object's own kind (detrending.py:102-120), the last one with

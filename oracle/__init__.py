@@ -387,3 +387,22 @@ def polyfit_trend(x, gidx, G, W, time_num, degree, preserve_mean=False, kind="+"
                 tr = tr - tr.mean() if kind == "+" else tr / tr.mean()
             out[c, idx] = tr
     return out.astype(x.dtype)
+
+
+def interp_on_quantiles_1d(newx, oldx, oldy, method="linear", extrap="constant"):
+    """utils._interp_on_quantiles_1D (utils.py:350-377) for ONE cell with scipy.interpolate.interp1d itself: NaN pairs of the
+    table dropped, NaN abscissae stay NaN, outside the table the first / last valid factor ("constant") or NaN."""
+    from scipy.interpolate import interp1d
+
+    newx, oldx, oldy = np.asarray(newx), np.asarray(oldx), np.asarray(oldy)
+    mask_new = np.isnan(newx)
+    mask_old = np.isnan(oldy) | np.isnan(oldx)
+    out = np.full(newx.shape, np.nan, oldy.dtype)
+    if mask_new.all() or mask_old.all():
+        return out
+    if extrap == "constant":  # the first / last non-NaN FACTOR, whatever its abscissa (utils.py:362-366)
+        fill = (oldy[~np.isnan(oldy)][0], oldy[~np.isnan(oldy)][-1])
+    else:
+        fill = np.nan
+    out[~mask_new] = interp1d(oldx[~mask_old], oldy[~mask_old], kind=method, bounds_error=False, fill_value=fill)(newx[~mask_new])
+    return out

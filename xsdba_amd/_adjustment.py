@@ -274,7 +274,7 @@ def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     _check_group(group, ds)
     if interp not in ("nearest", "linear", "cubic"):
         raise ValueError(f"interp must be 'nearest', 'linear' or 'cubic', got {interp!r}")
-    if interp == "cubic" or (interp != "nearest" and group.prop != "group" and not grouped_linear):
+    if (interp == "cubic" and group.prop != "group") or (interp != "nearest" and group.prop != "group" and not grouped_linear):
         raise NotImplementedError(
             f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path"
             + (": on the regular (quantile, group) grid of QDM every cell of the grid is a cocircular quadruple, so the "

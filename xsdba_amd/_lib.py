@@ -18,7 +18,7 @@ LIB_PATH = _PKG / "lib" / "libxsdba_hip.so"
 CSRC = _PKG / "csrc"
 
 F32, F64 = 0, 1
-INTERP = {"nearest": 0, "linear": 1}
+INTERP = {"nearest": 0, "linear": 1, "cubic": 2}
 EXTRAP = {"constant": 0, "nan": 1}
 
 # every symbol include/xsdba_hip.h declares (checked by tests/test_cabi_symbols.py against the header)

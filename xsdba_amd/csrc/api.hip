@@ -843,7 +843,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     {
         // sort-based kernel (qdm_cell.hpp): any grouping at O(T log T) per cell instead of O(T * row length)
         const char *force = getenv("XSDBA_HIP_QDM");  // "count" pins the generic kernel (A/B runs, tests)
-        fast = pl->simple && T <= 11 * 1024 && T >= 64 && G <= xs::QdmCfg<11>::GMAX && (ranks_only || Q <= xs::QdmCfg<11>::QMAX) &&
+        fast = interp != XSDBA_INTERP_CUBIC && pl->simple && T <= 11 * 1024 && T >= 64 && G <= xs::QdmCfg<11>::GMAX && (ranks_only || Q <= xs::QdmCfg<11>::QMAX) &&
                s.st == 1 && !(force && !strcmp(force, "count"));
         // exact (non-windowed) ranking inside short windowed groups, e.g. 30 members per day of year: counting over
         // 30 values beats the sort (measured 6.8 vs 8.6 ms per 16384 cells); "cell" forces the sort kernel anyway

@@ -107,6 +107,7 @@ template <typename R> struct CellTab {
     const double *xfirst, *xlast;  // [G] first/last non-NaN abscissa (NaN if none) — nbutils.py:380-389
     const R *yfirst, *ylast;       // [G] first/last non-NaN factor
     int G, Q, any_valid, xstride;
+    const double *spl = nullptr;  // [n] second derivatives of the not-a-knot cubic spline of row 0 (interp = cubic, one group)
 };
 
 __device__ __forceinline__ int ext_row(int rr, int G) { return rr == 0 ? G - 1 : (rr == G + 1 ? 0 : rr - 1); }
@@ -114,14 +115,50 @@ __device__ __forceinline__ int ext_row(int rr, int G) { return rr == 0 ? G - 1 :
 // utils._interp_on_quantiles_1D (utils.py:350-377) with scipy.interpolate.interp1d 'nearest'
 // (x_bds = x/2 summed pairwise in the table dtype, searchsorted side='left': ties go DOWN) or 'linear'
 // (slope in the table dtype; evaluation in float64 when the abscissa is float64, the QDM path).
+// Second derivatives M[0..n) of the cubic spline through (xs, ys) with not-a-knot end conditions — what
+// scipy.interpolate.interp1d(kind="cubic") builds (make_interp_spline(k=3), its default boundary condition) — by the
+// Thomas algorithm on the interior unknowns after eliminating M_0 and M_{n-1}; float64; w: 2 n doubles of work space.
+// n < 4 (scipy refuses) or repeated abscissae (scipy raises) give NaN.  One thread.
+template <typename R>
+__device__ inline void spline_not_a_knot(const R *xs, const R *ys, int n, double *M, double *w)
+{
+    if (n < 4) { for (int i = 0; i < n; i++) M[i] = __builtin_nan(""); return; }
+    double *cp = w, *dp = w + n;  // modified upper diagonal / right-hand side
+    auto h = [&](int i) { return (double)xs[i + 1] - (double)xs[i]; };
+    auto rhs = [&](int i) { return 6.0 * (((double)ys[i + 1] - (double)ys[i]) / h(i) - ((double)ys[i] - (double)ys[i - 1]) / h(i - 1)); };
+    // unknowns M_1 .. M_{n-2}; row i: a_i M_{i-1} + b_i M_i + c_i M_{i+1} = r_i with the end rows folded in:
+    //   M_0 = ((h0 + h1) M_1 - h0 M_2) / h1,  M_{n-1} = ((h_{n-3} + h_{n-2}) M_{n-2} - h_{n-2} M_{n-3}) / h_{n-3}
+    for (int i = 1; i <= n - 2; i++) {
+        double a = h(i - 1), b = 2.0 * (h(i - 1) + h(i)), c = h(i);
+        if (i == 1) { const double h0 = h(0), h1 = h(1); b += h0 * (h0 + h1) / h1; c -= h0 * h0 / h1; a = 0.0; }
+        if (i == n - 2) { const double hl = h(n - 2), hp = h(n - 3); b += hl * (hp + hl) / hp; a -= hl * hl / hp; c = 0.0; }
+        const double r = rhs(i);
+        if (i == 1) { cp[i] = c / b; dp[i] = r / b; }
+        else { const double den = b - a * cp[i - 1]; cp[i] = c / den; dp[i] = (r - a * dp[i - 1]) / den; }
+    }
+    M[n - 2] = dp[n - 2];
+    for (int i = n - 3; i >= 1; i--) M[i] = dp[i] - cp[i] * M[i + 1];
+    M[0] = ((h(0) + h(1)) * M[1] - h(0) * M[2]) / h(1);
+    M[n - 1] = ((h(n - 3) + h(n - 2)) * M[n - 2] - h(n - 2) * M[n - 3]) / h(n - 3);
+}
+
 template <typename R>
 __device__ __forceinline__ R interp1d_eval(double x, bool x_is_double, const R *xs, const R *ys, int n, R yfirst,
-                                           R ylast, int interp, int extrap, int &node)
+                                           R ylast, int interp, int extrap, int &node, const double *spl = nullptr)
 {
     node = -1;
     if (x != x || n == 0) return nan_of<R>();
     if (x < (double)xs[0]) return extrap == 0 ? yfirst : nan_of<R>();
     if (x > (double)xs[n - 1]) return extrap == 0 ? ylast : nan_of<R>();
+    if (interp == 2) {  // cubic: the spline piece of the interval that holds x, in float64
+        if (!spl || n < 4) return nan_of<R>();
+        int lo = 0, hi = n - 1;  // xs[lo] <= x <= xs[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((double)xs[mid] <= x) lo = mid; else hi = mid; }
+        const double x0 = (double)xs[lo], x1 = (double)xs[hi], hh = x1 - x0, a = x1 - x, b = x - x0;
+        const double v = spl[lo] * a * a * a / (6.0 * hh) + spl[hi] * b * b * b / (6.0 * hh) +
+                         ((double)ys[lo] / hh - spl[lo] * hh / 6.0) * a + ((double)ys[hi] / hh - spl[hi] * hh / 6.0) * b;
+        return (R)v;
+    }
     if (interp == 0) {
         int lo = 0, hi = n - 1;
         while (lo < hi) {
@@ -203,7 +240,7 @@ __device__ __forceinline__ R celltab_eval(const CellTab<R> &ct, double x, bool x
                                           int extrap, int &node)
 {
     if (ct.G == 1)
-        return interp1d_eval<R>(x, x_is_double, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, node);
+        return interp1d_eval<R>(x, x_is_double, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, node, ct.spl);
     if (g0 < 0) { node = -1; return nan_of<R>(); }
     return interp2d_nearest<R, double>(x, g0, ct, extrap, node);
 }

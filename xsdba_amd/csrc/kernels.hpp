@@ -166,13 +166,14 @@ template <typename R> struct TabLds {
     R *yfirst, *ylast;
     int *any;
     int xstride;  // Q, or 0 for the shared abscissa row
+    double *spl;  // [3 Q] cubic-spline second derivatives of row 0 + work space (tab_spline)
 };
 
 template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q, bool shared_x = false)
 {
     size_t n = (size_t)G * Q;
-    return 2 * sizeof(double) * (size_t)G + sizeof(R) * (n + (shared_x ? (size_t)Q : n)) + 2 * sizeof(R) * (size_t)G +
-           sizeof(int) * ((size_t)G + 2) + 16;
+    return 2 * sizeof(double) * (size_t)G + 3 * sizeof(double) * (size_t)Q + sizeof(R) * (n + (shared_x ? (size_t)Q : n)) +
+           2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16;
 }
 
 template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q, bool shared_x = false)
@@ -182,6 +183,7 @@ template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned ch
     t.xstride = shared_x ? 0 : Q;
     t.xfirst = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
     t.xlast = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
+    t.spl = reinterpret_cast<double *>(p); p += 3 * sizeof(double) * (size_t)Q;
     t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * (shared_x ? (size_t)Q : n);
     t.ys = reinterpret_cast<R *>(p); p += sizeof(R) * n;
     t.yfirst = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
@@ -264,6 +266,16 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     return ct;
 }
 
+// interp = cubic on a one-group table: the spline of the compacted row (after tab_stage; ends on a barrier)
+template <typename R>
+__device__ __forceinline__ void tab_spline(CellTab<R> &ct, const TabLds<R> &t, int interp)
+{
+    if (interp != 2 || ct.G != 1) return;
+    if (threadIdx.x == 0) spline_not_a_knot<R>(ct.xs, ct.ys, ct.rn[0], t.spl, t.spl + ct.Q);
+    __syncthreads();
+    ct.spl = t.spl;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: qm_adjust (_adjustment.py:594-676) and the mapping stage of dqm_adjust (:748-773).
 // One block per cell; the cell's (hist_q, af) table is staged in LDS once, then the block streams the
@@ -291,6 +303,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
     const int Ti = (int)T;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
+        if constexpr (!GROUPED) tab_spline<R>(ct, tl, interp);
         const R *x = sim + c * sc;
         R *o = scen + c * osc;
         const R *scal = DQM ? scaling + (size_t)c * G : nullptr;
@@ -320,7 +333,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                     if (g0[e] < 0) { nd[e] = -1; a[e] = nan_of<R>(); }
                     else a[e] = interp2d_nearest<R, R>(v[e], g0[e], ct, extrap, nd[e]);
                 } else {
-                    a[e] = interp1d_eval<R>((double)v[e], false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd[e]);
+                    a[e] = interp1d_eval<R>((double)v[e], false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd[e], ct.spl);
                 }
             }
 #pragma unroll
@@ -632,8 +645,9 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         if (TAB_LDS) {
             ct = tab_stage<R>(tl, quantiles, 0, af + (size_t)c * G * Q, G, Q);
             tab_global = ct.any_valid < 0;
+            if (!tab_global) tab_spline<R>(ct, tl, interp);
         }
-        if (tab_global) ctg = tab_stage<R>(tlg, quantiles, 0, af + (size_t)c * G * Q, G, Q);
+        if (tab_global) { ctg = tab_stage<R>(tlg, quantiles, 0, af + (size_t)c * G * Q, G, Q); tab_spline<R>(ctg, tlg, interp); }
     }
     const R *x = sim + c * sc;
     for (int64_t t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t * st];

@@ -111,8 +111,8 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
     """
     newx, xq, yq = as_dataarray(newx), as_dataarray(xq), as_dataarray(yq)
     dim, prop = group.dim, group.prop
-    if method not in ("nearest", "linear"):
-        raise NotImplementedError(f"interp_on_quantiles(method={method!r}) is not implemented on the HIP path")
+    if method not in ("nearest", "linear", "cubic") or (method == "cubic" and prop != "group"):
+        raise NotImplementedError(f"interp_on_quantiles(method={method!r}) with group {group.name!r} is not implemented on the HIP path")
     x2, cell_dims, cell_shape = cell_time_view(newx, dim)
     if prop == "group":
         if "group" in xq.dims:
