@@ -178,7 +178,9 @@ int xsdba_hip_qdm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t
                          int rank_window, int interp, int extrap, char kind, void *scen, double *sim_q,
                          int64_t out_stride_t, int64_t out_stride_c);
 
-/* ---- a18: utils.rank(pct=True) through Grouper.apply (utils.py:573-638): float64 out[c*osc + t*ost] */
+/* ---- a18: utils.rank through Grouper.apply (utils.py:573-638): float64 out[c*osc + t*ost].  rank_window bit 0: rank
+ * within the windowed row instead of the exact group; bit 1 (value 2): the average ranks themselves (pct=False) instead
+ * of the percent ranks rescaled to [0, 1] (pct=True) */
 int xsdba_hip_rank_groups(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell,
                           int64_t stride_t, int64_t stride_c, const int32_t *group_of_time, int32_t n_groups,
                           int32_t window, int rank_window, double *out, int64_t out_stride_t, int64_t out_stride_c);
@@ -257,6 +259,13 @@ int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int6
                               int64_t stride_c, const int32_t *group_of_time, int32_t n_groups, int32_t window,
                               const double *time_num, int32_t degree, int preserve_mean, char kind, void *trend,
                               int64_t out_stride_t, int64_t out_stride_c);
+
+/* ---- a7 / a16: utils.apply_correction of a series by another series (utils.py:149-177; BaseDetrend._detrend / _retrend,
+ * detrending.py:102-120): out = x (+|*) f, or x (+|*) invert(f) when `inverted`; skip_zeros: out = x where f == 0
+ * (mult_skip_zeros).  f has the layout (f_stride_t, f_stride_c); f_stride_c == 0 broadcasts one series over all cells. */
+int xsdba_hip_series_correction(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                                int64_t stride_c, const void *f, int64_t f_stride_t, int64_t f_stride_c, char kind,
+                                int inverted, int skip_zeros, void *out, int64_t out_stride_t, int64_t out_stride_c);
 
 /* ---- bench / test utility: fill a DEVICE series block with the synthetic cubes of SURVEY §8d.
  * generator 0 = seasonal temperature-like, 1 = gamma precipitation-like; array_id 0/1/2 = ref/hist/sim;

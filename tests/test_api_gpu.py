@@ -403,8 +403,11 @@ class TestMoreReferenceCases:
         uu = random.random(n)
         da = timelonlatseries(uu, attrs={"units": "K"})
         da2 = timelonlatseries(uu, attrs={"units": "degC"})
-        with pytest.raises((ValueError, NotImplementedError)):
-            xs.EmpiricalQuantileMapping.train(da, da2)  # unit conversion (pint) is outside this path: refused, not guessed
+        # different but compatible units are harmonized (adjustment.py:182-185): hist (degC) comes to the units of ref (K)
+        eq = xs.EmpiricalQuantileMapping.train(da, da2, group="time", nquantiles=3)
+        np.testing.assert_allclose(eq.ds.af.values, -273.15, atol=1e-3)
+        with pytest.raises(ValueError, match="different dimensions"):
+            xs.EmpiricalQuantileMapping.train(da, timelonlatseries(uu, attrs={"units": "mm d-1"}))
         with pytest.raises(ValueError, match="units"):
             xs.EmpiricalQuantileMapping.train(da, timelonlatseries(uu))
         short = timelonlatseries(uu[:-1], attrs={"units": "K"})
@@ -451,8 +454,12 @@ def test_interp_on_quantiles_monthly(random):
     af = u.get_correction(hist_q, ref_q, "+")
     afi = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="nearest", extrapolation="constant")
     assert afi.isnull().sum("time") == 0
-    with pytest.raises(NotImplementedError):  # grouped linear/cubic: Qhull path of the reference
-        u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="linear")
+    # the reference loops over all three methods (:144-146); "linear" goes through the per-cell Delaunay triangulation here,
+    # grouped "cubic" (Clough-Tocher in the reference) is not implemented
+    afl = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="linear", extrapolation="constant")
+    assert afl.isnull().sum("time") == 0
+    with pytest.raises(NotImplementedError):
+        u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="cubic")
 
 
 def test_rank(random):

@@ -128,3 +128,37 @@ def test_int_degree_above_one_in_dqm():
     scaled = oracle.scaling_adjust(sim, sc, gidx, "+")
     exp = oracle.polyfit_trend(scaled, gidx, G, 31, gr._time_index(cube(sim, dims)).numeric_ns, 3)
     np.testing.assert_allclose(out.trend.transpose(*dims).values, exp, rtol=3e-6)
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_series_correction_and_detrend_retrend_on_the_device(kind):
+    """BaseDetrend._detrend / _retrend (detrending.py:102-120) run on the device (xsdba_hip_series_correction)"""
+    rng = np.random.default_rng(8)
+    x = (5 + rng.random((3, 500))).astype(np.float32)
+    f = (1 + rng.random((3, 500))).astype(np.float32)
+    f[0, :5] = 0
+    got = hip.series_correction(x, f, kind, inverted=True, skip_zeros=(kind == "*"))
+    with np.errstate(divide="ignore"):
+        exp = x - f if kind == "+" else x * (np.float32(1) / f)
+    if kind == "*":
+        exp[0, :5] = x[0, :5]
+    np.testing.assert_array_equal(got, exp)
+    np.testing.assert_array_equal(hip.series_correction(x, f[1], kind), x + f[1] if kind == "+" else x * f[1])
+    da = cube(data(rng, 2, 4 * 365, np.float64), ("lat", "time"))
+    det = PolyDetrend(group="time", degree=2, kind=kind).fit(da)
+    np.testing.assert_allclose(det.retrend(det.detrend(da)).values, da.values, rtol=1e-12)
+
+
+def test_rank_without_pct_is_computed_on_the_device():
+    from xsdba_amd import utils as u
+    from scipy.stats import rankdata
+
+    rng = np.random.default_rng(9)
+    x = np.round(rng.standard_normal((4, 300)), 1)
+    x[1, 10:20] = np.nan
+    r = u.rank(DataArray(x, ("lat", "time")), dim="time", pct=False).values
+    exp = np.full_like(x, np.nan)
+    for c in range(4):
+        ok = ~np.isnan(x[c])
+        exp[c, ok] = rankdata(x[c, ok], "average")
+    np.testing.assert_array_equal(r, exp)

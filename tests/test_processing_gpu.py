@@ -52,8 +52,10 @@ def test_jitter_over_thresh():
     out = jitter_over_thresh(da, "2 m", "3 m")
     assert da.values[1] != out.values[1] and 2 <= out.values[1] < 3
     np.testing.assert_allclose(da.values[[0, 2]], out.values[[0, 2]])
-    with pytest.raises(NotImplementedError, match="units"):
-        jitter_over_thresh(da, "200 cm", "0.003 km")  # unit conversion (pint) is outside this path
+    out = jitter_over_thresh(da, "200 cm", "0.003 km")  # thresholds in other units of the same dimension (test_processing.py:57-63)
+    assert da.values[1] != out.values[1] and 2 <= out.values[1] < 3
+    with pytest.raises(ValueError, match="cannot be expressed"):
+        jitter_over_thresh(da, "2 K", "3 K")
 
 
 @pytest.mark.parametrize("test_val", [1e-6, 1, 100, 1e6])

@@ -77,19 +77,16 @@ class BaseAdjustment(ParametrizableWithDataset):
 
     @classmethod
     def _harmonize_units(cls, *inputs, target=None):
-        """Same units => no-op (units.py:301-304).  Unit conversion itself (pint) is outside this path."""
+        """Bring the inputs to common units: those of the first one, or `target` (adjustment.py:182-185, units.py:269-321);
+        same units => no-op, else converted on the device (xsdba_amd/units.py)."""
+        from .units import convert_units_to
+
         for inda in inputs:
             if "units" not in inda.attrs:
                 raise ValueError(f"Input {inda.name or '<array>'!s} has no `units` attribute (required like in the reference)")
-        if target is None:
+        if target is None or target == "":
             target = inputs[0].attrs["units"]
-        for inda in inputs:
-            if inda.attrs["units"] != target:
-                raise NotImplementedError(
-                    f"inputs carry different units ({inda.attrs['units']!r} vs {target!r}); unit conversion is not part of "
-                    "the HIP path — convert before calling"
-                )
-        return inputs, target
+        return tuple(inda if inda.attrs["units"] == target else convert_units_to(inda, target) for inda in inputs), target
 
     @classmethod
     def _check_matching_times(cls, ref, hist):

@@ -787,6 +787,8 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
              char kind, void *scen, double *sim_q, int64_t ost, int64_t osc)
 {
     const bool ranks_only = af == nullptr;
+    if (ranks_only) { interp = (rank_window & 2) ? -1 : 0; }  // bit 1 of rank_window: plain average ranks instead of percent ranks
+    rank_window &= 1;
     if (C <= 0 || (!ranks_only && (Q <= 0 || !quantiles || !scen)) || (ranks_only && !sim_q)) return fail(XSDBA_E_ARG, "null/empty argument");
     if (!ranks_only && G > 1 && interp != XSDBA_INTERP_NEAREST) return fail(XSDBA_E_UNSUPPORTED, "grouped interpolation other than 'nearest' is not implemented");
     int rc;
@@ -1094,6 +1096,33 @@ int scaling_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t 
     }
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
     return sync_if(ctx, o.copy_back || !is_device_ptr(sim));
+}
+
+template <typename R>
+int series_correction_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, const void *f,
+                           int64_t fst, int64_t fsc, char kind, int inv, int skip0, void *out, int64_t ost, int64_t osc)
+{
+    if (C <= 0 || T <= 0 || !x || !f || !out) return fail(XSDBA_E_ARG, "null/empty argument");
+    int rc;
+    SeriesIn s, sf;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x, T, C, st, sc, &s))) return rc;
+    const bool bcast = fsc == 0;  // one series for all cells
+    if ((rc = series_in<R>(ctx, S_IN1, S_CM2, f, T, bcast ? 1 : C, fst, bcast ? T : fsc, &sf))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, out, T, C, ost, osc, &o))) return rc;
+    {
+        LaunchScope ls(ctx, "k_series_correction");
+        const unsigned gx = (unsigned)std::min<int64_t>((T + 255) / 256, 64);
+        for (int64_t c0 = 0; c0 < C; c0 += 65535) {
+            const int64_t nc = std::min<int64_t>(65535, C - c0);
+            hipLaunchKernelGGL(xs::k_series_correction<R>, dim3(gx, (unsigned)nc), dim3(256), 0, ctx->stream,
+                               (const R *)s.dev + c0 * s.sc, (const R *)sf.dev + (bcast ? 0 : c0 * sf.sc), T, s.sc, bcast ? (int64_t)0 : sf.sc,
+                               (int)kind, inv, skip0, (R *)o.kernel_dst + c0 * T, T);
+        }
+        if ((rc = check_launch("k_series_correction"))) return rc;
+    }
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
+    return sync_if(ctx, true);
 }
 
 template <typename R>
@@ -1561,6 +1590,16 @@ API int xsdba_hip_polydetrend_trend(xsdba_hip_ctx *ctx, const void *x, int dtype
     if (rc) return rc;
     return DISPATCH(dtype, (trend_impl<float>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, 0, '+', trend, ost, osc)),
                     (trend_impl<double>(ctx, x, T, C, st, sc, gidx, G, W, time_num, degree, 0, '+', trend, ost, osc)));
+}
+
+API int xsdba_hip_series_correction(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                    const void *f, int64_t fst, int64_t fsc, char kind, int inverted, int skip_zeros, void *out,
+                                    int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, false))) return rc;
+    return DISPATCH(dtype, (series_correction_impl<float>(ctx, x, T, C, st, sc, f, fst, fsc, kind, inverted ? 1 : 0, skip_zeros ? 1 : 0, out, ost, osc)),
+                    (series_correction_impl<double>(ctx, x, T, C, st, sc, f, fst, fsc, kind, inverted ? 1 : 0, skip_zeros ? 1 : 0, out, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

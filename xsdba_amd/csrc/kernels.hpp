@@ -761,7 +761,7 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
                     const double N = gstat[3 * g[e]], pmin = gstat[3 * g[e] + 1], pmax = gstat[3 * g[e] + 2];
                     const double r = (double)lo[e] + (double)(hi[e] - lo[e] + 1) / 2.0;
                     const double pr = r / N;
-                    sq[e] = pmax * (pr - pmin) / (pmax - pmin);
+                    sq[e] = interp == -1 ? r : pmax * (pr - pmin) / (pmax - pmin);  // interp -1 (ranks only): the average ranks themselves
                 }
             }
 #pragma unroll
@@ -789,7 +789,7 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
             const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
             double r = (double)less + (double)(eq + 1) / 2.0;
             double pr = r / N;
-            sq = pmax * (pr - pmin) / (pmax - pmin);
+            sq = interp == -1 ? r : pmax * (pr - pmin) / (pmax - pmin);
         }
         if (sim_q) sim_q[c * osc + t * ost] = sq;
         if (af) {

@@ -365,6 +365,24 @@ __global__ void k_scale_groups(const R *__restrict__ sim, int64_t T, int64_t sc,
     }
 }
 
+// utils.apply_correction of one series by another (detrending.py:102-120: detrend = x (+|*) invert(trend), retrend =
+// x (+|*) trend; mult_skip_zeros keeps x where the trend is 0).  Both cell-major [cell][time], f broadcast over the cells
+// when f_stride_c == 0.
+template <typename R>
+__global__ void k_series_correction(const R *__restrict__ x, const R *__restrict__ f, int64_t T, int64_t sc, int64_t fsc, int kind,
+                                    int inv, int skip0, R *__restrict__ out, int64_t osc)
+{
+    const int64_t c = blockIdx.y;
+    const R *xr = x + c * sc, *fr = f + c * fsc;
+    R *o = out + c * osc;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+        const R v = xr[t], w = fr[t];
+        R y = apply_corr<R>(v, inv ? invert<R>(w, kind) : w, kind);
+        if (skip0 && w == (R)0) y = v;
+        o[t] = y;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // LOCI (_adjustment.py:889-939).  Two kernels per training, one workgroup per (cell, group) block:
 //   k_loci_thresh: q = (#(ref <= thresh) + 1) / (#valid ref + 1)  (utils._ecdf_1d :35-37: the sorted sample is prefixed

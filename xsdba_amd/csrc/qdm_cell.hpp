@@ -267,7 +267,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
                 const double r = (double)r2 / 2.0;
                 const double pr = r / N;
-                sq = pmax * (pr - pmin) / (pmax - pmin);
+                sq = interp == -1 ? r : pmax * (pr - pmin) / (pmax - pmin);  // interp -1 (ranks only): the average ranks themselves
             }
             if (sim_q) sim_q[(size_t)c * T + t] = sq;
             if (af) {

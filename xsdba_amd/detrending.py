@@ -7,10 +7,12 @@ from __future__ import annotations
 
 import warnings
 
+import numpy as np
+
 from . import hip
 from .base import Grouper, ParametrizableWithDataset, _register, parse_group
 from .labeled import DataArray, as_dataarray
-from .utils import ADDITIVE, apply_correction, cell_time_view, invert
+from .utils import ADDITIVE, cell_time_view
 
 
 class BaseDetrend(ParametrizableWithDataset):
@@ -43,19 +45,31 @@ class BaseDetrend(ParametrizableWithDataset):
             raise ValueError("You must call fit() before retrending")
         return self._retrend(as_dataarray(da), self.ds.trend)
 
-    def _detrend(self, da, trend):
+    def _apply(self, da, trend, inverted, skip_zeros):
+        """da (+|*) trend, or invert(trend), on the device: both as [cell, time] blocks in the dimension order of `da`"""
+        dim = self.group.dim
         trend = trend.transpose(*[d for d in da.dims if d in trend.dims])
-        out = apply_correction(da, invert(trend, self.kind), self.kind)
+        x2, cell_dims, cell_shape = cell_time_view(da, dim)
+        dt = x2.dtype if x2.dtype.kind == "f" else np.float64
+        if set(trend.dims) == {dim}:
+            f2 = trend.values
+        else:
+            missing = [d for d in cell_dims if d not in trend.dims]
+            if missing:
+                raise ValueError(f"trend lacks dimension(s) {missing} of the data")
+            f2, _, _ = cell_time_view(trend.transpose(*cell_dims, dim), dim)
+        out = hip.series_correction(x2.astype(dt, copy=False), f2.astype(dt, copy=False), self.kind, inverted, skip_zeros)
+        coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == dim}
+        return DataArray(out.reshape(cell_shape + (out.shape[-1],)), cell_dims + (dim,), coords, dict(da.attrs), da.name).transpose(*da.dims)
+
+    def _detrend(self, da, trend):
         if self.mult_skip_zeros and self.kind != "*":
             warnings.warn(f"mult_skip_zeros is only used for kind='*'. Your kind is {self.kind}. mult_skip_zeros will be ignored.",
                           UserWarning, stacklevel=2)
-        if self.mult_skip_zeros and self.kind == "*":
-            out = out.where(trend != 0, da)
-        return out
+        return self._apply(da, trend, True, bool(self.mult_skip_zeros) and self.kind == "*")
 
     def _retrend(self, da, trend):
-        trend = trend.transpose(*[d for d in da.dims if d in trend.dims])
-        return apply_correction(da, trend, self.kind)
+        return self._apply(da, trend, False, False)
 
     def _get_trend(self, da):
         raise NotImplementedError

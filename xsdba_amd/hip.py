@@ -375,14 +375,32 @@ def loci_adjust(sim, af, hist_thresh, gidx, thresh, g_hi=None, frac=None, ctx=No
     return scen
 
 
-def rank_groups(x, gidx, G, W, rank_window=False, ctx=None):
-    """utils.rank(pct=True) through Grouper.apply -> float64 [C, T]"""
+def series_correction(x, f, kind="+", inverted=False, skip_zeros=False, ctx=None):
+    """utils.apply_correction(x, f or invert(f), kind) for series x [C, T] and f [C, T] or [T] (broadcast) -> [C, T]"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    f = np.ascontiguousarray(f, s.dtype)
+    if f.shape == (s.T,):
+        fst, fsc = 1, 0
+    elif f.shape == (s.C, s.T):
+        fst, fsc = 1, s.T
+    else:
+        raise ValueError(f"f must have shape {(s.C, s.T)} or {(s.T,)}")
+    out = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    check(load().xsdba_hip_series_correction(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                             _vp(f), _i64(fst), _i64(fsc), C.c_char(kind.encode()), C.c_int(int(bool(inverted))),
+                                             C.c_int(int(bool(skip_zeros))), _vp(out), _i64(1), _i64(s.T)), "series_correction")
+    return out
+
+
+def rank_groups(x, gidx, G, W, rank_window=False, pct=True, ctx=None):
+    """utils.rank(pct) through Grouper.apply -> float64 [C, T] (average ranks, or percent ranks rescaled to [0, 1])"""
     ctx = ctx or default_context()
     s = _Series(x)
     g = _gidx(gidx, s.T, G)
     out = _out(ctx, s.dev, (s.C, s.T), np.float64)
     check(load().xsdba_hip_rank_groups(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
-                                       _vp(g), C.c_int(G), C.c_int(W), C.c_int(int(bool(rank_window))), _vp(out),
+                                       _vp(g), C.c_int(G), C.c_int(W), C.c_int(int(bool(rank_window)) | (0 if pct else 2)), _vp(out),
                                        _i64(1), _i64(s.T)), "rank_groups")
     return out
 
@@ -401,5 +419,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, preserve_mean=False, ki
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "qm_adjust_linear2d", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "loci_train", "loci_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "qm_adjust_linear2d", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "series_correction", "loci_train", "loci_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]

@@ -21,22 +21,22 @@ def _draw_seed() -> int:
 
 
 def quantity_to_float(q, like: DataArray | None = None, name: str = "threshold") -> float | None:
-    """'1 mm d-1' -> 1.0 when the units are those of ``like`` (units.convert_units_to :226-266 without pint: a quantity in
-    other units raises); plain numbers pass through."""
+    """'1 mm d-1' -> the number in the units of ``like`` (units.convert_units_to :226-266; xsdba_amd/units.py); plain
+    numbers pass through."""
     if q is None:
         return None
     if isinstance(q, (int, float, np.integer, np.floating)):
         return float(q)
-    parts = str(q).strip().split(None, 1)
-    try:
-        val = float(parts[0])
-    except ValueError as err:
-        raise ValueError(f"cannot parse the {name} {q!r} (expected '<number> <units>')") from err
-    units = parts[1].strip() if len(parts) > 1 else ""
+    from .units import conversion, str2quantity
+
+    val, units = str2quantity(q)
     have = str(like.attrs.get("units", "")).strip() if like is not None else ""
-    if units and have and " ".join(units.split()) != " ".join(have.split()):
-        raise NotImplementedError(
-            f"{name} {q!r} is not in the units of the data ({have!r}); unit conversion (pint) is outside this path")
+    if units and have:
+        try:
+            f, o = conversion(units, have)
+        except ValueError as err:
+            raise ValueError(f"{name} {q!r} cannot be expressed in the units of the data ({have!r}): {err}") from err
+        val = val * f + o
     return val
 
 

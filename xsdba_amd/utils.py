@@ -185,8 +185,7 @@ def broadcast(grouped, x, *, group: str | Grouper = "time", interp: str = "neare
 def rank(da, dim: str | list = "time", pct: bool = False, use_random_tiebreak: bool = False):
     """Rank data along a dimension (utils.py:573-638): average ties, NaN stay NaN; ``pct=True`` rescales to [0, 1].
 
-    Computed by the HIP rank kernel (percent ranks); integer ranks are recovered from them exactly when
-    the extremes are untied, otherwise through the count of valid values.
+    Computed by the HIP rank kernel (average ranks, or percent ranks).
     """
     if use_random_tiebreak:
         raise NotImplementedError("use_random_tiebreak is not implemented on the HIP path")
@@ -197,22 +196,7 @@ def rank(da, dim: str | list = "time", pct: bool = False, use_random_tiebreak: b
     x2, cell_dims, cell_shape = cell_time_view(da, dims[0])
     x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
     T = x2.shape[1]
-    pr = hip.rank_groups(x2, None, 1, 1, False)
-    if not pct:
-        # pr = pmax*(p-pmin)/(pmax-pmin) with p = r/N: invert with the extreme average ranks of each row
-        valid = ~np.isnan(x2)
-        N = valid.sum(axis=1, keepdims=True).astype(np.float64)
-        with np.errstate(all="ignore"):
-            mn = np.nanmin(np.where(valid, x2, np.nan), axis=1, keepdims=True)
-            mx = np.nanmax(np.where(valid, x2, np.nan), axis=1, keepdims=True)
-        nmin = (x2 == mn).sum(axis=1, keepdims=True)
-        nmax = (x2 == mx).sum(axis=1, keepdims=True)
-        rmin, rmax = (nmin + 1) / 2.0, (N - nmax) + (nmax + 1) / 2.0
-        with np.errstate(all="ignore"):
-            # p = pr*(pmax-pmin)/pmax + pmin with pmax = rmax/N, pmin = rmin/N ; r = p*N
-            r = (pr * ((rmax - rmin) / N) / (rmax / N) + rmin / N) * N
-        r = np.where((rmax == rmin) & valid, rmin, r)
-        pr = np.rint(r * 2) / 2
+    pr = hip.rank_groups(x2, None, 1, 1, False, pct=bool(pct))
     coords = {k: c for k, c in da.coords.items()}
     out = DataArray(pr.reshape(cell_shape + (T,)), cell_dims + (dims[0],), coords, da.attrs, da.name)
     return out.transpose(*da.dims)
