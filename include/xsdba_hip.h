@@ -149,11 +149,16 @@ int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t 
  * group_coord [n_groups + 2]: coordinates of the wrapped rows (month: 0..13); new_group [n_time]: fractional group
  * coordinate of every time step (Grouper.get_index(interp=True), base.py:308-320).  trend (nullable, contiguous
  * [cell][time]): the series is detrended with it before the mapping and retrended after (the DQM variant; the caller
- * passes the scaled series).  Tied quantiles: of exactly repeated nodes one is kept (Qhull's own choice is undefined). */
+ * passes the scaled series).  Tied quantiles: of exactly repeated nodes one is kept (Qhull's own choice is undefined).
+ * lookup (nullable, contiguous float64 [cell][time]): the abscissa looked up in the table when it is not the series itself,
+ * and hist_q_is_row != 0: hist_q is ONE row [nq] shared by every group and cell — together the QDM form (_adjustment.py:
+ * 873-881: af interpolated at (sim_q, group) over the regular (quantile, group) grid; every cell of that grid is a
+ * cocircular quadruple, so which diagonal splits it is the triangulator's choice, here as in Qhull). */
 int xsdba_hip_qm_adjust_linear2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
                                  int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q, int32_t n_groups,
                                  int32_t nq, const double *group_coord, const double *new_group, int extrap, char kind,
-                                 const void *trend, void *scen, int64_t out_stride_t, int64_t out_stride_c);
+                                 const void *trend, const double *lookup, int hist_q_is_row, void *scen, int64_t out_stride_t,
+                                 int64_t out_stride_c);
 
 /* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
  * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`

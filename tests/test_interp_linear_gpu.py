@@ -166,14 +166,46 @@ def test_dqm_grouped_linear(kind):
     assert (~np.isclose(got[both], exp[both], rtol=3e-5, atol=3e-4)).sum() <= 2e-3 * got.size
 
 
-def test_qdm_grouped_linear_is_refused_with_the_reason():
+def test_qdm_grouped_linear_on_the_regular_grid():
+    """QDM looks sim_q up in the regular (quantile, group) grid: every grid cell is a cocircular quadruple, so the diagonal
+    that splits it is the triangulator's choice (Qhull's looks random).  Both are linear interpolants of the same nodes:
+    they agree where the four corners are coplanar, and never differ by more than the cell's twist |f00 + f11 - f01 - f10|/2."""
     rng = np.random.default_rng(25)
-    ref, hist, sim = gen(rng, 1, 3 * 365)
+    ref, hist, sim = gen(rng, 2, 5 * 365)
     dims = ("lat", "time")
-    qdm = xs.QuantileDeltaMapping.train(cube(ref, dims), cube(hist, dims), group="time.month", nquantiles=10)
-    with pytest.raises(ValueError) as ei:
-        qdm.adjust(cube(sim, dims), interp="linear")
-    assert isinstance(ei.value.__cause__, NotImplementedError) and "cocircular" in str(ei.value.__cause__)
+    gr = xs.Grouper("time.month")
+    Q = 10
+    qdm = xs.QuantileDeltaMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=Q)
+    with xs.set_options(extra_output=True):
+        out = qdm.adjust(cube(sim, dims), interp="linear")
+    got = out.scen.transpose(*dims).values - sim
+    sim_q = out.sim_q.transpose(*dims).values
+    af = qdm.ds.af.transpose("lat", "month", "quantiles").values
+    q = qdm.ds.quantiles.values.astype(np.float32)
+    gcoord = np.arange(0, 14.0)
+    newg = np.asarray(gr.get_index(cube(sim, dims), interp=True).values, np.float64)
+    for c in range(2):
+        exp = oracle.interp_on_quantiles_2d(sim_q[c], newg, np.repeat(q[None], 14, 0), wrap(af[c]), np.repeat(gcoord[:, None], Q, 1), "linear", "constant")
+        w = wrap(af[c]).astype(np.float64)
+        twist = np.abs(w[:-1, :-1] + w[1:, 1:] - w[:-1, 1:] - w[1:, :-1]).max() / 2
+        assert np.isfinite(got[c]).all() and np.isfinite(exp).all()
+        assert np.abs(got[c] - exp).max() <= twist + 1e-5
+        assert np.median(np.abs(got[c] - exp)) < 0.05 * twist + 1e-6
+
+
+def test_reference_qdm_seasonal():
+    """reference tests/test_adjustment.py:804-833 (TestQDM.test_seasonal): group="time.season", interp="linear" """
+    from scipy.stats import uniform
+
+    rng = np.random.default_rng(26)
+    uu = rng.random(10000)
+    x, y = uniform(loc=1, scale=1).ppf(uu), uniform(loc=2, scale=4).ppf(uu)
+    t = xs.date_range("2000-01-01", uu.size, "standard").values
+    mk = lambda a: DataArray(a.astype(np.float32), ("time",), {"time": t}, {"units": "K"})  # noqa: E731
+    qdm = xs.QuantileDeltaMapping.train(mk(y), mk(x), kind="+", group="time.season", nquantiles=10)
+    p = qdm.adjust(mk(x), interp="linear").values
+    middle = (uu > 1e-2) & (uu < 0.99)
+    np.testing.assert_array_almost_equal(p[middle], y[middle].astype(np.float32), 1)
 
 
 def test_reference_test_utils_grouped_interp_has_no_nan():

@@ -277,10 +277,7 @@ def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     if (interp == "cubic" and group.prop != "group") or (interp != "nearest" and group.prop != "group" and not grouped_linear):
         raise NotImplementedError(
             f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path"
-            + (": on the regular (quantile, group) grid of QDM every cell of the grid is a cocircular quadruple, so the "
-               "Qhull triangulation behind scipy.griddata (utils.py:391-396) picks its diagonals arbitrarily and the "
-               "reference's values are not reproducible; use interp='nearest' (its default)" if interp == "linear" else
-               ": the reference routes it through scipy.griddata's Clough-Tocher interpolant (utils.py:391-396); use 'nearest' or 'linear'")
+            + ": the reference routes a grouped 'cubic' through scipy.griddata's Clough-Tocher interpolant (utils.py:391-396); use 'nearest' or 'linear'"
         )
     sim = as_dataarray(ds["sim"])
     dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
@@ -450,12 +447,23 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
                 category=DeprecationWarning,
                 stacklevel=2,
             )
-    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp)
+    sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     quantiles = np.asarray(ds["quantiles"].values, dt)
     P = _n_pooled(group, cell_dims, cell_shape)
-    if P > 1 and rank_window:
+    sim_q = None
+    if interp == "linear" and G > 1:
+        # the factors interpolated at (sim_q, fractional group) over the regular (quantile, group) grid (:873-881).  Every
+        # cell of that grid is a cocircular quadruple: which diagonal splits it is the triangulator's choice (Qhull's in
+        # the reference, the sweep's here), so the two agree exactly only where the four corner factors are coplanar.
+        _no_linear_tail_mask(group, max_tail_factor)
+        if P > 1 and rank_window:
+            raise NotImplementedError("qdm_adjust with `add_dims`, rank_window and a grouped interp='linear' is not implemented on the HIP path")
+        sim_q = hip.rank_groups(s2, gidx, G, group.window, bool(rank_window))
+        gcoord, newg = _linear_group_coords(group, sim)
+        scen = hip.qm_adjust_linear2d(s2, af, quantiles, gcoord, newg, extrapolation, kind, lookup=sim_q)
+    elif P > 1 and rank_window:
         # ranks over (time, window, pooled members) (_adjustment.py:873: main_only = not rank_window): the members of a
         # cell laid end to end as one series, like at training; the table of the cell serves all of them
         T = s2.shape[1]

@@ -41,7 +41,7 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
 
 template <typename R>
 __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq, const double *__restrict__ gcoord, int G, int Q,
-                              int64_t C, unsigned char *__restrict__ scratch, size_t stride)
+                              int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -56,7 +56,8 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     for (int r = 0; r < G + 2; r++) {
         rowb[r] = n;
         const int g = ext_row(r, G);
-        const R *xr = xq + ((size_t)c * G + g) * Q, *yr = yq + ((size_t)c * G + g) * Q;
+        // xq_is_row: one abscissa row for every group and cell (QDM: the quantile nodes)
+        const R *xr = xq_is_row ? xq : xq + ((size_t)c * G + g) * Q, *yr = yq + ((size_t)c * G + g) * Q;
         double xf = __builtin_nan(""), xl = xf, yf = xf, yl = xf;
         bool fx = false, fy = false;
         const int row_begin = n;
@@ -122,7 +123,7 @@ template <typename R, bool USE_LDS>
 __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const double *__restrict__ newg,
                                const double *__restrict__ gcoord, int G, int Q, const unsigned char *__restrict__ scratch,
                                size_t stride, int extrap, int kind, const R *__restrict__ trend, R *__restrict__ scen,
-                               int64_t osc)
+                               int64_t osc, const double *__restrict__ lookup)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lin2DLayout L = lin2d_layout(G, Q);
@@ -152,6 +153,7 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         d.ntri = hdr[1];
         const R *x = sim + c * sc;
         const R *trc = trend ? trend + (size_t)c * T : nullptr;
+        const double *lk = lookup ? lookup + (size_t)c * T : nullptr;  // the abscissa to look up when it is not the series itself (QDM: sim_q)
         R *o = scen + c * osc;
         for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
             R v = x[t];
@@ -159,7 +161,8 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
             if (trc) { tr = trc[t]; v = apply_corr<R>(v, invert<R>(tr, kind), kind); }
             const double g = newg[t];
             R a = nan_of<R>();
-            if (v == v && g == g && d.n > 0) {  // (a cell without a single valid node stays NaN: utils.py:384-390)
+            const double vx = lk ? lk[t] : (double)v;
+            if (vx == vx && g == g && d.n > 0) {  // (a cell without a single valid node stays NaN: utils.py:384-390)
                 // start the walk at a triangle of the node nearest in (row, x): the row next to g, bisection on its abscissae
                 int r0 = 0, r1 = G + 1;
                 while (r1 - r0 > 1) { const int mid = (r0 + r1) >> 1; if (gcoord[mid] <= g) r0 = mid; else r1 = mid; }
@@ -168,19 +171,19 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
                 int hint = 0;
                 if (rowb[r + 1] > rowb[r]) {
                     int lo = rowb[r], hi = rowb[r + 1] - 1;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.px[mid] < (double)v) lo = mid + 1; else hi = mid; }
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.px[mid] < vx) lo = mid + 1; else hi = mid; }
                     hint = vt[lo];
                 }
-                const int tri = dt_locate(d, (double)v, g, hint);
-                if (tri >= 0) a = (R)dt_eval(d, pv, tri, (double)v, g);
+                const int tri = dt_locate(d, vx, g, hint);
+                if (tri >= 0) a = (R)dt_eval(d, pv, tri, vx, g);
                 // nbutils._extrapolate_on_quantiles: below / above the group-interpolated first / last node
                 const double lo = extrap == 0 ? np_interp_rows(g, gcoord, meta, 4, G + 2) : 0.0;
                 const double hi = extrap == 0 ? np_interp_rows(g, gcoord, meta + 1, 4, G + 2) : 0.0;
                 // (only for extrapolation="constant": with "nan" the reference leaves griddata's own NaN outside the hull and
                 // does not call it, utils.py:397-399)
                 if (extrap == 0) {
-                    if ((double)v < lo) a = (R)np_interp_rows(g, gcoord, meta + 2, 4, G + 2);
-                    if ((double)v > hi) a = (R)np_interp_rows(g, gcoord, meta + 3, 4, G + 2);
+                    if (vx < lo) a = (R)np_interp_rows(g, gcoord, meta + 2, 4, G + 2);
+                    if (vx > hi) a = (R)np_interp_rows(g, gcoord, meta + 3, 4, G + 2);
                 }
             }
             R y = kind ? apply_corr<R>(v, a, kind) : a;  // kind 0: the interpolated factor itself (utils.interp_on_quantiles)

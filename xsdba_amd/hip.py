@@ -171,15 +171,17 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
     return (scen, node) if return_nodes else scen
 
 
-def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, ctx=None):
+def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, lookup=None, ctx=None):
     """qm_adjust with grouped interp="linear" (utils._interp_on_quantiles_2d through scipy.griddata, utils.py:380-400) -> scen
     [C, T].  ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the
-    fractional group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping."""
+    fractional group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping.
+    QDM form: ``hist_q`` a single row [Q] (the quantile nodes) and ``lookup`` [C, T] float64 (sim_q) to look up instead of sim."""
     ctx = ctx or default_context()
     s = _Series(sim)
     G, Q = (af.shape[1], af.shape[2])
     af = _table(af, s.dtype, (s.C, G, Q))
-    hist_q = _table(hist_q, s.dtype, (s.C, G, Q))
+    row = tuple(hist_q.shape) == (Q,)
+    hist_q = np.ascontiguousarray(hist_q, s.dtype) if row else _table(hist_q, s.dtype, (s.C, G, Q))
     gc = np.ascontiguousarray(group_coord, np.float64)
     ng = np.ascontiguousarray(new_group, np.float64)
     if gc.shape != (G + 2,) or ng.shape != (s.T,):
@@ -188,10 +190,15 @@ def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant
         trend = trend if isinstance(trend, DeviceArray) else np.ascontiguousarray(trend, s.dtype)
         if tuple(trend.shape) != (s.C, s.T):
             raise ValueError(f"trend must have shape {(s.C, s.T)}")
+    if lookup is not None:
+        lookup = lookup if isinstance(lookup, DeviceArray) else np.ascontiguousarray(lookup, np.float64)
+        if tuple(lookup.shape) != (s.C, s.T):
+            raise ValueError(f"lookup must have shape {(s.C, s.T)}")
     scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
     check(load().xsdba_hip_qm_adjust_linear2d(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
                                               _vp(af), _vp(hist_q), C.c_int(G), C.c_int(Q), _vp(gc), _vp(ng), C.c_int(EXTRAP[extrap]),
-                                              C.c_char(kind.encode() if kind else b"\0"), _vp(trend), _vp(scen), _i64(1), _i64(s.T)),
+                                              C.c_char(kind.encode() if kind else b"\0"), _vp(trend), _vp(lookup), C.c_int(int(row)),
+                                              _vp(scen), _i64(1), _i64(s.T)),
           "qm_adjust_linear2d")
     return scen
 
