@@ -496,3 +496,70 @@ def test_poly_detrend():
     np.testing.assert_array_almost_equal(xt.values, x.values)
     fx2 = xs.PolyDetrend.from_dataset(fx.ds)
     np.testing.assert_array_equal(fx2.detrend(x).values, dx.values)
+
+
+class TestPreprocessingInsideTheClasses:
+    """reference tests/test_adjustment.py:494-499 (adapt_freq grouping), :585-596 (explicit adapt_freq == the option),
+    :1085-1130 (jitter inside == jitter outside, on synthetic data instead of the gosset files), :61-70 (harmonize_units)"""
+
+    @pytest.mark.parametrize("group", ["time", "time.month"])
+    def test_adapt_freq_grouping(self, group, random):
+        ref, hist, sim = _cannon_2015_rvs(15000, rng=random)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dqm = xs.DetrendedQuantileMapping.train(ref, hist, kind="*", group=group, adapt_freq_thresh="1 kg m-2 d-1")
+        assert np.isfinite(dqm.adjust(sim).values).all()
+        for v in ("P0_ref", "P0_hist", "pth"):
+            assert v in dqm.ds.data_vars
+
+    def test_adapt_freq_time_explicit(self, random):
+        from xsdba_amd.processing import adapt_freq, jitter_under_thresh
+
+        ref, hist, _ = _cannon_2015_rvs(15000, rng=random)
+        thr = "1 kg m-2/d"
+        np.random.seed(3)
+        ref = jitter_under_thresh(ref, "0.1   kg m-2 / d")
+        hist = jitter_under_thresh(hist, "0.1 kg m-2 / d")
+        np.random.seed(5)
+        hist_ad, _, _ = adapt_freq(ref, hist, group="time", thresh=thr)
+        np.random.seed(5)  # the same draw inside the class (one integer of numpy's generator seeds the device stream)
+        adj = xs.DetrendedQuantileMapping.train(ref, hist, kind="*", group="time", adapt_freq_thresh=thr)
+        np.random.seed(7)
+        out = adj.adjust(hist)
+        adj.adapt_freq_thresh = None
+        out_ad = adj.adjust(hist_ad)
+        # the values the adaptation replaced are random draws (other seed at adjust time): compare where nothing was replaced
+        same = hist.values == hist_ad.values
+        assert same.mean() > 0.9
+        np.testing.assert_allclose(out.values[same], out_ad.values[same], rtol=1e-5)
+
+    def test_jitter_under_and_over_thresh_inside(self, random):
+        from xsdba_amd.processing import jitter_over_thresh, jitter_under_thresh
+
+        n = 12000
+        pr = lambda s: timeseries(np.where(random.random(n) < 0.3, 0.0, random.gamma(2.0, s, n)), units="mm/d")  # noqa: E731
+        ref, hist = pr(3.0), pr(4.0)
+        np.random.seed(42)
+        inside = xs.EmpiricalQuantileMapping.train(ref, hist, jitter_under_thresh_value="0.01 mm/d", group="time").ds.af.values
+        np.random.seed(42)
+        outside = xs.EmpiricalQuantileMapping.train(ref, jitter_under_thresh(hist, "0.01 mm/d"), group="time").ds.af.values
+        np.testing.assert_array_equal(inside, outside)  # the same seed gives the same device stream
+        tas = lambda m: timeseries(np.clip(m + random.standard_normal(n), None, 2.5), units="K")  # noqa: E731
+        ref, hist = tas(1.0), tas(1.5)
+        np.random.seed(42)
+        inside = xs.EmpiricalQuantileMapping.train(ref, hist, jitter_over_thresh_value="2 K", jitter_over_thresh_upper_bnd="3 K", group="time").ds.af.values
+        np.random.seed(42)
+        outside = xs.EmpiricalQuantileMapping.train(ref, jitter_over_thresh(hist, "2 K", "3 K"), group="time").ds.af.values
+        np.testing.assert_array_equal(inside, outside)
+
+    def test_harmonize_units(self, random):
+        from xsdba_amd.adjustment import BaseAdjustment
+        from xsdba_amd.units import convert_units_to
+
+        da = timelonlatseries(random.random(10) + 280, attrs={"units": "K", "kind": ADDITIVE})
+        da2 = convert_units_to(da, "degC")
+        assert da2.attrs["units"] == "degC"
+        np.testing.assert_allclose(da2.values, da.values - 273.15, atol=1e-4)
+        (a, b), _ = BaseAdjustment._harmonize_units(da, da2)
+        assert a.attrs["units"] == b.attrs["units"] == "K"
+        np.testing.assert_allclose(b.values, da.values, atol=1e-4)
