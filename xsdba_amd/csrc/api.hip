@@ -661,6 +661,14 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
     void *scratch;
     if ((rc = ensure(ctx, S_SCR, L.total * (size_t)chunk, &scratch))) return rc;
     const int use_lds = L.staged <= 64 * 1024 ? 1 : 0;
+    void *jrow;  // the row bracket of every time step, shared by all cells
+    if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (size_t)T, &jrow))) return rc;
+    {
+        LaunchScope ls(ctx, "k_lin2d_rows");
+        hipLaunchKernelGGL(xs::k_lin2d_rows, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, ctx->stream, (const double *)dng,
+                           (const double *)dgc, G + 2, T, (int *)jrow);
+    }
+    if ((rc = check_launch("k_lin2d_rows"))) return rc;
     if (use_lds && (rc = set_lds(xs::k_lin2d_adjust<R, true>, L.staged, ctx, "the triangulated table"))) return rc;
     for (int64_t c0 = 0; c0 < C; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, C - c0);
@@ -676,7 +684,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
             const unsigned nblk = (unsigned)std::min<int64_t>(nc, 8 * ctx->n_cu);
             auto launch = [&](auto k, size_t lds) {
                 hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, ctx->stream, (const R *)s.dev + c0 * s.sc, T, nc, s.sc,
-                                   (const double *)dng, (const double *)dgc, G, Q, (const unsigned char *)scratch, L.total, extrap,
+                                   (const double *)dng, (const int *)jrow, G, Q, (const unsigned char *)scratch, L.total, extrap,
                                    (int)kind, dtr ? (const R *)dtr + (size_t)c0 * T : (const R *)nullptr,
                                    (R *)o.kernel_dst + (size_t)c0 * T, T, dlk ? (const double *)dlk + (size_t)c0 * T : (const double *)nullptr);
             };

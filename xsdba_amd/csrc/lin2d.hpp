@@ -15,7 +15,7 @@
 namespace xs {
 
 struct Lin2DLayout {
-    size_t px, py, pv, tv, tn, vt, rowb, hull, meta, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
+    size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
 };
 
 __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
@@ -25,6 +25,7 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
     size_t o = 0;
     L.hdr = o; o += 16;                       // int n, ntri
     L.meta = o; o += 4 * sizeof(double) * (size_t)(G + 2);  // per cyclic row: first x, last x, first y, last y
+    L.gc = o; o += sizeof(double) * (size_t)(G + 2);        // the row coordinates (a copy per cell: staged with the rest)
     L.px = o; o += sizeof(double) * N;
     L.py = o; o += sizeof(double) * N;
     L.pv = o; o += sizeof(double) * N;
@@ -52,9 +53,11 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     double *px = reinterpret_cast<double *>(base + L.px), *py = reinterpret_cast<double *>(base + L.py);
     double *pv = reinterpret_cast<double *>(base + L.pv);
     int *rowb = reinterpret_cast<int *>(base + L.rowb);
+    double *gcs = reinterpret_cast<double *>(base + L.gc);
     int n = 0;
     for (int r = 0; r < G + 2; r++) {
         rowb[r] = n;
+        gcs[r] = gcoord[r];
         const int g = ext_row(r, G);
         // xq_is_row: one abscissa row for every group and cell (QDM: the quantile nodes)
         const R *xr = xq_is_row ? xq : xq + ((size_t)c * G + g) * Q, *yr = yq + ((size_t)c * G + g) * Q;
@@ -98,20 +101,37 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     for (int t = 0; t < ntri; t++) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
 }
 
-// numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside
-__device__ __forceinline__ double np_interp_rows(double x, const double *xp, const double *fp, int stride, int n)
+// numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside.
+// The bracket j of every time step (xp[j] <= x < xp[j+1]; -1 below the first row, -2 at or above the last, -3 NaN) is the
+// same for all cells: k_lin2d_rows finds it once.
+__global__ void k_lin2d_rows(const double *__restrict__ newg, const double *__restrict__ xp, int n, int64_t T, int *__restrict__ jrow)
 {
-    if (x != x) return x;
-    if (x <= xp[0]) return fp[0];
-    if (x >= xp[n - 1]) return fp[(size_t)(n - 1) * stride];
-    int lo = 0, hi = n - 1;  // xp[lo] <= x < xp[hi]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
-    const double f0 = fp[(size_t)lo * stride], f1 = fp[(size_t)hi * stride];
-    if (x == xp[lo]) return f0;
-    const double slope = (f1 - f0) / (xp[hi] - xp[lo]);
-    double res = slope * (x - xp[lo]) + f0;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const double x = newg[t];
+    int j;
+    if (x != x) j = -3;
+    else if (x <= xp[0]) j = -1;
+    else if (x >= xp[n - 1]) j = -2;
+    else {
+        int lo = 0, hi = n - 1;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xp[mid] <= x) lo = mid; else hi = mid; }
+        j = lo;
+    }
+    jrow[t] = j;
+}
+
+__device__ __forceinline__ double np_interp_at(int j, double x, const double *xp, const double *fp, int stride, int n)
+{
+    if (j == -3) return x;
+    if (j == -1) return fp[0];
+    if (j == -2) return fp[(size_t)(n - 1) * stride];
+    const double f0 = fp[(size_t)j * stride], f1 = fp[(size_t)(j + 1) * stride];
+    if (x == xp[j]) return f0;
+    const double slope = (f1 - f0) / (xp[j + 1] - xp[j]);
+    double res = slope * (x - xp[j]) + f0;
     if (res != res) {
-        res = slope * (x - xp[hi]) + f1;
+        res = slope * (x - xp[j + 1]) + f1;
         if (res != res && f0 == f1) res = f0;
     }
     return res;
@@ -121,7 +141,7 @@ __device__ __forceinline__ double np_interp_rows(double x, const double *xp, con
 // scaled series).  dynamic LDS: L.staged bytes when use_lds, else 0.
 template <typename R, bool USE_LDS>
 __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const double *__restrict__ newg,
-                               const double *__restrict__ gcoord, int G, int Q, const unsigned char *__restrict__ scratch,
+                               const int *__restrict__ jrow, int G, int Q, const unsigned char *__restrict__ scratch,
                                size_t stride, int extrap, int kind, const R *__restrict__ trend, R *__restrict__ scen,
                                int64_t osc, const double *__restrict__ lookup)
 {
@@ -142,6 +162,7 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         const int *rowb = reinterpret_cast<const int *>(base + L.rowb);
         const int *hdr = reinterpret_cast<const int *>(base + L.hdr);
         const double *meta = reinterpret_cast<const double *>(base + L.meta);
+        const double *gcoord = reinterpret_cast<const double *>(base + L.gc);
         Tri2D d;
         d.px = reinterpret_cast<const double *>(base + L.px);
         d.py = reinterpret_cast<const double *>(base + L.py);
@@ -164,8 +185,8 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
             const double vx = lk ? lk[t] : (double)v;
             if (vx == vx && g == g && d.n > 0) {  // (a cell without a single valid node stays NaN: utils.py:384-390)
                 // start the walk at a triangle of the node nearest in (row, x): the row next to g, bisection on its abscissae
-                int r0 = 0, r1 = G + 1;
-                while (r1 - r0 > 1) { const int mid = (r0 + r1) >> 1; if (gcoord[mid] <= g) r0 = mid; else r1 = mid; }
+                const int jr = jrow[t];
+                const int r0 = jr == -1 ? 0 : (jr == -2 ? G : jr), r1 = r0 + 1;
                 int r = (g - gcoord[r0] <= gcoord[r1] - g) ? r0 : r1;
                 if (rowb[r + 1] == rowb[r]) r = r == r0 ? r1 : r0;
                 int hint = 0;
@@ -177,13 +198,13 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
                 const int tri = dt_locate(d, vx, g, hint);
                 if (tri >= 0) a = (R)dt_eval(d, pv, tri, vx, g);
                 // nbutils._extrapolate_on_quantiles: below / above the group-interpolated first / last node
-                const double lo = extrap == 0 ? np_interp_rows(g, gcoord, meta, 4, G + 2) : 0.0;
-                const double hi = extrap == 0 ? np_interp_rows(g, gcoord, meta + 1, 4, G + 2) : 0.0;
+                const double lo = extrap == 0 ? np_interp_at(jr, g, gcoord, meta, 4, G + 2) : 0.0;
+                const double hi = extrap == 0 ? np_interp_at(jr, g, gcoord, meta + 1, 4, G + 2) : 0.0;
                 // (only for extrapolation="constant": with "nan" the reference leaves griddata's own NaN outside the hull and
                 // does not call it, utils.py:397-399)
                 if (extrap == 0) {
-                    if (vx < lo) a = (R)np_interp_rows(g, gcoord, meta + 2, 4, G + 2);
-                    if (vx > hi) a = (R)np_interp_rows(g, gcoord, meta + 3, 4, G + 2);
+                    if (vx < lo) a = (R)np_interp_at(jr, g, gcoord, meta + 2, 4, G + 2);
+                    if (vx > hi) a = (R)np_interp_at(jr, g, gcoord, meta + 3, 4, G + 2);
                 }
             }
             R y = kind ? apply_corr<R>(v, a, kind) : a;  // kind 0: the interpolated factor itself (utils.interp_on_quantiles)
