@@ -162,3 +162,27 @@ def test_rank_without_pct_is_computed_on_the_device():
         ok = ~np.isnan(x[c])
         exp[c, ok] = rankdata(x[c, ok], "average")
     np.testing.assert_array_equal(r, exp)
+
+
+def test_rank_over_several_dims_and_random_tiebreak():
+    """utils.rank (utils.py:573-638): a list of dims is ranked together (stacked); use_random_tiebreak breaks the ties at
+    random without moving anything else"""
+    from scipy.stats import rankdata
+
+    from xsdba_amd import utils as u
+
+    rng = np.random.default_rng(10)
+    x = np.round(rng.standard_normal((3, 4, 200)), 1)
+    da = DataArray(x, ("lat", "member", "time"))
+    r = u.rank(da, dim=["time", "member"], pct=False).values
+    for c in range(3):
+        np.testing.assert_array_equal(r[c], rankdata(x[c].ravel(), "average").reshape(4, 200))
+    p = u.rank(da, dim=["time", "member"], pct=True).values
+    assert p.min() == 0.0 and p.max() == 1.0
+    np.random.seed(1)
+    rt = u.rank(da, dim="time", pct=False, use_random_tiebreak=True).values
+    for c in range(3):
+        for m in range(4):
+            assert sorted(rt[c, m]) == list(range(1, 201))  # a permutation: no ties left
+            avg = rankdata(x[c, m], "average")
+            assert np.abs(rt[c, m] - avg).max() <= (np.unique(x[c, m], return_counts=True)[1].max() - 1) / 2 + 1e-9

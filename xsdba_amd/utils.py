@@ -185,20 +185,25 @@ def broadcast(grouped, x, *, group: str | Grouper = "time", interp: str = "neare
 def rank(da, dim: str | list = "time", pct: bool = False, use_random_tiebreak: bool = False):
     """Rank data along a dimension (utils.py:573-638): average ties, NaN stay NaN; ``pct=True`` rescales to [0, 1].
 
-    Computed by the HIP rank kernel (average ranks, or percent ranks).
+    Computed by the HIP rank kernel (average ranks, or percent ranks).  Several dimensions are ranked together (the
+    reference stacks them): the extra ones are laid end to end on the first.  ``use_random_tiebreak``: like the reference,
+    U(0.1, 0.25) noise (numpy's global generator) is added to the average ranks, which are then ranked again.
     """
-    if use_random_tiebreak:
-        raise NotImplementedError("use_random_tiebreak is not implemented on the HIP path")
     da = as_dataarray(da)
     dims = dim if isinstance(dim, list) else [dim]
-    if len(dims) > 1:
-        raise NotImplementedError("multi-dimensional rank is reached through qdm_adjust(rank_window=True) on the HIP path")
-    x2, cell_dims, cell_shape = cell_time_view(da, dims[0])
-    x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
-    T = x2.shape[1]
+    main, extra = dims[0], [d for d in dims[1:] if d in da.dims]
+    cell_dims = tuple(d for d in da.dims if d not in dims)
+    t = da.transpose(*cell_dims, *extra, main)
+    v = t.values.astype(np.result_type(t.values.dtype, np.float32), copy=False)
+    cell_shape, pool_shape, T = v.shape[:len(cell_dims)], v.shape[len(cell_dims):-1], v.shape[-1]
+    x2 = np.ascontiguousarray(v).reshape(int(np.prod(cell_shape, dtype=np.int64)), -1)  # [cell, pooled * T]
+    if use_random_tiebreak:
+        r = hip.rank_groups(x2, None, 1, 1, False, pct=False)
+        noise = np.random.uniform(low=0.1, high=0.25, size=r.shape)
+        x2 = hip.series_correction(r, noise, "+")
     pr = hip.rank_groups(x2, None, 1, 1, False, pct=bool(pct))
     coords = {k: c for k, c in da.coords.items()}
-    out = DataArray(pr.reshape(cell_shape + (T,)), cell_dims + (dims[0],), coords, da.attrs, da.name)
+    out = DataArray(pr.reshape(cell_shape + pool_shape + (T,)), cell_dims + tuple(extra) + (main,), coords, da.attrs, da.name)
     return out.transpose(*da.dims)
 
 
