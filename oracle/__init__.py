@@ -6,6 +6,10 @@ HIP library is missing instead of falling back to this).
 
 All functions take cell-major numpy arrays ``x[C, T]`` (any strides), 0-based ``gidx[T]`` (int32
 group of the window centre), and return new arrays; see the C file for the reference citations.
+
+The functions at the end of this file (``interp_on_quantiles_2d``, ``interp_on_quantiles_1d``, ``polyfit_trend``) are plain
+numpy / scipy: they call the third-party routine the reference itself calls (scipy griddata / interp1d, numpy lstsq)
+composed as the cited reference lines do — the checker for the rows whose arithmetic lives in those libraries.
 """
 from __future__ import annotations
 
