@@ -541,19 +541,36 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
             double sx = 0, sy = 0;
             int n = 0;
-            for (int p = p0; p < p1; p++) {
-                const int t = mem_idx[p];
-                const R v = m[t];
-                if (v == v) { sx += tnum[t]; sy += (double)v; n++; }
+            // the member list, the window means and the time axis are gathers (global / L2 latency): NB members are
+            // fetched before the first is consumed, then accumulated in member order (the sums stay deterministic)
+            constexpr int NB = 8;
+            for (int pb = p0; pb < p1; pb += NB) {
+                int tt[NB];
+                R vv[NB];
+                double xx[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) tt[k] = mem_idx[min(pb + k, p1 - 1)];
+#pragma unroll
+                for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = tnum[tt[k]]; }
+#pragma unroll
+                for (int k = 0; k < NB; k++)
+                    if (pb + k < p1 && vv[k] == vv[k]) { sx += xx[k]; sy += (double)vv[k]; n++; }
             }
             const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
             double slope = 0.0;
             if (degree >= 1 && n >= 2) {
                 double sxx = 0, sxy = 0;
-                for (int p = p0; p < p1; p++) {
-                    const int t = mem_idx[p];
-                    const R v = m[t];
-                    if (v == v) { const double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                for (int pb = p0; pb < p1; pb += NB) {
+                    int tt[NB];
+                    R vv[NB];
+                    double xx[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) tt[k] = mem_idx[min(pb + k, p1 - 1)];
+#pragma unroll
+                    for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = tnum[tt[k]]; }
+#pragma unroll
+                    for (int k = 0; k < NB; k++)
+                        if (pb + k < p1 && vv[k] == vv[k]) { const double dx = xx[k] - xb; sxx += dx * dx; sxy += dx * ((double)vv[k] - yb); }
                 }
                 slope = sxx > 0 ? sxy / sxx : 0.0;
             }
