@@ -202,7 +202,19 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     bool has_nan = false;
     if (t.xstride == 0) {  // one shared abscissa row (xq_row_stride == 0)
         for (int i = threadIdx.x; i < Q; i += blockDim.x) { const R xv = xq[i]; t.xs[i] = xv; has_nan |= xv != xv; }
-        for (int i = threadIdx.x; i < n; i += blockDim.x) { const R yv = yq[i]; t.ys[i] = yv; has_nan |= yv != yv; }
+        {
+            constexpr int NB = 8;  // batched like the straight copy below
+            for (int i0 = threadIdx.x; i0 < n; i0 += NB * blockDim.x) {
+                R yv[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) yv[k] = yq[min(i0 + k * (int)blockDim.x, n - 1)];
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int i = i0 + k * (int)blockDim.x;
+                    if (i < n) { t.ys[i] = yv[k]; has_nan |= yv[k] != yv[k]; }
+                }
+            }
+        }
         CellTab<R> ct;
         ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
         ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.xstride = 0;
@@ -216,11 +228,17 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         return ct;
     }
     if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const R xv = xq[i], yv = yq[i];
-            t.xs[i] = xv;
-            t.ys[i] = yv;
-            has_nan |= (xv != xv) || (yv != yv);
+        // NB elements of each table are requested before the first is stored: one memory latency per batch
+        constexpr int NB = 8;
+        for (int i0 = threadIdx.x; i0 < n; i0 += NB * blockDim.x) {
+            R xv[NB], yv[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) { const int i = min(i0 + k * (int)blockDim.x, n - 1); xv[k] = xq[i]; yv[k] = yq[i]; }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int i = i0 + k * (int)blockDim.x;
+                if (i < n) { t.xs[i] = xv[k]; t.ys[i] = yv[k]; has_nan |= (xv[k] != xv[k]) || (yv[k] != yv[k]); }
+            }
         }
     } else {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -310,7 +328,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
         const R *trc = DQM ? trend + (size_t)c * T : nullptr;
         int *ndc = node ? node + (size_t)c * T : nullptr;
         // EU elements per thread and round: their table searches are independent chains of LDS reads
-        constexpr int EU = DQM ? 1 : 4;
+        constexpr int EU = DQM ? 2 : 4;
         for (int t0 = threadIdx.x; t0 < Ti; t0 += EU * blockDim.x) {
             R v[EU], tr[EU], a[EU];
             int g0[EU], nd[EU];
@@ -413,13 +431,27 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     R *tr_out = trend_cm + (size_t)c * T;
     for (int i = threadIdx.x; i <= W; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
     R *m = M_LDS ? xs + T : tr_out;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-        R v = x[t * st];
-        if (scaling) {
-            int g = gidx[t];
-            v = apply_corr<R>(v, g >= 0 ? scaling[(size_t)c * G + g] : nan_of<R>(), kind);
+    {
+        constexpr int NB = 8;  // NB series values (and their groups) are requested before the first is consumed
+        for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
+            R v[NB];
+            int gg[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int64_t t = t0 + (int64_t)k * blockDim.x, tc = t < T ? t : T - 1;
+                v[k] = x[tc * st];
+                gg[k] = scaling ? gidx[tc] : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int64_t t = t0 + (int64_t)k * blockDim.x;
+                if (t < T) {
+                    R w = v[k];
+                    if (scaling) w = apply_corr<R>(w, gg[k] >= 0 ? scaling[(size_t)c * G + gg[k]] : nan_of<R>(), kind);
+                    xs[t] = w;
+                }
+            }
         }
-        xs[t] = v;
     }
     __syncthreads();
     const int h = W / 2;
@@ -610,9 +642,20 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         }
     }
     __syncthreads();
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) {
-        int g = gidx[t];
-        tr_out[t] = g >= 0 ? (R)(coef[3 * g + 1] + coef[3 * g + 2] * (tnum[t] - coef[3 * g])) : nan_of<R>();
+    {
+        constexpr int NB = 4;
+        for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
+            int gg[NB];
+            double xx[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) { const int64_t t = t0 + (int64_t)k * blockDim.x, tc = t < T ? t : T - 1; gg[k] = gidx[tc]; xx[k] = tnum[tc]; }
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const int64_t t = t0 + (int64_t)k * blockDim.x;
+                const int g = gg[k];
+                if (t < T) tr_out[t] = g >= 0 ? (R)(coef[3 * g + 1] + coef[3 * g + 2] * (xx[k] - coef[3 * g])) : nan_of<R>();
+            }
+        }
     }
 }
 
@@ -667,7 +710,16 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         if (tab_global) { ctg = tab_stage<R>(tlg, quantiles, 0, af + (size_t)c * G * Q, G, Q); tab_spline<R>(ctg, tlg, interp); }
     }
     const R *x = sim + c * sc;
-    for (int64_t t = threadIdx.x; t < T; t += blockDim.x) xs[t] = x[t * st];
+    {
+        constexpr int NB = 8;  // the whole series is requested in batches of NB loads per thread
+        for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
+            R v[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) { const int64_t t = t0 + (int64_t)k * blockDim.x; v[k] = x[(t < T ? t : T - 1) * st]; }
+#pragma unroll
+            for (int k = 0; k < NB; k++) { const int64_t t = t0 + (int64_t)k * blockDim.x; if (t < T) xs[t] = v[k]; }
+        }
+    }
     __syncthreads();
     if (sort_w) {
         // sorted ranking rows: sort_w lanes per row, 64 / sort_w rows per wave; UNR independent rows per lane keep the
