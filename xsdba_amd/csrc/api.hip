@@ -17,6 +17,7 @@
 #include "../../include/xsdba_hip.h"
 #include "kernels.hpp"
 #include "lin2d.hpp"
+#include "train_cell3.hpp"
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
 #include "train_long.hpp"
@@ -465,7 +466,26 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 return pl->d_tog64 ? go(cfg, false_type{}, dqm, true_type{}) : go(cfg, false_type{}, dqm, false_type{});
             };
             auto pick_dqm = [&](auto cfg) -> int { return mode == 2 ? pick_t64(cfg, true_type{}) : pick_t64(cfg, false_type{}); };
-            if (dbg && ept == 11 && mode != 2 && pl->d_tog64)  // timing aids (XSDBA_HIP_DEBUG_PHASE): diagnostic build
+            // three group streams per wave (train_cell3.hpp): plain / EQM quantiles of up to 21 nodes on windowed day-of-year-like
+            // groups (padded toggle table, at least three groups per wave).  XSDBA_HIP_TRAIN3=0 pins the two-stream kernel.
+            auto go3 = [&](auto cfg) -> int {
+                constexpr int EPT = decltype(cfg)::value;
+                const size_t lds = xs::CellCfg3<EPT>::lds_bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_cell3<EPT>, lds, ctx, "the per-cell sort"))) return rc2;
+                const int gm = getenv("XSDBA_HIP_GRID_MULT") ? atoi(getenv("XSDBA_HIP_GRID_MULT")) : 4;
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)std::max(gm, 1) * ctx->n_cu);
+                LaunchScope ls(ctx, "k_train_cell3");
+                hipLaunchKernelGGL((xs::k_train_cell3<EPT>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, G, (const float *)dq, Q, (int)kind, mode,
+                                   (float *)oaf.dev, (float *)ohq.dev, flag_count, flag_list, C, pl->d_tog64);
+                return check_launch("k_train_cell3");
+            };
+            const char *t3 = getenv("XSDBA_HIP_TRAIN3");
+            const bool three = !dbg && mode != 2 && pl->d_tog64 && Q <= 21 && G >= 48 && !(t3 && !strcmp(t3, "0"));
+            if (three)
+                rc = ept == 4 ? go3(integral_constant<int, 4>{}) : ept == 8 ? go3(integral_constant<int, 8>{}) : go3(integral_constant<int, 11>{});
+            else if (dbg && ept == 11 && mode != 2 && pl->d_tog64)  // timing aids (XSDBA_HIP_DEBUG_PHASE): diagnostic build
                 rc = go(integral_constant<int, 11>{}, true_type{}, false_type{}, true_type{});
             else rc = ept == 4 ? pick_dqm(integral_constant<int, 4>{})
                  : ept == 8 ? pick_dqm(integral_constant<int, 8>{})

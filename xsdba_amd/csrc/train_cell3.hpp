@@ -1,0 +1,258 @@
+// train_cell3.hpp — k_train_cell with THREE group streams per wave (float32, EQM / plain quantiles, Q <= 21, the padded
+// [G][64] toggle table).
+//
+// Phase C of k_train_cell serves one quantile per lane and two streams per wave: with the usual 20 quantiles, 40 of 64
+// lanes work in the select — the most expensive part of a group step — and its instruction count does not depend on how
+// many lanes take part.  Here a wave walks three streams (21 lanes each, lane 63 idle): the wave's groups [r0, r1) are cut
+// in three runs, B walks down from gb - 1, A up from gb, C up from gb + nA.  ONE vector is built (group gb) and copied
+// twice; C first fast-forwards nA toggle lists without selecting.  A third fewer group steps per wave for the same select
+// cost; the popcount scan runs twice (A|B packed, C alone) and the owner-lane bisection reads two registers per step.
+// LDS: three vectors per wave only fit because rank[] moves into the u16 index buffer the sort leaves free and the
+// vectors are packed at 354 words (the last word any lane of a T <= 11264 series owns) instead of 384.
+#pragma once
+#include "train_cell.hpp"
+
+namespace xs {
+
+template <int EPT> struct CellCfg3 {
+    using Base = CellCfg<EPT>;
+    static constexpr int NT = 1024, TPAD = Base::TPAD, WPL = Base::WPL, NWAVE = Base::NWAVE;
+    static constexpr int VSTRIDE = ((TPAD / 32 + WPL - 1) / WPL) * WPL;  // words per vector: whole lanes
+    static constexpr int NLANE = VSTRIDE / WPL;                          // lanes that own words
+    static constexpr size_t off_bits = Base::off_union;
+    static constexpr size_t sel_end = off_bits + (size_t)3 * NWAVE * VSTRIDE * 4;
+    static constexpr size_t off_misc = ((Base::sort_end > sel_end ? Base::sort_end : sel_end) + 15) & ~(size_t)15;
+    static constexpr size_t lds_bytes = off_misc + 64 * 8;
+};
+
+template <int EPT>
+__device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
+                                                      int lane, int wid, const int *__restrict__ row_ptr,
+                                                      const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
+                                                      const float *__restrict__ q, int Q, int kind, int mode, int arr, int64_t c,
+                                                      float *__restrict__ af, float *out_hq, bool &flag_cell)
+{
+    using Cfg = CellCfg3<EPT>;
+    constexpr int TPAD = Cfg::TPAD, WPL = Cfg::WPL, VS = Cfg::VSTRIDE, NL = Cfg::NLANE, QL = 21;
+    const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
+    const int r0 = min(G, wid * gpw), r1 = min(G, r0 + gpw), n = r1 - r0;
+    if (n <= 0) return;
+    const int nA = (n + 2) / 3, nB = (n - nA + 1) / 2, nC = n - nA - nB;  // nA >= nB >= nC; nA iterations
+    const int gb = r0 + nB, gc3 = gb + nA;
+    uint32_t *bA = bits_all + (size_t)(3 * wid) * VS, *bB = bA + VS, *bC = bB + VS;
+    for (int i = lane; i < VS; i += 64) bA[i] = 0u;
+    lds_wave_fence();
+    const int sid = lane / QL, k = lane - QL * sid;  // lane 63: sid 3, takes no part
+    const uint32_t *bits_s = sid == 0 ? bA : (sid == 1 ? bB : bC);
+    auto flip = [&](uint32_t *bits, int t) {
+        if (t >= 0) {
+            const int r = (int)rank[t];
+            if (r < nvalid) (void)__hip_atomic_fetch_xor(&bits[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    // ---- the vector of group gb from its row list, copied to B and C
+    {
+        const int *l = row_sorted + row_ptr[gb];
+        const int len = row_ptr[gb + 1] - row_ptr[gb];
+        for (int i0 = 0; i0 < len; i0 += 512) {
+            int ts[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) flip(bA, ts[u]);
+        }
+        lds_wave_fence();
+        for (int i = lane; i < VS; i += 64) { const uint32_t w = bA[i]; bB[i] = w; bC[i] = w; }
+        lds_wave_fence();
+    }
+    // ---- C fast-forwards to group gc3 (lists gb+1 .. gc3), four lists in flight
+    if (nC > 0) {
+        for (int s0 = 1; s0 <= nA; s0 += 4) {
+            int ts[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) ts[u] = s0 + u <= nA ? tog64[(size_t)(gb + s0 + u) * 64 + lane] : -1;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { flip(bC, ts[u]); lds_wave_fence(); }  // the same element may toggle twice: keep the order
+        }
+    }
+    // ---- lock-step walk; the next lists are prefetched under the select
+    int preA = -1, preB = -1, preC = -1;
+    if (nA > 1) preA = tog64[(size_t)(gb + 1) * 64 + lane];
+    if (nB > 0) preB = tog64[(size_t)gb * 64 + lane];
+    if (nC > 1) preC = tog64[(size_t)(gc3 + 1) * 64 + lane];
+    int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case = 3, c_lo = 0;
+    float c_gamma = 0.f;
+    for (int it = 0; it < nA; it++) {
+        const bool vB = it < nB, vC = it < nC;
+        const int tA = it > 0 ? preA : -1, tB = vB ? preB : -1, tC = (it > 0 && vC) ? preC : -1;
+        flip(bA, tA);
+        flip(bB, tB);
+        flip(bC, tC);
+        if (it + 1 < nA) preA = tog64[(size_t)(gb + it + 1) * 64 + lane];
+        if (it + 1 < nB) preB = tog64[(size_t)(gb - it - 1) * 64 + lane];
+        if (it + 1 < nC) preC = tog64[(size_t)(gc3 + it + 1) * 64 + lane];
+        lds_wave_fence();
+        // per-lane member counts: A | B packed in one register, C in another; two prefix scans
+        int clAB = 0, clC = 0;
+        if (lane < NL) {
+#pragma unroll
+            for (int j = 0; j < WPL; j++) {
+                clAB += __popc(bA[lane * WPL + j]) + (__popc(bB[lane * WPL + j]) << 16);
+                clC += __popc(bC[lane * WPL + j]);
+            }
+        }
+        const int inAB = wave_incl_scan(clAB), inC = wave_incl_scan(clC);
+        const int exAB = inAB - clAB, exC = inC - clC;
+        const int totAB = __builtin_amdgcn_readlane(inAB, 63), cntC = __builtin_amdgcn_readlane(inC, 63);
+        const int cntA = totAB & 0xFFFF, cntB = (int)((unsigned)totAB >> 16);
+        const unsigned long long balA = __ballot((clAB & 0xFFFF) != 0), balB = __ballot(((unsigned)clAB >> 16) != 0u), balC = __ballot(clC != 0);
+        const int ns = sid == 0 ? cntA : (sid == 1 ? cntB : cntC);
+        const int g = sid == 0 ? gb + it : (sid == 1 ? gb - 1 - it : gc3 + it);
+        const bool vs = sid == 0 || (sid == 1 && vB) || (sid == 2 && vC);
+        const bool act = vs && k < Q;
+        // quantile-index math depends on (n, k) only: cached while the three streams keep their counts
+        int casek, lo;  // 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
+        float gamma;
+        if (cntA == nA_prev && cntB == nB_prev && cntC == nC_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
+        else {
+            const double qk = (double)q[k < Q ? k : 0];
+            const double vi = (double)ns * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
+            lo = 0; gamma = 0.f;
+            if (ns == 0) casek = 3;
+            else if (vi != vi || vi >= (double)(ns - 1)) { casek = 1; lo = ns - 1; }
+            else if (vi < 0.0) { casek = 2; lo = 0; }
+            else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
+            c_case = casek; c_lo = lo; c_gamma = gamma;
+        }
+        nA_prev = cntA; nB_prev = cntB; nC_prev = cntC;
+        // owner lane of member `lo`: the last lane whose exclusive count is <= lo (branch-free bisection; every step reads
+        // both scan registers of the candidate lane and keeps this stream's field)
+        int L4 = 0, eL = 0;
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const int cand4 = L4 + 4 * s;
+            const int eab = __builtin_amdgcn_ds_bpermute(cand4, exAB), ec = __builtin_amdgcn_ds_bpermute(cand4, exC);
+            const int e = sid == 0 ? (eab & 0xFFFF) : (sid == 1 ? (int)((unsigned)eab >> 16) : ec);
+            const bool ok = e <= lo;
+            L4 = ok ? cand4 : L4;
+            eL = ok ? e : eL;
+        }
+        int L = L4 >> 2;
+        L = min(L, NL - 1);  // (empty streams / idle lanes: stay inside the vector)
+        int rem = lo - eL;
+        const uint32_t *wp = bits_s + L * WPL;
+        uint32_t wv[WPL];
+#pragma unroll
+        for (int i = 0; i < WPL; i++) wv[i] = wp[i];
+        bool ge[WPL];
+        int run = 0, sub = 0, wi = 0;
+        uint32_t w = wv[0];
+#pragma unroll
+        for (int i = 0; i < WPL - 1; i++) {
+            run += __popc(wv[i]);
+            ge[i] = rem >= run;
+            w = ge[i] ? wv[i + 1] : w;
+            sub = ge[i] ? run : sub;
+            wi = ge[i] ? i + 1 : wi;
+        }
+        rem -= sub;
+        int nw = 0;
+        uint32_t nwv = 0u;
+#pragma unroll
+        for (int i = WPL - 1; i >= 1; i--) {
+            const bool cnd = wv[i] != 0u && !ge[i - 1];
+            nw = cnd ? i : nw;
+            nwv = cnd ? wv[i] : nwv;
+        }
+        const uint32_t wsel = w;
+        int pos = 0;
+#pragma unroll
+        for (int s = 16; s > 0; s >>= 1) {
+            const int cw = __popc(w & ((1u << s) - 1u));
+            const bool g2 = rem >= cw;
+            rem -= g2 ? cw : 0;
+            w = g2 ? (w >> s) : w;
+            pos += g2 ? s : 0;
+        }
+        const int wbase = L * WPL * 32;
+        const int lrank = wbase + wi * 32 + pos;
+        const uint32_t rest = (wsel >> pos) >> 1;
+        const bool inword = rest != 0u;
+        const bool found = inword || nw != 0;
+        int hrank = inword ? lrank + __ffs((int)rest) : wbase + nw * 32 + __ffs((int)nwv) - 1;
+        const bool need_slow = casek == 0 && !found && sid < 3;
+        if (__any(need_slow)) {
+            const unsigned long long bal = sid == 0 ? balA : (sid == 1 ? balB : balC);
+            const unsigned long long restm = L < 63 ? (bal >> (L + 1)) : 0ull;
+            const int L2 = min(restm ? L + __ffsll(restm) : L, NL - 1);
+            const uint32_t *wp2 = bits_s + L2 * WPL;
+            uint32_t w2[WPL];
+#pragma unroll
+            for (int i = 0; i < WPL; i++) w2[i] = wp2[i];
+            int hr2 = 0;
+#pragma unroll
+            for (int i = WPL - 1; i >= 0; i--) hr2 = w2[i] != 0u ? i * 32 + __ffs((int)w2[i]) - 1 : hr2;
+            if (need_slow) hrank = L2 * WPL * 32 + hr2;
+        }
+        const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
+        float v, vhi;
+        vals.at_ranks(rs0, rs1, v, vhi);
+        float res;
+        if (casek == 3) res = __builtin_nanf("");
+        else if (casek != 0) res = v;
+        else {
+            const float diff = vhi - v;
+            if (gamma >= 0.5f) res = (float)((double)vhi - (double)diff * (1.0 - (double)gamma));
+            else res = v + diff * gamma;
+            if (res != res && act) flag_cell = true;  // inf - inf: the generic kernel redoes the cell
+        }
+        if (act) {
+            const size_t o = ((size_t)c * G + g) * (size_t)Q + k;
+            if (mode == 0 || arr == 0) out_hq[o] = res;
+            else af[o] = get_corr<float>(out_hq[o], res, kind);
+        }
+    }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc,
+                                                       const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, int G,
+                                                       const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af,
+                                                       float *out_hq, int *__restrict__ flag_count, int *__restrict__ flag_list,
+                                                       int64_t C, const int *__restrict__ tog64)
+{
+    using Cfg = CellCfg<EPT>;
+    using Cfg3 = CellCfg3<EPT>;
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
+    uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0), *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
+    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg3::off_bits);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg3::off_misc);
+    const int tid = threadIdx.x, wid = tid >> 6;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const int npass_arr = mode == 0 ? 1 : 2;
+        bool flag_cell = false;
+        for (int arr = 0; arr < npass_arr; arr++) {
+            int lane = tid & 63;
+            __asm__ volatile("" : "+v"(lane));
+            const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;  // hist first, then ref (see k_train_cell)
+            int nvalid;
+            const uint16_t *sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid);  // no rank[] in the union region
+            uint16_t *rank = sorted == idx0 ? idx1 : idx0;                               // the buffer the sort left free
+            for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
+            __syncthreads();
+            const LdsVals vals{keys, sorted, TPAD};
+            cell_group_quantiles3<EPT>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode, arr, c,
+                                       af, out_hq, flag_cell);
+            __syncthreads();
+        }
+        const int any = __syncthreads_or(flag_cell ? 1 : 0);
+        if (any && tid == 0 && flag_list) {
+            const int slot = atomicAdd(flag_count, 1);
+            flag_list[slot] = (int)c;
+        }
+    }
+}
+
+}  // namespace xs
