@@ -25,12 +25,16 @@ template <int EPT> struct CellCfg3 {
     static constexpr size_t lds_bytes = off_misc + 64 * 8;
 };
 
-template <int EPT>
+// P10: every group row holds < 1024 values (day-of-year windows over up to ~33 years): the three per-lane counts share ONE
+// register (10-bit fields), one prefix scan and one bpermute per bisection step serve all three streams.
+// DQM: group means from running float64 sums updated by the same toggles (one per stream), normalisation of the selected
+// order statistics, scaling — with the guards of cell_group_quantiles (train_cell.hpp).
+template <int EPT, bool P10, bool DQM>
 __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
                                                       const float *__restrict__ q, int Q, int kind, int mode, int arr, int64_t c,
-                                                      float *__restrict__ af, float *out_hq, bool &flag_cell)
+                                                      float *__restrict__ af, float *out_hq, float *scaling, bool &flag_cell)
 {
     using Cfg = CellCfg3<EPT>;
     constexpr int TPAD = Cfg::TPAD, WPL = Cfg::WPL, VS = Cfg::VSTRIDE, NL = Cfg::NLANE, QL = 21;
@@ -44,12 +48,30 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
     lds_wave_fence();
     const int sid = lane / QL, k = lane - QL * sid;  // lane 63: sid 3, takes no part
     const uint32_t *bits_s = sid == 0 ? bA : (sid == 1 ? bB : bC);
-    auto flip = [&](uint32_t *bits, int t) {
+    double amax = 0.0;  // DQM: largest magnitude this lane pushed through the running sums
+    auto flip = [&](uint32_t *bits, int t, double &dloc) {
         if (t >= 0) {
             const int r = (int)rank[t];
-            if (r < nvalid) (void)__hip_atomic_fetch_xor(&bits[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (r < nvalid) {
+                const uint32_t m = 1u << (r & 31);
+                if (DQM) {
+                    const uint32_t old = atomicXor(&bits[r >> 5], m);
+                    const float v = vals.at_time(t);
+                    dloc += (old & m) ? -(double)v : (double)v;
+                    amax = fmax(amax, fabs((double)v));
+                } else {
+                    (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
         }
     };
+    double dlocA = 0.0, dlocB = 0.0, dlocC = 0.0, gsumA = 0.0, gsumB = 0.0, gsumC = 0.0;
+    if (DQM && kind == '+' && wid == 0 && lane == 0 && nvalid > 1) {  // additive kind: extremes against the IQR, once per array
+        float lo, hi, q1, q3;
+        vals.at_ranks(0, nvalid - 1, lo, hi);
+        vals.at_ranks(nvalid / 4, (3 * nvalid) / 4, q1, q3);
+        if (!(fmax(fabs((double)lo), fabs((double)hi)) <= 1.0e8 * ((double)q3 - (double)q1))) flag_cell = true;
+    }
     // ---- the vector of group gb from its row list, copied to B and C
     {
         const int *l = row_sorted + row_ptr[gb];
@@ -59,7 +81,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
 #pragma unroll
             for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) flip(bA, ts[u]);
+            for (int u = 0; u < 8; u++) flip(bA, ts[u], dlocA);
         }
         lds_wave_fence();
         for (int i = lane; i < VS; i += 64) { const uint32_t w = bA[i]; bB[i] = w; bC[i] = w; }
@@ -72,7 +94,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
 #pragma unroll
             for (int u = 0; u < 4; u++) ts[u] = s0 + u <= nA ? tog64[(size_t)(gb + s0 + u) * 64 + lane] : -1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { flip(bC, ts[u]); lds_wave_fence(); }  // the same element may toggle twice: keep the order
+            for (int u = 0; u < 4; u++) { flip(bC, ts[u], dlocC); lds_wave_fence(); }  // (DQM reads the old bit: one list at a time)
         }
     }
     // ---- lock-step walk; the next lists are prefetched under the select
@@ -85,31 +107,53 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
     for (int it = 0; it < nA; it++) {
         const bool vB = it < nB, vC = it < nC;
         const int tA = it > 0 ? preA : -1, tB = vB ? preB : -1, tC = (it > 0 && vC) ? preC : -1;
-        flip(bA, tA);
-        flip(bB, tB);
-        flip(bC, tC);
+        flip(bA, tA, dlocA);
+        flip(bB, tB, dlocB);
+        flip(bC, tC, dlocC);
         if (it + 1 < nA) preA = tog64[(size_t)(gb + it + 1) * 64 + lane];
         if (it + 1 < nB) preB = tog64[(size_t)(gb - it - 1) * 64 + lane];
         if (it + 1 < nC) preC = tog64[(size_t)(gc3 + it + 1) * 64 + lane];
         lds_wave_fence();
         // per-lane member counts: A | B packed in one register, C in another; two prefix scans
+        constexpr int FB = P10 ? 10 : 16;            // field width of A and B
+        constexpr int FM = (1 << FB) - 1;
         int clAB = 0, clC = 0;
         if (lane < NL) {
 #pragma unroll
             for (int j = 0; j < WPL; j++) {
-                clAB += __popc(bA[lane * WPL + j]) + (__popc(bB[lane * WPL + j]) << 16);
-                clC += __popc(bC[lane * WPL + j]);
+                clAB += __popc(bA[lane * WPL + j]) + (__popc(bB[lane * WPL + j]) << FB);
+                if (P10) clAB += __popc(bC[lane * WPL + j]) << 20;
+                else clC += __popc(bC[lane * WPL + j]);
             }
         }
-        const int inAB = wave_incl_scan(clAB), inC = wave_incl_scan(clC);
+        const int inAB = wave_incl_scan(clAB), inC = P10 ? 0 : wave_incl_scan(clC);
         const int exAB = inAB - clAB, exC = inC - clC;
-        const int totAB = __builtin_amdgcn_readlane(inAB, 63), cntC = __builtin_amdgcn_readlane(inC, 63);
-        const int cntA = totAB & 0xFFFF, cntB = (int)((unsigned)totAB >> 16);
-        const unsigned long long balA = __ballot((clAB & 0xFFFF) != 0), balB = __ballot(((unsigned)clAB >> 16) != 0u), balC = __ballot(clC != 0);
+        const int totAB = __builtin_amdgcn_readlane(inAB, 63);
+        const int cntA = totAB & FM, cntB = (totAB >> FB) & FM;
+        const int cntC = P10 ? ((totAB >> 20) & FM) : __builtin_amdgcn_readlane(inC, 63);
+        const unsigned long long balA = __ballot((clAB & FM) != 0), balB = __ballot(((clAB >> FB) & FM) != 0),
+                                 balC = __ballot(P10 ? ((clAB >> 20) & FM) != 0 : clC != 0);
         const int ns = sid == 0 ? cntA : (sid == 1 ? cntB : cntC);
         const int g = sid == 0 ? gb + it : (sid == 1 ? gb - 1 - it : gc3 + it);
         const bool vs = sid == 0 || (sid == 1 && vB) || (sid == 2 && vC);
         const bool act = vs && k < Q;
+        float mu = 0.f, inv = 0.f;
+        if (DQM) {
+            // it == 0: dlocA holds the sum of the built vector (B and C start from it), dlocC the fast-forward of C on top
+            const double sA = __shfl(wave_sum(dlocA), 0, 64), sB = __shfl(wave_sum(dlocB), 0, 64), sC = __shfl(wave_sum(dlocC), 0, 64);
+            dlocA = dlocB = dlocC = 0.0;
+            if (it == 0) { gsumB = sA; gsumC = sA; }
+            gsumA += sA;
+            gsumB += sB;
+            gsumC += sC;
+            const double gs = sid == 0 ? gsumA : (sid == 1 ? gsumB : gsumC);
+            mu = ns ? (float)(gs / (double)ns) : __builtin_nanf("");
+            inv = invert<float>(mu, kind);
+            if (vs && sid < 3 && ns && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
+            const double inf = __builtin_inf();
+            const double gmin = fmin(fmin(cntA ? fabs(gsumA) : inf, (vB && cntB) ? fabs(gsumB) : inf), (vC && cntC) ? fabs(gsumC) : inf);
+            if (kind == '*' && !(amax <= 1.0e6 * gmin)) flag_cell = true;  // see cell_group_quantiles: rounding of the running sums
+        }
         // quantile-index math depends on (n, k) only: cached while the three streams keep their counts
         int casek, lo;  // 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
         float gamma;
@@ -131,8 +175,10 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) {
             const int cand4 = L4 + 4 * s;
-            const int eab = __builtin_amdgcn_ds_bpermute(cand4, exAB), ec = __builtin_amdgcn_ds_bpermute(cand4, exC);
-            const int e = sid == 0 ? (eab & 0xFFFF) : (sid == 1 ? (int)((unsigned)eab >> 16) : ec);
+            const int eab = __builtin_amdgcn_ds_bpermute(cand4, exAB);
+            int e;
+            if (P10) e = (eab >> (10 * (sid < 3 ? sid : 0))) & FM;
+            else { const int ec = __builtin_amdgcn_ds_bpermute(cand4, exC); e = sid == 0 ? (eab & 0xFFFF) : (sid == 1 ? (int)((unsigned)eab >> 16) : ec); }
             const bool ok = e <= lo;
             L4 = ok ? cand4 : L4;
             eL = ok ? e : eL;
@@ -197,6 +243,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
         const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
         float v, vhi;
         vals.at_ranks(rs0, rs1, v, vhi);
+        if (DQM) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
         float res;
         if (casek == 3) res = __builtin_nanf("");
         else if (casek != 0) res = v;
@@ -211,15 +258,19 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
             if (mode == 0 || arr == 0) out_hq[o] = res;
             else af[o] = get_corr<float>(out_hq[o], res, kind);
         }
+        if (DQM && vs && sid < 3 && k == 0) {
+            if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced by the factor in the ref pass
+            else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
+        }
     }
 }
 
-template <int EPT>
+template <int EPT, bool P10, bool DQM>
 __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc,
                                                        const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, int G,
                                                        const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af,
-                                                       float *out_hq, int *__restrict__ flag_count, int *__restrict__ flag_list,
-                                                       int64_t C, const int *__restrict__ tog64)
+                                                       float *out_hq, float *scaling, int *__restrict__ flag_count,
+                                                       int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64)
 {
     using Cfg = CellCfg<EPT>;
     using Cfg3 = CellCfg3<EPT>;
@@ -243,8 +294,8 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
             __syncthreads();
             const LdsVals vals{keys, sorted, TPAD};
-            cell_group_quantiles3<EPT>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode, arr, c,
-                                       af, out_hq, flag_cell);
+            cell_group_quantiles3<EPT, P10, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode,
+                                                 arr, c, af, out_hq, scaling, flag_cell);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
