@@ -140,12 +140,17 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
         float mu = 0.f, inv = 0.f;
         if (DQM) {
             // it == 0: dlocA holds the sum of the built vector (B and C start from it), dlocC the fast-forward of C on top
-            const double sA = __shfl(wave_sum(dlocA), 0, 64), sB = __shfl(wave_sum(dlocB), 0, 64), sC = __shfl(wave_sum(dlocC), 0, 64);
+            // (the totals sit in lane 0; read into scalar registers: the running sums are wave-uniform and stay out of the VGPRs)
+            auto uni = [](double v) {
+                const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+                return __hiloint2double(hi, lo);
+            };
+            const double sA = uni(wave_sum(dlocA)), sB = uni(wave_sum(dlocB)), sC = uni(wave_sum(dlocC));
             dlocA = dlocB = dlocC = 0.0;
             if (it == 0) { gsumB = sA; gsumC = sA; }
-            gsumA += sA;
-            gsumB += sB;
-            gsumC += sC;
+            gsumA = uni(gsumA + sA);
+            gsumB = uni(gsumB + sB);
+            gsumC = uni(gsumC + sC);
             const double gs = sid == 0 ? gsumA : (sid == 1 ? gsumB : gsumC);
             mu = ns ? (float)(gs / (double)ns) : __builtin_nanf("");
             inv = invert<float>(mu, kind);
