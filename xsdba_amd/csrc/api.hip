@@ -612,7 +612,11 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
         if (tab <= (size_t)ctx->lds_limit) {
             if ((rc = set_lds(xs::k_qm_adjust<R, true, GROUPED, DQM>, tab, ctx, "the factor table"))) return rc;
             LaunchScope ls(ctx, name);
-            hipLaunchKernelGGL((xs::k_qm_adjust<R, true, GROUPED, DQM>), dim3((unsigned)C), dim3(adj_threads()), tab, ctx->stream,
+            // big tables leave room for two blocks per CU only: 12 waves each hide the table-staging and gather latencies best
+            // (measured on the doy table, 68.6 KB: 512 threads 3.51 ms, 640 3.81, 768 2.92, 896 4.32, 1024 3.99; small tables
+            // keep 512: many blocks per CU already)
+            const unsigned nthr = (!getenv("XSDBA_HIP_ADJ_THREADS") && tab > 54 * 1024) ? 768u : adj_threads();
+            hipLaunchKernelGGL((xs::k_qm_adjust<R, true, GROUPED, DQM>), dim3((unsigned)C), dim3(nthr), tab, ctx->stream,
                                (const R *)s.dev, T, C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node,
                                scaling, trend_cm, (unsigned char *)nullptr, (size_t)0, tkind, skip0);
         } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
