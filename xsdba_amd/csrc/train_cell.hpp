@@ -38,6 +38,25 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
+// wave total of a double on the DPP cross-lane path (the steps of wave_incl_scan on both halves of the value; lanes without
+// a source add +0.0), read from lane 63 into scalar registers: wave-uniform
+__device__ __forceinline__ double wave_total_dpp(double v)
+{
+    auto step = [&](auto ctrl, auto rmask) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    };
+    using std::integral_constant;
+    step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+    step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ __forceinline__ void lds_wave_fence() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int EPT> struct CellCfg {
@@ -422,7 +441,7 @@ __device__ __forceinline__ void cell_group_quantiles(
             R mu = (R)0, inv = (R)0;
             if (DQM) {
                 // at it == 0 dlocA holds the sum of the built vector, which B starts from, and dlocB B's first toggles
-                const double sA = __shfl(wave_sum(dlocA), 0, 64), sB = __shfl(wave_sum(dlocB), 0, 64);
+                const double sA = wave_total_dpp(dlocA), sB = wave_total_dpp(dlocB);
                 if (it == 0) gsumB = sA;
                 gsumA += sA;
                 gsumB += sB;
