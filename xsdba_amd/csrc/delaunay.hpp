@@ -223,9 +223,13 @@ XS_HD int dt_locate(const Tri2D &d, double qx, double qy, int start)
             const int nb = d.tn[3 * t + k];
             if (nb == from && from >= 0) continue;
             const double o = dt_orient_q(d, a, b, qx, qy);
-            const double scale = (fabs(d.px[b] - d.px[a]) + fabs(d.py[b] - d.py[a])) * (fabs(qx - d.px[a]) + fabs(qy - d.py[a]) + 1.0);
-            if (o < -2.3e-14 * scale) {
-                if (nb == DT_NONE) return -1;
+            if (o < 0.0) {
+                if (nb == DT_NONE) {
+                    // a hull edge: only a point clearly beyond it is outside (the tolerance is evaluated here alone)
+                    const double scale = (fabs(d.px[b] - d.px[a]) + fabs(d.py[b] - d.py[a])) * (fabs(qx - d.px[a]) + fabs(qy - d.py[a]) + 1.0);
+                    if (o < -2.3e-14 * scale) return -1;
+                    continue;
+                }
                 go = nb;
                 moved = true;
                 break;
