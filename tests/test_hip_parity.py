@@ -764,3 +764,27 @@ def test_nan_mask_large(hip, train_kernel):
     oaf, ohq = oracle.eqm_train(ref[sub], hist[sub], gidx, G, W, q, "+")
     assert_close(eqhq[sub], ohq, rtol=0.0, what="eqm hist_q with NaN mask")
     assert_close(eqaf[sub], oaf, rtol=0.0, what="eqm af with NaN mask")
+
+
+@pytest.mark.parametrize("method", ["eqm", "dqm"])
+def test_three_and_two_stream_train_kernels_agree(hip, monkeypatch, method, train_kernel):
+    """k_train_cell3 (three group streams per wave: the default for windowed day-of-year groups with <= 21 quantiles) and
+    the two-stream k_train_cell (XSDBA_HIP_TRAIN3=0) select the same order statistics: bit-identical tables"""
+    if train_kernel != "cell":
+        pytest.skip("compares the two per-cell kernels")
+    rng = np.random.default_rng(77)
+    C, T, Q = 5, 10 * 365, 20
+    ref = (280 + 8 * rng.standard_normal((C, T))).astype(np.float32)
+    hist = (282 + 9 * rng.standard_normal((C, T))).astype(np.float32)
+    hist[1, rng.random(T) < 0.05] = np.nan
+    hist[2] = np.nan
+    gidx = (np.arange(T) % 365).astype(np.int32)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    fn = hip.eqm_train if method == "eqm" else hip.dqm_train
+    a = fn(ref, hist, gidx, 365, 31, q, "+")
+    monkeypatch.setenv("XSDBA_HIP_TRAIN3", "0")
+    b = fn(ref, hist, gidx, 365, 31, q, "+")
+    for x, y in zip(a[:2], b[:2]):
+        np.testing.assert_array_equal(x, y)
+    if method == "dqm":  # the group means come from differently ordered float64 sums
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-6, equal_nan=True)
