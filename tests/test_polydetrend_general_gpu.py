@@ -186,3 +186,45 @@ def test_rank_over_several_dims_and_random_tiebreak():
             assert sorted(rt[c, m]) == list(range(1, 201))  # a permutation: no ties left
             avg = rankdata(x[c, m], "average")
             assert np.abs(rt[c, m] - avg).max() <= (np.unique(x[c, m], return_counts=True)[1].max() - 1) / 2 + 1e-9
+
+
+def test_mean_and_no_detrend():
+    """reference tests/test_detrending.py:55-64 (MeanDetrend) and the NoDetrend placeholder"""
+    from xsdba_amd.detrending import MeanDetrend, NoDetrend
+
+    t = xs.date_range("2000-07-01", int(20 * 365.25), "standard").values
+    x = DataArray(np.arange(int(20 * 365.25), dtype=np.float64), ("time",), {"time": t}, {"units": "K"})
+    md = MeanDetrend().fit(x)
+    assert (md.ds.trend.values == x.values.mean()).all()
+    np.testing.assert_array_almost_equal(md.retrend(md.detrend(x)).values, x.values)
+    rng = np.random.default_rng(12)
+    y = cube(data(rng, 2, 3 * 365, np.float32), ("lat", "time"))
+    mm = MeanDetrend(group="time.month").fit(y)
+    gidx, G = xs.Grouper("time.month").group_index(y)
+    for g in range(G):
+        np.testing.assert_allclose(mm.ds.trend.values[:, gidx == g], y.values[:, gidx == g].mean(axis=1, keepdims=True) * np.ones((1, (gidx == g).sum())), rtol=2e-6)
+    nd = NoDetrend().fit(y)
+    np.testing.assert_array_equal(nd.retrend(nd.detrend(y)).values, y.values)
+
+
+def test_dqm_adjust_with_mean_and_no_detrend():
+    """dqm_adjust(detrend=MeanDetrend() / NoDetrend()): the trend handed to the mapping is the group mean / nothing"""
+    from xsdba_amd.detrending import MeanDetrend, NoDetrend
+
+    rng = np.random.default_rng(13)
+    C, T = 2, 4 * 365
+    ref, hist, sim = (data(rng, C, T, np.float32) for _ in range(3))
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.dayofyear", 31)
+    dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=10)
+    gidx, G = gr.group_index(cube(sim, dims))
+    af = np.ascontiguousarray(dqm.ds.af.transpose("lat", "dayofyear", "quantiles").values)
+    hq = np.ascontiguousarray(dqm.ds.hist_q.transpose("lat", "dayofyear", "quantiles").values)
+    sc = np.ascontiguousarray(dqm.ds.scaling.transpose("lat", "dayofyear").values)
+    scaled = oracle.scaling_adjust(sim, sc, gidx, "+")
+    got = dqm.adjust(cube(sim, dims), detrend=NoDetrend()).transpose(*dims).values
+    np.testing.assert_array_equal(got, oracle.qm_adjust(scaled, af, hq, gidx, "nearest", "constant", "+"))
+    got = dqm.adjust(cube(sim, dims), detrend=MeanDetrend(group="time")).transpose(*dims).values
+    m = scaled.astype(np.float64).mean(axis=1, keepdims=True).astype(np.float32)
+    exp = oracle.qm_adjust(scaled - m, af, hq, gidx, "nearest", "constant", "+") + m
+    np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-4)

@@ -25,7 +25,7 @@ from . import hip
 from . import nbutils as nbu
 from . import utils as u
 from .base import Grouper, map_blocks, map_groups
-from .detrending import PolyDetrend
+from .detrending import BaseDetrend, MeanDetrend, NoDetrend, PolyDetrend
 from .labeled import Coordinate, DataArray, Dataset, as_dataarray, full_like
 from .utils import cell_time_view, table_view
 
@@ -386,8 +386,10 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
             own = detrend
     elif isinstance(detrend, (int, np.integer)):
         degree = int(detrend)
+    elif isinstance(detrend, (MeanDetrend, NoDetrend)):
+        degree, own = 0, detrend
     else:
-        raise NotImplementedError("dqm_adjust on the HIP path supports polynomial detrending (an int degree or a PolyDetrend) only")
+        raise NotImplementedError("dqm_adjust on the HIP path supports an int degree, PolyDetrend, MeanDetrend or NoDetrend")
     if not 0 <= degree <= 6:
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0..6)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
@@ -406,9 +408,16 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
                           UserWarning, stacklevel=2)
         gidx_d, G_d = own.group.group_index(sim)
         scaled = hip.scaling_adjust(s2, sc, gidx if G > 1 else None, kind)
-        trend_in = hip.polydetrend_trend(scaled, gidx_d, G_d, own.group.window, tnum, degree, bool(own.preserve_mean), own.kind)
+        own_kind = own.kind
+        if isinstance(own, NoDetrend):  # nothing is removed: a zero additive trend
+            trend_in, own_kind = np.zeros_like(scaled), "+"
+        elif isinstance(own, MeanDetrend):
+            means = hip.group_means(scaled, gidx_d, G_d, own.group.window)
+            trend_in = hip.scaling_adjust(np.zeros_like(scaled), means, gidx_d if G_d > 1 else None, "+")
+        else:
+            trend_in = hip.polydetrend_trend(scaled, gidx_d, G_d, own.group.window, tnum, degree, bool(own.preserve_mean), own.kind)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in,
-                                     trend_kind=own.kind, mult_skip_zeros=bool(own.mult_skip_zeros) and own.kind == "*")
+                                     trend_kind=own_kind, mult_skip_zeros=bool(own.mult_skip_zeros) and own_kind == "*")
     elif interp == "linear" and G > 1:
         # the scaling is broadcast linearly between the group centres too, except on day-of-year groups (:748-757); then
         # fit / detrend / grouped-linear mapping / retrend (:759-773) as separate device steps

@@ -99,4 +99,36 @@ class PolyDetrend(BaseDetrend):
         return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
 
 
+class NoDetrend(BaseDetrend):
+    """Convenience class for polymorphism; does nothing (detrending.py:134-147)."""
+
+    def _get_trend(self, da: DataArray) -> DataArray:
+        return da.isel({self.group.dim: 0})
+
+    def _detrend(self, da, trend):
+        return da
+
+    def _retrend(self, da, trend):
+        return da
+
+
+class MeanDetrend(BaseDetrend):
+    """Removes only the (group) mean from the data (detrending.py:150-162): the NaN-skipping mean of every (cell, group)
+    block over time and window (``k_group_mean``), broadcast on the group of each time step (``k_scale_groups``)."""
+
+    def _get_trend(self, da: DataArray) -> DataArray:
+        group: Grouper = self.group
+        if group.add_dims:
+            raise NotImplementedError("MeanDetrend with `add_dims` is not implemented on the HIP path")
+        x2, cell_dims, cell_shape = cell_time_view(da, group.dim)
+        x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
+        gidx, G = group.group_index(da)
+        means = hip.group_means(x2, gidx, G, group.window)
+        tr = hip.scaling_adjust(np.zeros_like(x2), means, gidx if G > 1 else None, "+")
+        coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == group.dim}
+        return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
+
+
 _register(PolyDetrend, "xsdba.detrending")
+_register(NoDetrend, "xsdba.detrending")
+_register(MeanDetrend, "xsdba.detrending")
