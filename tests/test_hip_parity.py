@@ -788,3 +788,26 @@ def test_three_and_two_stream_train_kernels_agree(hip, monkeypatch, method, trai
         np.testing.assert_array_equal(x, y)
     if method == "dqm":  # the group means come from differently ordered float64 sums
         np.testing.assert_allclose(a[2], b[2], rtol=1e-6, equal_nan=True)
+
+
+@pytest.mark.parametrize("method", ["eqm", "dqm"])
+@pytest.mark.parametrize("T,W,Q", [(10950, 61, 20), (10950, 31, 21), (3000, 91, 7), (10950, 31, 22)])
+def test_train_long_rows_and_other_quantile_counts(hip, method, T, W, Q):
+    """k_train_cell3 beyond the bench shape: rows of >= 1024 values (61- / 91-day windows: the three per-lane counts no
+    longer share one register), 21 nodes (every lane of a stream busy), a short series, and 22 nodes (two-stream kernel)"""
+    rng = np.random.default_rng(T + W + Q)
+    C = 3
+    gidx = (np.arange(T) % 365).astype(np.int32)
+    ref, hist, _ = _synth(rng, C, T, "+", np.float32, nan_frac=0.01)
+    hist[1, :400] = np.nan
+    q = _nodes(Q)
+    if method == "eqm":
+        af, hq = hip.eqm_train(ref, hist, gidx, 365, W, q, "+")
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, W, q, "+")
+        assert_close(hq, ehq, rtol=0.0, what="hist_q")
+        assert_close(af, eaf, rtol=0.0, what="af")
+    else:
+        af, hq, sc = hip.dqm_train(ref, hist, gidx, 365, W, q, "+")
+        eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, 365, W, q, "+")
+        assert_close(sc, esc, rtol=2e-6, what="scaling")
+        assert_close(hq, ehq, rtol=3e-6, atol=3e-5, what="hist_q")
