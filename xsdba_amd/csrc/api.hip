@@ -562,6 +562,27 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             using std::true_type;
             auto pick_t64 = [&](auto cfg, auto dqm) -> int { return pl->d_tog64 ? go(cfg, dqm, true_type{}) : go(cfg, dqm, false_type{}); };
             auto pick_dqm = [&](auto cfg) -> int { return mode == 2 ? pick_t64(cfg, true_type{}) : pick_t64(cfg, false_type{}); };
+            // three group streams per wave, as for float32 (train_cell3.hpp)
+            auto go3 = [&](auto cfg, auto p10, auto dqm) -> int {
+                constexpr int EPT = decltype(cfg)::value;
+                constexpr bool P10 = decltype(p10)::value, DQM = decltype(dqm)::value;
+                const size_t lds = xs::CellCfg3<EPT>::lds_bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_cell3_f64<EPT, P10, DQM>, lds, ctx, "the per-cell sort"))) return rc2;
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
+                LaunchScope ls(ctx, "k_train_cell3_f64");
+                hipLaunchKernelGGL((xs::k_train_cell3_f64<EPT, P10, DQM>), dim3(nblk), dim3(1024), lds, ctx->stream, (const double *)s0.dev,
+                                   (const double *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, G, (const double *)dq, Q, (int)kind,
+                                   mode, (double *)oaf.dev, (double *)ohq.dev, (double *)osc.dev, flag_count, flag_list, C, pl->d_tog64);
+                return check_launch("k_train_cell3_f64");
+            };
+            auto pick3d = [&](auto cfg, auto p10) -> int { return mode == 2 ? go3(cfg, p10, true_type{}) : go3(cfg, p10, false_type{}); };
+            auto pick3 = [&](auto cfg) -> int { return pl->max_row <= 1023 ? pick3d(cfg, true_type{}) : pick3d(cfg, false_type{}); };
+            const char *t3 = getenv("XSDBA_HIP_TRAIN3");
+            const bool three = pl->d_tog64 && Q <= 21 && G >= 48 && !(t3 && !strcmp(t3, "0"));
+            if (three)
+                rc = ept == 4 ? pick3(integral_constant<int, 4>{}) : ept == 8 ? pick3(integral_constant<int, 8>{}) : pick3(integral_constant<int, 11>{});
+            else
             rc = ept == 4 ? pick_dqm(integral_constant<int, 4>{}) : ept == 8 ? pick_dqm(integral_constant<int, 8>{})
                                                                               : pick_dqm(integral_constant<int, 11>{});
             if (rc) return rc;

@@ -29,13 +29,17 @@ template <int EPT> struct CellCfg3 {
 // register (10-bit fields), one prefix scan and one bpermute per bisection step serve all three streams.
 // DQM: group means from running float64 sums updated by the same toggles (one per stream), normalisation of the selected
 // order statistics, scaling — with the guards of cell_group_quantiles (train_cell.hpp).
-template <int EPT, bool P10, bool DQM>
-__device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
+// Vals: where the values come from (LdsVals: float32 keys in LDS; GlobalF64Vals: the float64 series in global memory).
+template <int EPT, bool P10, bool DQM, typename Vals>
+__device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
-                                                      const float *__restrict__ q, int Q, int kind, int mode, int arr, int64_t c,
-                                                      float *__restrict__ af, float *out_hq, float *scaling, bool &flag_cell)
+                                                      const typename Vals::value_type *__restrict__ q, int Q, int kind, int mode,
+                                                      int arr, int64_t c, typename Vals::value_type *__restrict__ af,
+                                                      typename Vals::value_type *out_hq, typename Vals::value_type *scaling,
+                                                      bool &flag_cell)
 {
+    using R = typename Vals::value_type;
     using Cfg = CellCfg3<EPT>;
     constexpr int TPAD = Cfg::TPAD, WPL = Cfg::WPL, VS = Cfg::VSTRIDE, NL = Cfg::NLANE, QL = 21;
     const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
@@ -56,7 +60,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
                 const uint32_t m = 1u << (r & 31);
                 if (DQM) {
                     const uint32_t old = atomicXor(&bits[r >> 5], m);
-                    const float v = vals.at_time(t);
+                    const R v = vals.at_time(t);
                     dloc += (old & m) ? -(double)v : (double)v;
                     amax = fmax(amax, fabs((double)v));
                 } else {
@@ -67,10 +71,11 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
     };
     double dlocA = 0.0, dlocB = 0.0, dlocC = 0.0, gsumA = 0.0, gsumB = 0.0, gsumC = 0.0;
     if (DQM && kind == '+' && wid == 0 && lane == 0 && nvalid > 1) {  // additive kind: extremes against the IQR, once per array
-        float lo, hi, q1, q3;
+        R lo, hi, q1, q3;
         vals.at_ranks(0, nvalid - 1, lo, hi);
         vals.at_ranks(nvalid / 4, (3 * nvalid) / 4, q1, q3);
-        if (!(fmax(fabs((double)lo), fabs((double)hi)) <= 1.0e8 * ((double)q3 - (double)q1))) flag_cell = true;
+        constexpr double LIM_ADD = sizeof(R) == 8 ? 1.0e4 : 1.0e8;
+        if (!(fmax(fabs((double)lo), fabs((double)hi)) <= LIM_ADD * ((double)q3 - (double)q1))) flag_cell = true;
     }
     // ---- the vector of group gb from its row list, copied to B and C
     {
@@ -103,7 +108,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
     if (nB > 0) preB = tog64[(size_t)gb * 64 + lane];
     if (nC > 1) preC = tog64[(size_t)(gc3 + 1) * 64 + lane];
     int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case = 3, c_lo = 0;
-    float c_gamma = 0.f;
+    R c_gamma = (R)0;
     for (int it = 0; it < nA; it++) {
         const bool vB = it < nB, vC = it < nC;
         const int tA = it > 0 ? preA : -1, tB = vB ? preB : -1, tC = (it > 0 && vC) ? preC : -1;
@@ -137,7 +142,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
         const int g = sid == 0 ? gb + it : (sid == 1 ? gb - 1 - it : gc3 + it);
         const bool vs = sid == 0 || (sid == 1 && vB) || (sid == 2 && vC);
         const bool act = vs && k < Q;
-        float mu = 0.f, inv = 0.f;
+        R mu = (R)0, inv = (R)0;
         if (DQM) {
             // it == 0: dlocA holds the sum of the built vector (B and C start from it), dlocC the fast-forward of C on top
             // (the totals sit in lane 0; read into scalar registers: the running sums are wave-uniform and stay out of the VGPRs)
@@ -152,25 +157,26 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
             gsumB = uni(gsumB + sB);
             gsumC = uni(gsumC + sC);
             const double gs = sid == 0 ? gsumA : (sid == 1 ? gsumB : gsumC);
-            mu = ns ? (float)(gs / (double)ns) : __builtin_nanf("");
-            inv = invert<float>(mu, kind);
-            if (vs && sid < 3 && ns && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
+            mu = ns ? (R)(gs / (double)ns) : nan_of<R>();
+            inv = invert<R>(mu, kind);
+            if (vs && sid < 3 && ns && (!isfinite(mu) || (kind == '*' && !(inv > (R)0 && isfinite(inv))))) flag_cell = true;
             const double inf = __builtin_inf();
             const double gmin = fmin(fmin(cntA ? fabs(gsumA) : inf, (vB && cntB) ? fabs(gsumB) : inf), (vC && cntC) ? fabs(gsumC) : inf);
-            if (kind == '*' && !(amax <= 1.0e6 * gmin)) flag_cell = true;  // see cell_group_quantiles: rounding of the running sums
+            constexpr double LIM = sizeof(R) == 8 ? 200.0 : 1.0e6;
+            if (kind == '*' && !(amax <= LIM * gmin)) flag_cell = true;  // see cell_group_quantiles: rounding of the running sums
         }
         // quantile-index math depends on (n, k) only: cached while the three streams keep their counts
         int casek, lo;  // 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
-        float gamma;
+        R gamma;
         if (cntA == nA_prev && cntB == nB_prev && cntC == nC_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
         else {
             const double qk = (double)q[k < Q ? k : 0];
             const double vi = (double)ns * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
-            lo = 0; gamma = 0.f;
+            lo = 0; gamma = (R)0;
             if (ns == 0) casek = 3;
             else if (vi != vi || vi >= (double)(ns - 1)) { casek = 1; lo = ns - 1; }
             else if (vi < 0.0) { casek = 2; lo = 0; }
-            else { casek = 0; lo = (int)floor(vi); gamma = (float)(vi - (double)lo); }
+            else { casek = 0; lo = (int)floor(vi); gamma = (R)(vi - (double)lo); }
             c_case = casek; c_lo = lo; c_gamma = gamma;
         }
         nA_prev = cntA; nB_prev = cntB; nC_prev = cntC;
@@ -246,26 +252,26 @@ __device__ __forceinline__ void cell_group_quantiles3(const LdsVals &vals, const
             if (need_slow) hrank = L2 * WPL * 32 + hr2;
         }
         const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
-        float v, vhi;
+        R v, vhi;
         vals.at_ranks(rs0, rs1, v, vhi);
-        if (DQM) { v = apply_corr<float>(v, inv, kind); vhi = apply_corr<float>(vhi, inv, kind); }
-        float res;
-        if (casek == 3) res = __builtin_nanf("");
+        if (DQM) { v = apply_corr<R>(v, inv, kind); vhi = apply_corr<R>(vhi, inv, kind); }
+        R res;
+        if (casek == 3) res = nan_of<R>();
         else if (casek != 0) res = v;
         else {
-            const float diff = vhi - v;
-            if (gamma >= 0.5f) res = (float)((double)vhi - (double)diff * (1.0 - (double)gamma));
+            const R diff = vhi - v;
+            if (gamma >= (R)0.5) res = (R)((double)vhi - (double)diff * (1.0 - (double)gamma));
             else res = v + diff * gamma;
             if (res != res && act) flag_cell = true;  // inf - inf: the generic kernel redoes the cell
         }
         if (act) {
             const size_t o = ((size_t)c * G + g) * (size_t)Q + k;
             if (mode == 0 || arr == 0) out_hq[o] = res;
-            else af[o] = get_corr<float>(out_hq[o], res, kind);
+            else af[o] = get_corr<R>(out_hq[o], res, kind);
         }
         if (DQM && vs && sid < 3 && k == 0) {
             if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced by the factor in the ref pass
-            else scaling[(size_t)c * G + g] = get_corr<float>(scaling[(size_t)c * G + g], mu, kind);
+            else scaling[(size_t)c * G + g] = get_corr<R>(scaling[(size_t)c * G + g], mu, kind);
         }
     }
 }

@@ -10,7 +10,7 @@
 // Phase C is the one of k_train_cell instantiated for double: order statistics and DQM sums come from the series in
 // global memory through the sorted index array; quantile interpolation, factors and scaling are computed in float64.
 #pragma once
-#include "train_cell.hpp"
+#include "train_cell3.hpp"
 
 namespace xs {
 
@@ -31,14 +31,17 @@ struct GlobalF64Vals {
 
 // Phases A + B for a float64 series: 31-bit range keys in LDS, radix sort, tie repair, rank[].  Returns the sorted
 // index array.  All 1024 threads must call it; it ends on a barrier.
+// rank_out != nullptr: rank[] goes into the u16 index buffer the sort leaves free (k_train_cell3_f64: the union region is
+// then all bit-vectors) and its address is returned there; else into the union region as for k_train_cell.
 template <int EPT>
 __device__ __forceinline__ const uint16_t *cell_load_sort_f64(const double *__restrict__ x, int64_t T, unsigned char *smem,
-                                                              uint32_t *red, int &nvalid_out)
+                                                              uint32_t *red, int &nvalid_out, const uint16_t **rank_out = nullptr)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
     uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
+    uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0), *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
     int tid = threadIdx.x;
     __asm__ volatile("" : "+v"(tid));  // see cell_load_sort
     const int lane = tid & 63, wid = tid >> 6;
@@ -97,6 +100,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort_f64(const double *__re
         }
         if (!__syncthreads_or(swapped ? 1 : 0)) break;
     }
+    if (rank_out) { rank = sorted == idx0 ? idx1 : idx0; *rank_out = rank; }
     for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
     __syncthreads();
     return sorted;
@@ -144,6 +148,43 @@ __global__ __launch_bounds__(1024) void k_train_cell_f64(
                                                              tog_idx, tog64, G, q, Q, kind, mode, arr, c, af, out_hq, scaling,
                                                              flag_cell, 0, nostamp);
             }
+            __syncthreads();
+        }
+        const int any = __syncthreads_or(flag_cell ? 1 : 0);
+        if (any && tid == 0 && flag_list) {
+            const int slot = atomicAdd(flag_count, 1);
+            flag_list[slot] = (int)c;
+        }
+    }
+}
+
+// three group streams per wave (train_cell3.hpp) for float64 series
+template <int EPT, bool P10, bool DQM>
+__global__ __launch_bounds__(1024) void k_train_cell3_f64(const double *__restrict__ x0, const double *__restrict__ x1, int64_t T,
+                                                           int64_t sc, const int *__restrict__ row_ptr,
+                                                           const int *__restrict__ row_sorted, int G, const double *__restrict__ q,
+                                                           int Q, int kind, int mode, double *__restrict__ af, double *out_hq,
+                                                           double *scaling, int *__restrict__ flag_count,
+                                                           int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64)
+{
+    using Cfg3 = CellCfg3<EPT>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg3::off_bits);
+    uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg3::off_misc);
+    const int tid = threadIdx.x, wid = tid >> 6;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        const int npass_arr = mode == 0 ? 1 : 2;
+        bool flag_cell = false;
+        for (int arr = 0; arr < npass_arr; arr++) {
+            int lane = tid & 63;
+            __asm__ volatile("" : "+v"(lane));
+            const double *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
+            int nvalid;
+            const uint16_t *rank;
+            const uint16_t *sorted = cell_load_sort_f64<EPT>(x, T, smem, red, nvalid, &rank);
+            const GlobalF64Vals vals{x, sorted, (int)T};
+            cell_group_quantiles3<EPT, P10, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode,
+                                                 arr, c, af, out_hq, scaling, flag_cell);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
