@@ -265,6 +265,13 @@ int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int6
                               const double *time_num, int32_t degree, int preserve_mean, char kind, void *trend,
                               int64_t out_stride_t, int64_t out_stride_c);
 
+/* ---- a16: RollingMeanDetrend's trend on the whole series (detrending.py:342-356: da.rolling(center=True, min_periods,
+ * time=window).mean()): NaN-skipping mean of the centred window of every time step ([t - window/2, t - window/2 + window - 1],
+ * xarray's alignment for even windows too), NaN where fewer than min_periods values are present */
+int xsdba_hip_rolling_mean(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t n_time, int64_t n_cell, int64_t stride_t,
+                           int64_t stride_c, int32_t window, int32_t min_periods, void *out, int64_t out_stride_t,
+                           int64_t out_stride_c);
+
 /* ---- a7 / a16: utils.apply_correction of a series by another series (utils.py:149-177; BaseDetrend._detrend / _retrend,
  * detrending.py:102-120): out = x (+|*) f, or x (+|*) invert(f) when `inverted`; skip_zeros: out = x where f == 0
  * (mult_skip_zeros).  f has the layout (f_stride_t, f_stride_c); f_stride_c == 0 broadcasts one series over all cells. */

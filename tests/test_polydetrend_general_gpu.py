@@ -228,3 +228,34 @@ def test_dqm_adjust_with_mean_and_no_detrend():
     m = scaled.astype(np.float64).mean(axis=1, keepdims=True).astype(np.float32)
     exp = oracle.qm_adjust(scaled - m, af, hq, gidx, "nearest", "constant", "+") + m
     np.testing.assert_allclose(got, exp, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("win,minp", [(29, 1), (30, None), (30, 10), (5, 5)])
+def test_rolling_mean_detrend(win, minp):
+    """reference tests/test_detrending.py:67-77 (RollingMeanDetrend) + the window alignment / min_periods of
+    xarray's rolling(center=True): the window of step t is [t - win // 2, t - win // 2 + win - 1]"""
+    from xsdba_amd.detrending import RollingMeanDetrend
+
+    rng = np.random.default_rng(14)
+    T = 1200
+    x = (np.arange(T) * 0.01 + rng.standard_normal((2, T))).astype(np.float64)
+    x[0, 100:103] = np.nan
+    da = cube(x, ("lat", "time"))
+    fx = RollingMeanDetrend(group="time", win=win, min_periods=minp).fit(da)
+    mp = win if minp is None else minp
+    exp = np.full_like(x, np.nan)
+    for t in range(T):
+        lo, hi = t - win // 2, t - win // 2 + win - 1
+        w = x[:, max(lo, 0):min(hi, T - 1) + 1]
+        n = (~np.isnan(w)).sum(axis=1)
+        with np.errstate(invalid="ignore"):
+            m = np.nansum(w, axis=1) / np.maximum(n, 1)
+        exp[:, t] = np.where(n >= mp, m, np.nan)
+    np.testing.assert_allclose(fx.ds.trend.transpose("lat", "time").values, exp, rtol=1e-12, equal_nan=True)
+    if minp == 1:
+        ramp = DataArray(np.arange(int(12 * 365.25), dtype=np.float64), ("time",),
+                         {"time": xs.date_range("2000-07-01", int(12 * 365.25), "standard").values}, {"units": "K"})
+        f2 = RollingMeanDetrend(group="time", win=29, min_periods=1).fit(ramp)
+        dx = f2.detrend(ramp)
+        np.testing.assert_array_almost_equal(dx.values[30:3500], 0)
+        np.testing.assert_array_almost_equal(f2.retrend(dx).values, ramp.values)

@@ -25,7 +25,7 @@ from .adjustment import (  # noqa: E402,F401
 )
 from .base import Grouper, map_blocks, map_groups, parse_group  # noqa: E402,F401
 from .calendar import TimeIndex, date_range  # noqa: E402,F401
-from .detrending import MeanDetrend, NoDetrend, PolyDetrend  # noqa: E402,F401
+from .detrending import MeanDetrend, NoDetrend, PolyDetrend, RollingMeanDetrend  # noqa: E402,F401
 from .labeled import DataArray, Dataset, as_dataarray  # noqa: E402,F401
 from .options import set_options  # noqa: E402,F401
 from .io import open_dataset, to_netcdf  # noqa: E402,F401

@@ -25,7 +25,7 @@ from . import hip
 from . import nbutils as nbu
 from . import utils as u
 from .base import Grouper, map_blocks, map_groups
-from .detrending import BaseDetrend, MeanDetrend, NoDetrend, PolyDetrend
+from .detrending import BaseDetrend, MeanDetrend, NoDetrend, PolyDetrend, RollingMeanDetrend
 from .labeled import Coordinate, DataArray, Dataset, as_dataarray, full_like
 from .utils import cell_time_view, table_view
 
@@ -386,10 +386,10 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
             own = detrend
     elif isinstance(detrend, (int, np.integer)):
         degree = int(detrend)
-    elif isinstance(detrend, (MeanDetrend, NoDetrend)):
+    elif isinstance(detrend, (MeanDetrend, NoDetrend, RollingMeanDetrend)):
         degree, own = 0, detrend
     else:
-        raise NotImplementedError("dqm_adjust on the HIP path supports an int degree, PolyDetrend, MeanDetrend or NoDetrend")
+        raise NotImplementedError("dqm_adjust on the HIP path supports an int degree, PolyDetrend, MeanDetrend, RollingMeanDetrend or NoDetrend")
     if not 0 <= degree <= 6:
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0..6)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
@@ -414,6 +414,10 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
         elif isinstance(own, MeanDetrend):
             means = hip.group_means(scaled, gidx_d, G_d, own.group.window)
             trend_in = hip.scaling_adjust(np.zeros_like(scaled), means, gidx_d if G_d > 1 else None, "+")
+        elif isinstance(own, RollingMeanDetrend):
+            if own.group.prop != "group":
+                raise NotImplementedError("RollingMeanDetrend is implemented for group='time' on the HIP path")
+            trend_in = hip.rolling_mean(scaled, int(own.win), own.min_periods)
         else:
             trend_in = hip.polydetrend_trend(scaled, gidx_d, G_d, own.group.window, tnum, degree, bool(own.preserve_mean), own.kind)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in,

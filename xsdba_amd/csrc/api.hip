@@ -747,7 +747,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
 
 template <typename R>
 int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *scaling, Plan *pl, char kind,
-                 const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0)
+                 const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0, int min_periods = 0)
 {
     const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
     const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
@@ -763,13 +763,13 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods);
     }
     return check_launch("k_group_trend");
 }
@@ -835,6 +835,23 @@ int trend_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t 
     if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc;
     if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, preserve_mean))) return rc;
     if ((rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
+    return sync_if(ctx, true);
+}
+
+template <typename R>
+int rolling_mean_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t st, int64_t sc, int W, int min_periods, void *out,
+                      int64_t ost, int64_t osc)
+{
+    if (C <= 0 || !out || W < 1 || min_periods < 1 || min_periods > W) return fail(XSDBA_E_ARG, "bad window / min_periods");
+    int rc;
+    Plan *pl;
+    if ((rc = get_plan(ctx, nullptr, T, 1, W, &pl))) return rc;
+    SeriesIn s;
+    if ((rc = series_in<R>(ctx, S_IN0, S_CM0, x, T, C, st, sc, &s))) return rc;
+    SeriesOut o;
+    if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, out, T, C, ost, osc, &o))) return rc;
+    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, '+', (const double *)nullptr, 0, (R *)o.kernel_dst, 0, min_periods))) return rc;
+    if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
     return sync_if(ctx, true);
 }
 
@@ -1657,6 +1674,15 @@ API int xsdba_hip_series_correction(xsdba_hip_ctx *ctx, const void *x, int dtype
     if (rc || (rc = check_kind(kind, false))) return rc;
     return DISPATCH(dtype, (series_correction_impl<float>(ctx, x, T, C, st, sc, f, fst, fsc, kind, inverted ? 1 : 0, skip_zeros ? 1 : 0, out, ost, osc)),
                     (series_correction_impl<double>(ctx, x, T, C, st, sc, f, fst, fsc, kind, inverted ? 1 : 0, skip_zeros ? 1 : 0, out, ost, osc)));
+}
+
+API int xsdba_hip_rolling_mean(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                               int32_t window, int32_t min_periods, void *out, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    return DISPATCH(dtype, (rolling_mean_impl<float>(ctx, x, T, C, st, sc, window, min_periods, out, ost, osc)),
+                    (rolling_mean_impl<double>(ctx, x, T, C, st, sc, window, min_periods, out, ost, osc)));
 }
 
 API int xsdba_hip_polydetrend_fit(xsdba_hip_ctx *ctx, const void *x, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

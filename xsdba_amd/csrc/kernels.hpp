@@ -418,8 +418,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
-                              int preserve_mean)
+                              int preserve_mean, int min_periods)
 {
+    // min_periods > 0: rolling-mean mode (RollingMeanDetrend, detrending.py:342-356: da.rolling(center=True, min_periods)
+    // .mean()): the window means themselves are the result, NaN where fewer than min_periods values are in the window
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool general = degree >= 2 || preserve_mean;
     const int ncoef = general ? degree + 4 : 3;
@@ -465,7 +467,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     const bool inplace = !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
     auto mean_of = [&](double s, int n) {
         double mv = __builtin_nan("");
-        if (n) {
+        if (n && n >= min_periods) {
             const double dn = (double)n, rc = rcp[n];
             double q0 = s * rc;
             double r0 = __builtin_fma(-q0, dn, s);
@@ -513,6 +515,11 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         for (int64_t t = t0; t < t1; t++) { slide(t, t == t0, s, n, big); m[t] = mean_of(s, n); }
     }
     __syncthreads();
+    if (min_periods > 0) {
+        if (W == 1) { for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = xs[t]; }  // a window of one step
+        else if (m != tr_out) { for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = m[t]; }
+        return;
+    }
     if (general) {
         // general degree / preserve_mean: one lane per group, serial over its members (moments, solve, mean of the fit)
         for (int g = threadIdx.x; g < G; g += blockDim.x) {

@@ -129,6 +129,27 @@ class MeanDetrend(BaseDetrend):
         return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
 
 
+class RollingMeanDetrend(BaseDetrend):
+    """Detrend time series using a rolling mean (detrending.py:298-356), on the whole series (``group="time"``: the grouped
+    variants roll over the steps of each group, which is not on the HIP path; neither are ``weights``)."""
+
+    def __init__(self, group="time", kind=ADDITIVE, win=30, weights=None, min_periods=None, mult_skip_zeros=False):
+        if weights is not None:
+            raise NotImplementedError("RollingMeanDetrend(weights=...) is not implemented on the HIP path")
+        super().__init__(group=group, kind=kind, win=win, weights=weights, min_periods=min_periods, mult_skip_zeros=mult_skip_zeros)
+
+    def _get_trend(self, da: DataArray) -> DataArray:
+        group: Grouper = self.group
+        if group.prop != "group" or group.add_dims:
+            raise NotImplementedError("RollingMeanDetrend is implemented for group='time' on the HIP path")
+        x2, cell_dims, cell_shape = cell_time_view(da, group.dim)
+        x2 = x2.astype(np.result_type(x2.dtype, np.float32), copy=False)
+        tr = hip.rolling_mean(x2, int(self.win), self.min_periods)
+        coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == group.dim}
+        return DataArray(tr.reshape(cell_shape + (tr.shape[-1],)), cell_dims + (group.dim,), coords)
+
+
 _register(PolyDetrend, "xsdba.detrending")
+_register(RollingMeanDetrend, "xsdba.detrending")
 _register(NoDetrend, "xsdba.detrending")
 _register(MeanDetrend, "xsdba.detrending")

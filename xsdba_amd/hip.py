@@ -400,6 +400,17 @@ def series_correction(x, f, kind="+", inverted=False, skip_zeros=False, ctx=None
     return out
 
 
+def rolling_mean(x, window, min_periods=None, ctx=None):
+    """x.rolling(time=window, center=True, min_periods=min_periods).mean() -> [C, T] (min_periods defaults to window)"""
+    ctx = ctx or default_context()
+    s = _Series(x)
+    out = _out(ctx, s.dev, (s.C, s.T), s.dtype)
+    mp = int(window if min_periods is None else min_periods)
+    check(load().xsdba_hip_rolling_mean(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                                        C.c_int(int(window)), C.c_int(mp), _vp(out), _i64(1), _i64(s.T)), "rolling_mean")
+    return out
+
+
 def rank_groups(x, gidx, G, W, rank_window=False, pct=True, ctx=None):
     """utils.rank(pct) through Grouper.apply -> float64 [C, T] (average ranks, or percent ranks rescaled to [0, 1])"""
     ctx = ctx or default_context()
@@ -426,5 +437,5 @@ def polydetrend_trend(x, gidx, G, W, time_num, degree=1, preserve_mean=False, ki
     return out
 
 
-__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "qm_adjust_linear2d", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "series_correction", "loci_train", "loci_adjust", "rank_groups",
+__all__ = ["vecquantiles", "quantile_groups", "eqm_train", "dqm_train", "qm_adjust", "qm_adjust_linear2d", "dqm_adjust", "qdm_adjust", "tail_mask", "jitter", "adapt_freq", "group_means", "scaling_adjust", "series_correction", "rolling_mean", "loci_train", "loci_adjust", "rank_groups",
            "polydetrend_trend", "Context", "DeviceArray", "default_context"]
