@@ -35,6 +35,7 @@ WORKLOADS = {
     "eqm_time": ("eqm", "time", 1, "+", 0),
     "dqm_doy31": ("dqm", "dayofyear", 31, "+", 0),
     "qdm_doy31": ("qdm", "dayofyear", 31, "*", 1),
+    "qdm_doy31_rw": ("qdm", "dayofyear", 31, "*", 1),  # BASELINE configs[3], second mode: rank_window=True
     # BASELINE configs[4]: 60 years daily, 30 % of the cells all-NaN ("ocean") + 1 % i.i.d. NaN elsewhere (run it with
     # --days 21900; cells per GPU as memory allows)
     "dqm_doy31_nan": ("dqm", "dayofyear", 31, "+", 0),
@@ -106,11 +107,12 @@ def main():
 
     ctx = hip.Context(device)
     method, group, W, kind, gen = WORKLOADS[args.workload]
+    rank_window = args.workload.endswith("_rw")
     C, T, Q = args.cells, args.days, args.nquantiles
     gidx, G = group_index(group, T)
     q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
     tnum = (np.arange(T, dtype=np.float64) + 10950.0) * 86400e9
-    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3, "dqm_doy31_nan": 4}.get(args.workload, 1)
+    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3, "qdm_doy31_rw": 3, "dqm_doy31_nan": 4}.get(args.workload, 1)
     cell0 = rank * C
     ncf, nif = NAN_MASK.get(args.workload, (0.0, 0.0))
     ref = ctx.synth((C, T), np.float32, gen, 0, seed, cell0, ncf, nif, time_major=args.time_major)
@@ -136,7 +138,7 @@ def main():
             return [af, hq, sc, scen, trend]
         af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx, out=(o_af, o_hq))
         if method == "qdm":
-            scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, False, "nearest", "constant", kind, want_sim_q=False, ctx=ctx,
+            scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind, want_sim_q=False, ctx=ctx,
                                      out=o_scen)
         else:
             scen = hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind, ctx=ctx, out=o_scen)
@@ -228,7 +230,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic (device-generated, counter-based)",
             "config": {
-                "workload": f"{args.workload}: {method.upper()} train+adjust, group={group}, window={W}, kind='{kind}', "
+                "workload": f"{args.workload}: {method.upper()} train+adjust{' (rank_window=True)' if rank_window else ''}, group={group}, window={W}, kind='{kind}', "
                             f"nquantiles={Q}, interp=nearest, {C} cells/GPU x {T} days fp32, "
                             f"{'time-major (time,cell)' if args.time_major else 'cell-major (cell,time)'} cubes resident in HBM",
                 "cells_per_gpu": C, "days": T, "groups": G, "window": W, "parallelism": f"cells sharded over {world} GPU(s)",
@@ -239,7 +241,7 @@ def main():
             out["gather_ms"] = round(gather_ms, 3)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
-                                               args.cpu_seconds, args.time_major)
+                                               args.cpu_seconds, args.time_major, rank_window)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -262,7 +264,7 @@ def pmc_traffic(workload, cells, days, kernel):
     return None
 
 
-def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major):
+def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major, rank_window=False):
     """The CPU oracle (a restatement of the reference algorithm, kind="port") timed on this box's host cores
     on a bounded sample of the SAME device-generated cells; reported beside the GPU number, never the target."""
     import oracle
@@ -281,7 +283,7 @@ def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C,
         else:
             af, hq = oracle.eqm_train(r, h, gidx, G, W, q, kind)
             if method == "qdm":
-                oracle.qdm_adjust(s, af, q, gidx, W, False, "nearest", "constant", kind)
+                oracle.qdm_adjust(s, af, q, gidx, W, rank_window, "nearest", "constant", kind)
             else:
                 oracle.qm_adjust(s, af, hq, gidx, "nearest", "constant", kind)
         return time.perf_counter() - t0
