@@ -160,6 +160,16 @@ int xsdba_hip_qm_adjust_linear2d(xsdba_hip_ctx *ctx, const void *sim, int dtype,
                                  const void *trend, const double *lookup, int hist_q_is_row, void *scen, int64_t out_stride_t,
                                  int64_t out_stride_c);
 
+/* ---- the same call chain with grouped interp="cubic" (utils.py:391-396: scipy.griddata(method="cubic") =
+ * CloughTocher2DInterpolator(tol=1e-6, maxiter=400) on the same nodes): nodal gradients by Gauss-Seidel sweeps over the
+ * triangulation's edges, the C1 Clough-Tocher element on every triangle, then nbutils._extrapolate_on_quantiles as above.
+ * Arguments as for xsdba_hip_qm_adjust_linear2d. */
+int xsdba_hip_qm_adjust_cubic2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
+                                int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q, int32_t n_groups,
+                                int32_t nq, const double *group_coord, const double *new_group, int extrap, char kind,
+                                const void *trend, const double *lookup, int hist_q_is_row, void *scen, int64_t out_stride_t,
+                                int64_t out_stride_c);
+
 /* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
  * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`
  * (detrending.py:165-208; float64 abscissa, e.g. ns since 1970 as xarray.polyfit uses), quantile

@@ -31,3 +31,21 @@ extern "C" void dt_host_eval(int n, const double *px, const double *py, const do
         if (f >= 0) t = f;
     }
 }
+
+// griddata(method="cubic"): nodal gradients + the Clough-Tocher element
+extern "C" int dt_host_eval_ct(int n, const double *px, const double *py, const double *val, int ntri, uint16_t *tv,
+                               uint16_t *tn, int nq, const double *qx, const double *qy, double *out, double *grad)
+{
+    xs::Tri2D d{px, py, tv, tn, nullptr, nullptr, nullptr, n, ntri};
+    std::vector<int> ap(n + 1);
+    std::vector<uint16_t> ai(6 * (size_t)n + 8), fill(n);
+    xs::dt_adjacency(d, ap.data(), ai.data(), fill.data());
+    const int iters = xs::dt_gradients(d, val, ap.data(), ai.data(), grad);
+    int t = 0;
+    for (int i = 0; i < nq; i++) {
+        const int f = xs::dt_locate(d, qx[i], qy[i], t);
+        out[i] = f < 0 ? NAN : xs::dt_eval_ct(d, val, grad, f, qx[i], qy[i]);
+        if (f >= 0) t = f;
+    }
+    return iters;
+}

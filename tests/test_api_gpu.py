@@ -452,14 +452,11 @@ def test_interp_on_quantiles_monthly(random):
     ref_q = group.apply(nbu.quantile, refc, main_only=True, q=quantiles)
     hist_q = group.apply(nbu.quantile, hist, main_only=True, q=quantiles)
     af = u.get_correction(hist_q, ref_q, "+")
-    afi = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="nearest", extrapolation="constant")
-    assert afi.isnull().sum("time") == 0
-    # the reference loops over all three methods (:144-146); "linear" goes through the per-cell Delaunay triangulation here,
-    # grouped "cubic" (Clough-Tocher in the reference) is not implemented
-    afl = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="linear", extrapolation="constant")
-    assert afl.isnull().sum("time") == 0
-    with pytest.raises(NotImplementedError):
-        u.interp_on_quantiles(sim, hist_q, af, group="time.month", method="cubic")
+    # the reference loops over all three methods (:144-146); "linear" and "cubic" go through the per-cell Delaunay
+    # triangulation here (piecewise-linear / Clough-Tocher interpolant, like scipy.griddata)
+    for interp in ["nearest", "linear", "cubic"]:
+        afi = u.interp_on_quantiles(sim, hist_q, af, group="time.month", method=interp, extrapolation="constant")
+        assert afi.isnull().sum("time") == 0, interp
 
 
 def test_rank(random):

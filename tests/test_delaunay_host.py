@@ -9,7 +9,7 @@ from pathlib import Path
 
 import numpy as np
 import pytest
-from scipy.interpolate import griddata
+from scipy.interpolate import CloughTocher2DInterpolator, griddata
 from scipy.spatial import Delaunay
 
 ROOT = Path(__file__).resolve().parents[1]
@@ -86,3 +86,27 @@ def test_values_match_griddata_linear(lib, rows, Q):
     both = np.isfinite(ref) & np.isfinite(out)
     assert (np.isfinite(ref) != np.isfinite(out)).mean() < 2e-3  # hull-boundary ties only
     np.testing.assert_allclose(out[both], ref[both], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("rows,Q", [(14, 15), (14, 20), (6, 15), (40, 20)])
+def test_values_match_griddata_cubic(lib, rows, Q):
+    """griddata(method="cubic") = CloughTocher2DInterpolator(tol=1e-6, maxiter=400): nodal gradients (same Gauss-Seidel
+    sweeps, same stopping sweep) and the values of the Clough-Tocher element"""
+    rng = np.random.default_rng(rows + Q)
+    px, py = table_nodes(rng, rows, Q)
+    val = rng.standard_normal(len(px))
+    nt, tv, tn = build(lib, px, py)
+    nq = 4000
+    qx = (280 + 14 * rng.standard_normal(nq)).astype(np.float32).astype(np.float64)
+    qy = rng.uniform(0.0, rows - 1.0, nq)
+    qy[:200] = np.round(qy[:200])
+    out, grad = np.empty(nq), np.zeros(2 * len(px))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    iters = lib.dt_host_eval_ct(C.c_int(len(px)), p(px), p(py), p(val), C.c_int(nt), p(tv), p(tn), C.c_int(nq), p(qx), p(qy), p(out), p(grad))
+    assert 0 < iters < 400
+    ct = CloughTocher2DInterpolator(np.c_[px, py], val)
+    np.testing.assert_allclose(grad.reshape(-1, 2), ct.grad.reshape(-1, 2), rtol=1e-8, atol=1e-8)
+    ref = griddata((px, py), val, (qx, qy), method="cubic")
+    both = np.isfinite(ref) & np.isfinite(out)
+    assert (np.isfinite(ref) != np.isfinite(out)).mean() < 2e-3
+    np.testing.assert_allclose(out[both], ref[both], rtol=1e-8, atol=1e-8)

@@ -1,0 +1,141 @@
+"""Grouped interp="cubic" (qm_adjust -> interp_on_quantiles -> _interp_on_quantiles_2d with method="cubic", utils.py:380-400,
+476-513): scipy.griddata(method="cubic") = CloughTocher2DInterpolator on the Delaunay triangulation of a cell's table nodes.
+The device path (csrc/delaunay.hpp: dt_gradients + dt_eval_ct, k_lin2d_build / k_lin2d_adjust) is checked against griddata
+itself, composed exactly like the reference in oracle.interp_on_quantiles_2d.  The reference's own test of this path
+(tests/test_utils.py:116-146) only asserts that no NaN comes out (re-expressed in tests/test_api_gpu.py)."""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+import xsdba_amd as xs
+from xsdba_amd import hip
+
+from test_interp_linear_gpu import check, cube, gen, wrap
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    hip.default_context(0)
+
+
+def expected_cubic(sim, af, hq, gcoord, newg, extrap, kind):
+    out = np.empty_like(sim)
+    for c in range(sim.shape[0]):
+        oldg = np.repeat(gcoord[:, None], af.shape[2], 1)
+        a = oracle.interp_on_quantiles_2d(sim[c], newg, wrap(hq[c]), wrap(af[c]), oldg, "cubic", extrap)
+        out[c] = sim[c] + a if kind == "+" else sim[c] * a
+    return out
+
+
+@pytest.mark.parametrize("group", ["time.month", "time.season"])
+@pytest.mark.parametrize("kind", ["+", "*"])
+@pytest.mark.parametrize("extrap", ["constant", "nan"])
+def test_eqm_grouped_cubic_matches_griddata(group, kind, extrap):
+    rng = np.random.default_rng(31)
+    C, T, Q = 3, 6 * 365, 20
+    ref, hist, sim = gen(rng, C, T)
+    sim[1, rng.random(T) < 0.02] = np.nan
+    dims = ("lat", "time")
+    gr = xs.Grouper(group)
+    eqm = xs.EmpiricalQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, kind=kind, nquantiles=Q)
+    p = eqm.adjust(cube(sim, dims), interp="cubic", extrapolation=extrap).transpose(*dims).values
+    prop = gr.prop
+    af = np.ascontiguousarray(eqm.ds.af.transpose("lat", prop, "quantiles").values)
+    hq = np.ascontiguousarray(eqm.ds.hist_q.transpose("lat", prop, "quantiles").values)
+    crd = np.arange(1, 13.0) if prop == "month" else np.arange(4.0)
+    gcoord = np.concatenate([[crd[0] - 1], crd, [crd[-1] + 1]])
+    newg = np.asarray(gr.get_index(cube(sim, dims), interp=True).values, np.float64)
+    check(p, expected_cubic(sim, af, hq, gcoord, newg, extrap, kind))
+    assert p.dtype == np.float32
+    # and it is not the piecewise-linear interpolant
+    lin = eqm.adjust(cube(sim, dims), interp="linear", extrapolation=extrap).transpose(*dims).values
+    both = np.isfinite(lin) & np.isfinite(p)
+    assert np.abs(lin[both] - p[both]).max() > 1e-3
+
+
+def test_grouped_cubic_with_nan_nodes_and_float64():
+    rng = np.random.default_rng(32)
+    C, T, Q = 2, 5 * 365, 15
+    ref, hist, sim = (a.astype(np.float64) for a in gen(rng, C, T))
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.month")
+    eqm = xs.EmpiricalQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=Q)
+    af = eqm.ds.af.transpose("lat", "month", "quantiles").values.copy()
+    hq = eqm.ds.hist_q.transpose("lat", "month", "quantiles").values.copy()
+    af[0, 4, :] = np.nan
+    af[1, 2, 3] = np.nan
+    hq[1, 7, 0] = np.nan
+    gcoord = np.arange(0, 14.0)
+    newg = np.asarray(gr.get_index(cube(sim, dims), interp=True).values, np.float64)
+    got = hip.qm_adjust_linear2d(sim, af, hq, gcoord, newg, "constant", "+", cubic=True)
+    exp = np.empty_like(sim)
+    for c in range(C):
+        a = oracle.interp_on_quantiles_2d(sim[c], newg, wrap(hq[c]), wrap(af[c]), np.repeat(gcoord[:, None], Q, 1), "cubic", "constant")
+        exp[c] = sim[c] + a
+    nan_mismatch = np.isnan(got) != np.isnan(exp)
+    both = ~np.isnan(got) & ~np.isnan(exp)
+    assert nan_mismatch.sum() <= 2e-3 * got.size
+    # the gradients are an iterative solution (tol 1e-6): both sides stop at the same sweep, rounding differs
+    assert (~np.isclose(got[both], exp[both], rtol=1e-8, atol=1e-8)).sum() <= 2e-3 * got.size
+
+
+def test_eqm_dayofyear_cubic():
+    """day-of-year tables: 367 x Q nodes per cell (triangulation and gradients stay in global memory).  Windowed rows share
+    order statistics, so a fifth of the nodes sit exactly above a node of the next row: rectangles, i.e. cocircular
+    quadruples whose diagonal is the triangulator's choice (Qhull's is arbitrary) and feeds into the gradients around it.
+    (1) with the ties broken by a jitter of the abscissae the device path reproduces griddata; (2) on the tied table the two
+    stay an order of magnitude closer to each other than the cubic interpolant is to the linear one."""
+    rng = np.random.default_rng(33)
+    C, T, Q = 2, 6 * 365, 10
+    ref, hist, sim = gen(rng, C, T)
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.dayofyear", 31)
+    eqm = xs.EmpiricalQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=Q)
+    af = np.ascontiguousarray(eqm.ds.af.transpose("lat", "dayofyear", "quantiles").values)
+    hq = np.ascontiguousarray(eqm.ds.hist_q.transpose("lat", "dayofyear", "quantiles").values)
+    gcoord = np.arange(0, 367.0)
+    newg = np.asarray(gr.get_index(cube(sim, dims), interp=True).values, np.float64)
+    # (1)
+    hqj = np.sort(hq.astype(np.float64) + rng.uniform(0, 0.02, hq.shape), axis=-1)  # (float64: no accidental new ties)
+    assert not (hqj[:, 1:, :, None] == hqj[:, :-1, None, :]).any()
+    sim64, af64 = sim.astype(np.float64), af.astype(np.float64)
+    got = hip.qm_adjust_linear2d(sim64, af64, hqj, gcoord, newg, "constant", "+", cubic=True)
+    check(got, expected_cubic(sim64, af64, hqj, gcoord, newg, "constant", "+"), frac_tol=5e-3)
+    # (2)
+    p = eqm.adjust(cube(sim, dims), interp="cubic").transpose(*dims).values
+    lin = eqm.adjust(cube(sim, dims), interp="linear").transpose(*dims).values
+    exp = expected_cubic(sim, af, hq, gcoord, newg, "constant", "+")
+    assert np.isfinite(p).all()
+    d, dl = np.abs(p - exp), np.abs(p - lin)
+    assert np.median(d) < 1e-3 and np.quantile(d, 0.99) < 0.2 * np.quantile(dl, 0.99) and d.max() < 0.2 * dl.max()
+
+
+def test_qdm_grouped_cubic_runs_on_the_regular_grid():
+    """QDM looks sim_q up in the regular (quantile, group) grid, whose cells are cocircular quadruples: the diagonals are
+    the triangulator's choice (see test_interp_linear_gpu), so only the node values and smoothness are asserted"""
+    rng = np.random.default_rng(35)
+    ref, hist, sim = gen(rng, 2, 5 * 365)
+    dims = ("lat", "time")
+    gr = xs.Grouper("time.month")
+    qdm = xs.QuantileDeltaMapping.train(cube(ref, dims), cube(hist, dims), group=gr, nquantiles=10)
+    lin = qdm.adjust(cube(sim, dims), interp="linear").transpose(*dims).values
+    cub = qdm.adjust(cube(sim, dims), interp="cubic").transpose(*dims).values
+    assert np.isfinite(cub).all()
+    af = qdm.ds.af.values
+    assert np.abs(cub - lin).max() <= 0.5 * (af.max() - af.min())
+    assert np.median(np.abs(cub - lin)) < 0.05 * (af.max() - af.min())
+
+
+def test_dqm_grouped_cubic_is_refused():
+    rng = np.random.default_rng(36)
+    ref, hist, sim = gen(rng, 1, 3 * 365)
+    dims = ("lat", "time")
+    with pytest.warns(UserWarning):
+        dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group="time.month", nquantiles=8)
+    with pytest.raises(ValueError) as err:  # in-block failures are re-wrapped like the reference does (base.py:701-702)
+        dqm.adjust(cube(sim, dims), interp="cubic")
+    assert isinstance(err.value.__cause__, NotImplementedError)

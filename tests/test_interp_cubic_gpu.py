@@ -94,10 +94,10 @@ def test_qdm_time_cubic():
     np.testing.assert_allclose(out.scen.values, sim * a, rtol=3e-6)
 
 
-def test_grouped_cubic_is_refused():
+def test_grouped_cubic_takes_the_triangulated_path():
+    """a grouped table goes through griddata's Clough-Tocher interpolant (tests/test_interp_cubic2d_gpu.py); with ref == hist
+    every factor is zero and so is the interpolant"""
     rng = np.random.default_rng(34)
     x = tseries((280 + rng.standard_normal(1500)).astype(np.float32))
     eqm = xs.EmpiricalQuantileMapping.train(x, x, group="time.month", nquantiles=5)
-    with pytest.raises(ValueError) as ei:
-        eqm.adjust(x, interp="cubic")
-    assert isinstance(ei.value.__cause__, NotImplementedError)
+    np.testing.assert_array_equal(eqm.adjust(x, interp="cubic").values, x.values)

@@ -3,8 +3,8 @@
 qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` like the reference, but its
 body is ONE call into the HIP library that covers every group of every cell of the block.
 
-Not yet on the device path (rows "next" of SURVEY §8f; they raise NotImplementedError instead of running
-anything on the CPU): grouped ``interp`` other than "nearest", ``PolyDetrend`` degrees other than 0/1.
+Not on the device path (raises NotImplementedError instead of running anything on the CPU): DQM with a grouped
+``interp="cubic"``; the few option combinations refused below say so in their message.
 
 ``Grouper(add_dims=...)`` (base.py:413: the extra dimensions are pooled into every group's sample at training, and into
 the windowed ranks / the detrending fit at adjustment) needs no kernel of its own: the P pooled members of a cell are
@@ -274,11 +274,8 @@ def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     _check_group(group, ds)
     if interp not in ("nearest", "linear", "cubic"):
         raise ValueError(f"interp must be 'nearest', 'linear' or 'cubic', got {interp!r}")
-    if (interp == "cubic" and group.prop != "group") or (interp != "nearest" and group.prop != "group" and not grouped_linear):
-        raise NotImplementedError(
-            f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path"
-            + ": the reference routes a grouped 'cubic' through scipy.griddata's Clough-Tocher interpolant (utils.py:391-396); use 'nearest' or 'linear'"
-        )
+    if interp != "nearest" and group.prop != "group" and not grouped_linear:
+        raise NotImplementedError(f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path")
     sim = as_dataarray(ds["sim"])
     dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
     pooled = [d for d in group.add_dims if d in sim.dims]
@@ -348,10 +345,12 @@ def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None,
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
-    if interp == "linear" and G > 1:
+    if interp in ("linear", "cubic") and G > 1:
+        # the reference's griddata path (utils.py:391-396): "linear" = piecewise-linear on the Delaunay triangulation of the
+        # cell's table nodes, "cubic" = the Clough-Tocher interpolant on the same triangulation (csrc/lin2d.hpp)
         _no_linear_tail_mask(group, max_tail_factor)
         gcoord, newg = _linear_group_coords(group, sim)
-        scen = hip.qm_adjust_linear2d(s2, af, hq, gcoord, newg, extrapolation, kind)
+        scen = hip.qm_adjust_linear2d(s2, af, hq, gcoord, newg, extrapolation, kind, cubic=interp == "cubic")
     else:
         scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
@@ -393,6 +392,10 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     if not 0 <= degree <= 6:
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0..6)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
+    if interp == "cubic" and G > 1:
+        raise NotImplementedError("dqm_adjust with a grouped interp='cubic' is not implemented on the HIP path (the reference then "
+                                  "also broadcasts the scaling with a cubic spline between the group centres, _adjustment.py:748-757); "
+                                  "EQM and QDM accept it")
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
@@ -466,16 +469,16 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
     quantiles = np.asarray(ds["quantiles"].values, dt)
     P = _n_pooled(group, cell_dims, cell_shape)
     sim_q = None
-    if interp == "linear" and G > 1:
+    if interp in ("linear", "cubic") and G > 1:
         # the factors interpolated at (sim_q, fractional group) over the regular (quantile, group) grid (:873-881).  Every
         # cell of that grid is a cocircular quadruple: which diagonal splits it is the triangulator's choice (Qhull's in
         # the reference, the sweep's here), so the two agree exactly only where the four corner factors are coplanar.
         _no_linear_tail_mask(group, max_tail_factor)
         if P > 1 and rank_window:
-            raise NotImplementedError("qdm_adjust with `add_dims`, rank_window and a grouped interp='linear' is not implemented on the HIP path")
+            raise NotImplementedError("qdm_adjust with `add_dims`, rank_window and a grouped interp='linear' / 'cubic' is not implemented on the HIP path")
         sim_q = hip.rank_groups(s2, gidx, G, group.window, bool(rank_window))
         gcoord, newg = _linear_group_coords(group, sim)
-        scen = hip.qm_adjust_linear2d(s2, af, quantiles, gcoord, newg, extrapolation, kind, lookup=sim_q)
+        scen = hip.qm_adjust_linear2d(s2, af, quantiles, gcoord, newg, extrapolation, kind, lookup=sim_q, cubic=interp == "cubic")
     elif P > 1 and rank_window:
         # ranks over (time, window, pooled members) (_adjustment.py:873: main_only = not rank_window): the members of a
         # cell laid end to end as one series, like at training; the table of the cell serves all of them

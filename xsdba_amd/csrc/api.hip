@@ -687,7 +687,7 @@ int qm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, in
 template <typename R>
 int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t st, int64_t sc, const void *af,
                             const void *hq, int G, int Q, const double *gcoord, const double *newg, int extrap, char kind,
-                            const void *trend, const double *lookup, int hq_is_row, void *scen, int64_t ost, int64_t osc)
+                            const void *trend, const double *lookup, int hq_is_row, void *scen, int64_t ost, int64_t osc, int cubic = 0)
 {
     if (C <= 0 || T <= 0 || Q <= 0 || G < 2 || !af || !hq || !scen || !gcoord || !newg) return fail(XSDBA_E_ARG, "null/empty argument");
     if ((int64_t)(G + 2) * Q > 32000) return fail(XSDBA_E_UNSUPPORTED, "more than 32000 table nodes per cell (%d groups x %d quantiles)", G, Q);
@@ -703,7 +703,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
     if (lookup && (rc = stage_in(ctx, S_CM2, lookup, (size_t)T * C * sizeof(double), &dlk))) return rc;
     SeriesOut o;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
-    const xs::Lin2DLayout L = xs::lin2d_layout(G, Q);
+    const xs::Lin2DLayout L = xs::lin2d_layout(G, Q, cubic != 0);
     // cells in chunks so that the triangulations of a chunk take at most ~2 GiB of scratch
     const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(C, (int64_t)((2ull << 30) / L.total)));
     void *scratch;
@@ -724,7 +724,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
             LaunchScope ls(ctx, "k_lin2d_build");
             hipLaunchKernelGGL(xs::k_lin2d_build<R>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream,
                                (const R *)dhq + (hq_is_row ? 0 : (size_t)c0 * G * Q), (const R *)daf + (size_t)c0 * G * Q, (const double *)dgc, G, Q, nc,
-                               (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0);
+                               (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0, cubic);
         }
         if ((rc = check_launch("k_lin2d_build"))) return rc;
         {
@@ -734,7 +734,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
                 hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, ctx->stream, (const R *)s.dev + c0 * s.sc, T, nc, s.sc,
                                    (const double *)dng, (const int *)jrow, G, Q, (const unsigned char *)scratch, L.total, extrap,
                                    (int)kind, dtr ? (const R *)dtr + (size_t)c0 * T : (const R *)nullptr,
-                                   (R *)o.kernel_dst + (size_t)c0 * T, T, dlk ? (const double *)dlk + (size_t)c0 * T : (const double *)nullptr);
+                                   (R *)o.kernel_dst + (size_t)c0 * T, T, dlk ? (const double *)dlk + (size_t)c0 * T : (const double *)nullptr, cubic);
             };
             if (use_lds) launch(xs::k_lin2d_adjust<R, true>, L.staged);
             else launch(xs::k_lin2d_adjust<R, false>, 0);
@@ -1553,6 +1553,17 @@ API int xsdba_hip_qm_adjust_linear2d(xsdba_hip_ctx *ctx, const void *sim, int dt
     if (rc || (rc = check_kind(kind, trend == nullptr))) return rc;
     return DISPATCH(dtype, (qm_adjust_linear2d_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, lookup, hist_q_is_row, scen, ost, osc)),
                     (qm_adjust_linear2d_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, lookup, hist_q_is_row, scen, ost, osc)));
+}
+
+API int xsdba_hip_qm_adjust_cubic2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,
+                                    const void *af, const void *hist_q, int32_t G, int32_t Q, const double *group_coord,
+                                    const double *new_group, int extrap, char kind, const void *trend, const double *lookup,
+                                    int hist_q_is_row, void *scen, int64_t ost, int64_t osc)
+{
+    int rc = check_ctx(ctx);
+    if (rc || (rc = check_kind(kind, trend == nullptr))) return rc;
+    return DISPATCH(dtype, (qm_adjust_linear2d_impl<float>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, lookup, hist_q_is_row, scen, ost, osc, 1)),
+                    (qm_adjust_linear2d_impl<double>(ctx, sim, T, C, st, sc, af, hist_q, G, Q, group_coord, new_group, extrap, kind, trend, lookup, hist_q_is_row, scen, ost, osc, 1)));
 }
 
 API int xsdba_hip_dqm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t T, int64_t C, int64_t st, int64_t sc,

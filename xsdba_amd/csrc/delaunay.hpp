@@ -254,4 +254,135 @@ XS_HD double dt_eval(const Tri2D &d, const double *val, int t, double qx, double
     return c0 * val[a] + c1 * val[b] + c2 * val[c];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// griddata(method="cubic") = scipy.interpolate.CloughTocher2DInterpolator(points, values, tol=1e-6, maxiter=400) — what the
+// reference's grouped interp="cubic" evaluates (utils._interp_on_quantiles_2d, utils.py:391-396).  Its published algorithm
+// (scipy/interpolate/interpnd.pyx, restated from the paper trail it cites: Nielson 1983 / Renka & Cline 1984 for the
+// gradients, Alfeld 1984 / Farin 1986 for the element): (1) the gradient at every node minimises the curvature functional
+// of the cubic Hermite edge curves, solved by Gauss-Seidel sweeps over the nodes in index order until the largest relative
+// change of a sweep is below tol; (2) on every triangle the C1 Clough-Tocher element in Bezier form, the cross-boundary
+// derivative taken along the direction to the centroid of the neighbouring triangle (affine invariant).
+
+// vertex adjacency in CSR form from the triangle list.  adj_ptr [n + 1], adj_idx [sum of degrees <= 6 n], fill [n] scratch.
+XS_HD void dt_adjacency(const Tri2D &d, int *adj_ptr, uint16_t *adj_idx, uint16_t *fill)
+{
+    const int n = d.n;
+    for (int v = 0; v <= n; v++) adj_ptr[v] = 0;
+    // degree = incident triangles, + 1 on the hull (every hull vertex starts exactly one counter-clockwise hull edge)
+    for (int t = 0; t < d.ntri; t++)
+        for (int k = 0; k < 3; k++) {
+            adj_ptr[d.tv[3 * t + k] + 1]++;
+            if (d.tn[3 * t + k] == DT_NONE) adj_ptr[d.tv[3 * t + (k + 1) % 3] + 1]++;
+        }
+    for (int v = 0; v < n; v++) { adj_ptr[v + 1] += adj_ptr[v]; fill[v] = 0; }
+    for (int t = 0; t < d.ntri; t++)
+        for (int k = 0; k < 3; k++) {
+            const int a = d.tv[3 * t + k];
+            for (int j = 1; j <= 2; j++) {
+                const uint16_t b = d.tv[3 * t + (k + j) % 3];
+                uint16_t *l = adj_idx + adj_ptr[a];
+                const int cap = adj_ptr[a + 1] - adj_ptr[a];
+                int f = fill[a], i = 0;
+                while (i < f && l[i] != b) i++;
+                if (i == f && f < cap) { l[f] = b; fill[a] = (uint16_t)(f + 1); }
+            }
+        }
+}
+
+// Gauss-Seidel estimate of the nodal gradients grad[2 n] (interpnd._estimate_gradients_2d_global)
+XS_HD int dt_gradients(const Tri2D &d, const double *val, const int *adj_ptr, const uint16_t *adj_idx, double *grad,
+                       int maxiter = 400, double tol = 1e-6)
+{
+    const int n = d.n;
+    for (int i = 0; i < 2 * n; i++) grad[i] = 0.0;
+    for (int iter = 0; iter < maxiter; iter++) {
+        double err = 0.0;
+        for (int ip = 0; ip < n; ip++) {
+            if (adj_ptr[ip + 1] == adj_ptr[ip]) continue;  // a node outside the triangulation
+            double Q0 = 0.0, Q1 = 0.0, Q3 = 0.0, s0 = 0.0, s1 = 0.0;
+            const double f1 = val[ip];
+            for (int j = adj_ptr[ip]; j < adj_ptr[ip + 1]; j++) {
+                const int ip2 = adj_idx[j];
+                const double ex = d.px[ip2] - d.px[ip], ey = d.py[ip2] - d.py[ip];
+                const double L = sqrt(ex * ex + ey * ey), L3 = L * L * L;
+                const double f2 = val[ip2];
+                const double df2 = -ex * grad[2 * ip2] - ey * grad[2 * ip2 + 1];
+                Q0 += 4.0 * ex * ex / L3;
+                Q1 += 4.0 * ex * ey / L3;
+                Q3 += 4.0 * ey * ey / L3;
+                s0 += (6.0 * (f1 - f2) - 2.0 * df2) * ex / L3;
+                s1 += (6.0 * (f1 - f2) - 2.0 * df2) * ey / L3;
+            }
+            const double det = Q0 * Q3 - Q1 * Q1;
+            const double r0 = (Q3 * s0 - Q1 * s1) / det, r1 = (-Q1 * s0 + Q0 * s1) / det;
+            double change = fmax(fabs(grad[2 * ip] + r0), fabs(grad[2 * ip + 1] + r1));
+            grad[2 * ip] = -r0;
+            grad[2 * ip + 1] = -r1;
+            change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
+            err = fmax(err, change);
+        }
+        if (err < tol) return iter + 1;
+    }
+    return 0;  // not converged: the last sweep's values are used (scipy warns and does the same)
+}
+
+// barycentric coordinates of (qx, qy) in triangle t (c[2] belongs to the third vertex)
+XS_HD void dt_bary(const Tri2D &d, int t, double qx, double qy, double *c)
+{
+    const int a = d.tv[3 * t], b = d.tv[3 * t + 1], cc = d.tv[3 * t + 2];
+    const double m00 = d.px[a] - d.px[cc], m01 = d.px[b] - d.px[cc], m10 = d.py[a] - d.py[cc], m11 = d.py[b] - d.py[cc];
+    const double det = m00 * m11 - m01 * m10;
+    const double rx = qx - d.px[cc], ry = qy - d.py[cc];
+    c[0] = (m11 * rx - m01 * ry) / det;
+    c[1] = (m00 * ry - m10 * rx) / det;
+    c[2] = 1.0 - c[0] - c[1];
+}
+
+// value of the Clough-Tocher interpolant on triangle t at (qx, qy) (interpnd._clough_tocher_2d_single)
+XS_HD double dt_eval_ct(const Tri2D &d, const double *val, const double *grad, int t, double qx, double qy)
+{
+    const int v0 = d.tv[3 * t], v1 = d.tv[3 * t + 1], v2 = d.tv[3 * t + 2];
+    double b[3];
+    dt_bary(d, t, qx, qy, b);
+    const double e12x = d.px[v1] - d.px[v0], e12y = d.py[v1] - d.py[v0];
+    const double e23x = d.px[v2] - d.px[v1], e23y = d.py[v2] - d.py[v1];
+    const double e31x = d.px[v0] - d.px[v2], e31y = d.py[v0] - d.py[v2];
+    const double f1 = val[v0], f2 = val[v1], f3 = val[v2];
+    const double df12 = +(grad[2 * v0] * e12x + grad[2 * v0 + 1] * e12y);
+    const double df21 = -(grad[2 * v1] * e12x + grad[2 * v1 + 1] * e12y);
+    const double df23 = +(grad[2 * v1] * e23x + grad[2 * v1 + 1] * e23y);
+    const double df32 = -(grad[2 * v2] * e23x + grad[2 * v2 + 1] * e23y);
+    const double df31 = +(grad[2 * v2] * e31x + grad[2 * v2 + 1] * e31y);
+    const double df13 = -(grad[2 * v0] * e31x + grad[2 * v0 + 1] * e31y);
+    const double c3000 = f1, c2100 = (df12 + 3 * c3000) / 3, c2010 = (df13 + 3 * c3000) / 3;
+    const double c0300 = f2, c1200 = (df21 + 3 * c0300) / 3, c0210 = (df23 + 3 * c0300) / 3;
+    const double c0030 = f3, c1020 = (df31 + 3 * c0030) / 3, c0120 = (df32 + 3 * c0030) / 3;
+    const double c2001 = (c2100 + c2010 + c3000) / 3, c0201 = (c1200 + c0300 + c0210) / 3, c0021 = (c1020 + c0120 + c0030) / 3;
+    double g[3];
+    for (int k = 0; k < 3; k++) {
+        const int u = d.tn[3 * t + k];
+        if (u == DT_NONE) { g[k] = -0.5; continue; }
+        const int u0 = d.tv[3 * u], u1 = d.tv[3 * u + 1], u2 = d.tv[3 * u + 2];
+        double c[3];
+        dt_bary(d, t, (d.px[u0] + d.px[u1] + d.px[u2]) / 3, (d.py[u0] + d.py[u1] + d.py[u2]) / 3, c);
+        if (k == 0) g[k] = (2 * c[2] + c[1] - 1) / (2 - 3 * c[2] - 3 * c[1]);
+        else if (k == 1) g[k] = (2 * c[0] + c[2] - 1) / (2 - 3 * c[0] - 3 * c[2]);
+        else g[k] = (2 * c[1] + c[0] - 1) / (2 - 3 * c[1] - 3 * c[0]);
+    }
+    const double c0111 = (g[0] * (-c0300 + 3 * c0210 - 3 * c0120 + c0030) + (-c0300 + 2 * c0210 - c0120 + c0021 + c0201)) / 2;
+    const double c1011 = (g[1] * (-c0030 + 3 * c1020 - 3 * c2010 + c3000) + (-c0030 + 2 * c1020 - c2010 + c2001 + c0021)) / 2;
+    const double c1101 = (g[2] * (-c3000 + 3 * c2100 - 3 * c1200 + c0300) + (-c3000 + 2 * c2100 - c1200 + c2001 + c0201)) / 2;
+    const double c1002 = (c1101 + c1011 + c2001) / 3, c0102 = (c1101 + c0111 + c0201) / 3, c0012 = (c1011 + c0111 + c0021) / 3;
+    const double c0003 = (c1002 + c0102 + c0012) / 3;
+    double mn = b[0];
+    if (b[1] < mn) mn = b[1];
+    if (b[2] < mn) mn = b[2];
+    const double b1 = b[0] - mn, b2 = b[1] - mn, b3 = b[2] - mn, b4 = 3 * mn;
+    return b1 * b1 * b1 * c3000 + 3 * b1 * b1 * b2 * c2100 + 3 * b1 * b1 * b3 * c2010 + 3 * b1 * b1 * b4 * c2001 +
+           3 * b1 * b2 * b2 * c1200 + 6 * b1 * b2 * b4 * c1101 + 3 * b1 * b3 * b3 * c1020 + 6 * b1 * b3 * b4 * c1011 +
+           3 * b1 * b4 * b4 * c1002 + b2 * b2 * b2 * c0300 + 3 * b2 * b2 * b3 * c0210 + 3 * b2 * b2 * b4 * c0201 +
+           3 * b2 * b3 * b3 * c0120 + 6 * b2 * b3 * b4 * c0111 + 3 * b2 * b4 * b4 * c0102 + b3 * b3 * b3 * c0030 +
+           3 * b3 * b3 * b4 * c0021 + 3 * b3 * b4 * b4 * c0012 + b4 * b4 * b4 * c0003;
+}
+
 }  // namespace xs

@@ -8,6 +8,10 @@
 //
 //   k_lin2d_build : one THREAD per cell builds the cell's node list and triangulation (delaunay.hpp) in global scratch
 //   k_lin2d_adjust: one BLOCK per cell stages the triangulation in LDS (when it fits) and maps the series
+//
+// Grouped interp="cubic" takes the same route with griddata(method="cubic") = scipy's CloughTocher2DInterpolator: the build
+// kernel also estimates the nodal gradients (Gauss-Seidel sweeps, delaunay.hpp: dt_gradients) and the adjust kernel evaluates
+// the Clough-Tocher element instead of the plane of the triangle (`cubic` argument / layout flag).
 #pragma once
 #include "delaunay.hpp"
 #include "device_math.hpp"
@@ -16,9 +20,10 @@ namespace xs {
 
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
+    size_t grad, adjp, adji;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form (build only)
 };
 
-__host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
+__host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = false)
 {
     const size_t N = (size_t)(G + 2) * Q;
     Lin2DLayout L;
@@ -34,19 +39,23 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q)
     L.vt = o; o += (sizeof(uint16_t) * N + 3) & ~(size_t)3;   // a triangle incident to every node (walk starts)
     L.rowb = o; o += sizeof(int) * (size_t)(G + 3);            // first node of every cyclic row
     o = (o + 7) & ~(size_t)7;
+    L.grad = o; if (cubic) o += sizeof(double) * 2 * N;
     L.staged = o;
     L.hull = o; o += sizeof(uint16_t) * 4 * N;  // hull ring (3N) + insertion order (N): build only
+    o = (o + 7) & ~(size_t)7;
+    L.adjp = o; if (cubic) o += sizeof(int) * (N + 2);
+    L.adji = o; if (cubic) o += sizeof(uint16_t) * (6 * N + 8);
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
 
 template <typename R>
 __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq, const double *__restrict__ gcoord, int G, int Q,
-                              int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row)
+                              int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row, int cubic)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const Lin2DLayout L = lin2d_layout(G, Q);
+    const Lin2DLayout L = lin2d_layout(G, Q, cubic != 0);
     unsigned char *base = scratch + (size_t)c * stride;
     int *hdr = reinterpret_cast<int *>(base + L.hdr);
     double *meta = reinterpret_cast<double *>(base + L.meta);
@@ -99,6 +108,12 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     uint16_t *vt = reinterpret_cast<uint16_t *>(base + L.vt);
     for (int i = 0; i < n; i++) vt[i] = 0;
     for (int t = 0; t < ntri; t++) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
+    if (cubic) {  // nodal gradients of the Clough-Tocher interpolant (the hull ring is free again: scratch of the adjacency)
+        int *adjp = reinterpret_cast<int *>(base + L.adjp);
+        uint16_t *adji = reinterpret_cast<uint16_t *>(base + L.adji);
+        dt_adjacency(d, adjp, adji, d.hnext);
+        dt_gradients(d, pv, adjp, adji, reinterpret_cast<double *>(base + L.grad));
+    }
 }
 
 // numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside.
@@ -143,10 +158,10 @@ template <typename R, bool USE_LDS>
 __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const double *__restrict__ newg,
                                const int *__restrict__ jrow, int G, int Q, const unsigned char *__restrict__ scratch,
                                size_t stride, int extrap, int kind, const R *__restrict__ trend, R *__restrict__ scen,
-                               int64_t osc, const double *__restrict__ lookup)
+                               int64_t osc, const double *__restrict__ lookup, int cubic)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Lin2DLayout L = lin2d_layout(G, Q);
+    const Lin2DLayout L = lin2d_layout(G, Q, cubic != 0);
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const unsigned char *base;
         if constexpr (USE_LDS) {
@@ -167,6 +182,7 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         d.px = reinterpret_cast<const double *>(base + L.px);
         d.py = reinterpret_cast<const double *>(base + L.py);
         const double *pv = reinterpret_cast<const double *>(base + L.pv);
+        const double *grad = reinterpret_cast<const double *>(base + L.grad);
         d.tv = const_cast<uint16_t *>(reinterpret_cast<const uint16_t *>(base + L.tv));
         d.tn = const_cast<uint16_t *>(reinterpret_cast<const uint16_t *>(base + L.tn));
         d.hnext = d.hprev = d.htri = nullptr;
@@ -196,7 +212,7 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
                     hint = vt[lo];
                 }
                 const int tri = dt_locate(d, vx, g, hint);
-                if (tri >= 0) a = (R)dt_eval(d, pv, tri, vx, g);
+                if (tri >= 0) a = (R)(cubic ? dt_eval_ct(d, pv, grad, tri, vx, g) : dt_eval(d, pv, tri, vx, g));
                 // nbutils._extrapolate_on_quantiles: below / above the group-interpolated first / last node
                 const double lo = extrap == 0 ? np_interp_at(jr, g, gcoord, meta, 4, G + 2) : 0.0;
                 const double hi = extrap == 0 ? np_interp_at(jr, g, gcoord, meta + 1, 4, G + 2) : 0.0;

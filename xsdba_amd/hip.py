@@ -171,9 +171,10 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
     return (scen, node) if return_nodes else scen
 
 
-def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, lookup=None, ctx=None):
+def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, lookup=None, ctx=None,
+                       cubic=False):
     """qm_adjust with grouped interp="linear" (utils._interp_on_quantiles_2d through scipy.griddata, utils.py:380-400) -> scen
-    [C, T].  ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the
+    [C, T]; ``cubic=True``: grouped interp="cubic" (griddata's Clough-Tocher interpolant, ``xsdba_hip_qm_adjust_cubic2d``).  ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the
     fractional group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping.
     QDM form: ``hist_q`` a single row [Q] (the quantile nodes) and ``lookup`` [C, T] float64 (sim_q) to look up instead of sim."""
     ctx = ctx or default_context()
@@ -195,11 +196,12 @@ def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant
         if tuple(lookup.shape) != (s.C, s.T):
             raise ValueError(f"lookup must have shape {(s.C, s.T)}")
     scen = _out(ctx, s.dev, (s.C, s.T), s.dtype)
-    check(load().xsdba_hip_qm_adjust_linear2d(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
-                                              _vp(af), _vp(hist_q), C.c_int(G), C.c_int(Q), _vp(gc), _vp(ng), C.c_int(EXTRAP[extrap]),
-                                              C.c_char(kind.encode() if kind else b"\0"), _vp(trend), _vp(lookup), C.c_int(int(row)),
-                                              _vp(scen), _i64(1), _i64(s.T)),
-          "qm_adjust_linear2d")
+    entry = load().xsdba_hip_qm_adjust_cubic2d if cubic else load().xsdba_hip_qm_adjust_linear2d
+    check(entry(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
+                _vp(af), _vp(hist_q), C.c_int(G), C.c_int(Q), _vp(gc), _vp(ng), C.c_int(EXTRAP[extrap]),
+                C.c_char(kind.encode() if kind else b"\0"), _vp(trend), _vp(lookup), C.c_int(int(row)),
+                _vp(scen), _i64(1), _i64(s.T)),
+          "qm_adjust_cubic2d" if cubic else "qm_adjust_linear2d")
     return scen
 
 

@@ -107,11 +107,12 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
 
     Ungrouped: 1-D scipy-interp1d semantics ('nearest' | 'linear').  Grouped: the reference's 2-D griddata path:
     ``method="nearest"`` (true 2-D nearest neighbour) and ``"linear"`` (Delaunay triangulation of every cell's nodes +
-    piecewise-linear interpolant, csrc/lin2d.hpp); 'cubic' (Clough-Tocher in the reference) raises NotImplementedError.
+    piecewise-linear interpolant, csrc/lin2d.hpp) or ``"cubic"`` (the Clough-Tocher interpolant on the same triangulation).
+    Ungrouped 'cubic' is interp1d's not-a-knot spline.
     """
     newx, xq, yq = as_dataarray(newx), as_dataarray(xq), as_dataarray(yq)
     dim, prop = group.dim, group.prop
-    if method not in ("nearest", "linear", "cubic") or (method == "cubic" and prop != "group"):
+    if method not in ("nearest", "linear", "cubic"):
         raise NotImplementedError(f"interp_on_quantiles(method={method!r}) with group {group.name!r} is not implemented on the HIP path")
     x2, cell_dims, cell_shape = cell_time_view(newx, dim)
     if prop == "group":
@@ -136,13 +137,13 @@ def interp_on_quantiles(newx, xq, yq, *, group: str | Grouper = "time", method: 
         xt, yt = table_view(xq, cell_dims, prop), table_view(yq, cell_dims, prop)
         gidx, _ = group.group_index(newx)
     dt = np.result_type(yt.dtype, np.float32)
-    if gidx is not None and method == "linear":
+    if gidx is not None and method in ("linear", "cubic"):
         # the reference's griddata path: Delaunay triangulation of the (xq, group coordinate) nodes per cell (csrc/lin2d.hpp)
         c = (np.arange(4) if prop == "season" else np.asarray(crd.values)).astype(np.float64)
         gcoord = np.concatenate([[c[0] - (c[1] - c[0])], c, [c[-1] + (c[-1] - c[-2])]])
         newg = np.asarray(group.get_index(newx, interp=True).values, np.float64)
         out = hip.qm_adjust_linear2d(x2.astype(dt, copy=False), yt.astype(dt, copy=False), xt.astype(dt, copy=False), gcoord, newg,
-                                     extrapolation, kind=None)
+                                     extrapolation, kind=None, cubic=method == "cubic")
         coords = {k: c_ for k, c_ in newx.coords.items() if k in cell_dims or k == dim}
         return DataArray(out.reshape(cell_shape + (out.shape[-1],)), cell_dims + (dim,), coords)
     out = hip.qm_adjust(x2.astype(dt, copy=False), yt.astype(dt, copy=False), xt.astype(dt, copy=False), gidx, method,
