@@ -118,9 +118,13 @@ class TestScaling:
         fac = np.interp(i, np.arange(14), ext)
         exp = sim.values + fac if kind == ADDITIVE else sim.values * fac
         np.testing.assert_allclose(pl.values, exp, rtol=1e-12)
-        with pytest.raises(ValueError) as err:
-            scaling.adjust(sim, interp="cubic")
-        assert isinstance(err.value.__cause__, NotImplementedError)
+        # interp="cubic" on a lone series: xarray's .interp(method="cubic") = scipy's interp1d(kind="cubic") over the same nodes
+        from scipy.interpolate import interp1d
+
+        pc = scaling.adjust(sim, interp="cubic")
+        facc = interp1d(np.arange(14.0), ext, kind="cubic")(i)
+        expc = sim.values + facc if kind == ADDITIVE else sim.values * facc
+        np.testing.assert_allclose(pc.values, expc, rtol=1e-6)
 
 
 class TestQM:

@@ -22,12 +22,18 @@ def _gpu():
     hip.default_context(0)
 
 
-def expected_cubic(sim, af, hq, gcoord, newg, extrap, kind):
+def expected_cubic(sim, af, hq, gcoord, newg, extrap, kind, trend=None):
     out = np.empty_like(sim)
     for c in range(sim.shape[0]):
+        x = sim[c]
+        if trend is not None:
+            x = x - trend[c] if kind == "+" else x * (np.float32(1) / trend[c])
         oldg = np.repeat(gcoord[:, None], af.shape[2], 1)
-        a = oracle.interp_on_quantiles_2d(sim[c], newg, wrap(hq[c]), wrap(af[c]), oldg, "cubic", extrap)
-        out[c] = sim[c] + a if kind == "+" else sim[c] * a
+        a = oracle.interp_on_quantiles_2d(x, newg, wrap(hq[c]), wrap(af[c]), oldg, "cubic", extrap)
+        y = x + a if kind == "+" else x * a
+        if trend is not None:
+            y = y + trend[c] if kind == "+" else y * trend[c]
+        out[c] = y
     return out
 
 
@@ -130,12 +136,58 @@ def test_qdm_grouped_cubic_runs_on_the_regular_grid():
     assert np.median(np.abs(cub - lin)) < 0.05 * (af.max() - af.min())
 
 
-def test_dqm_grouped_cubic_is_refused():
-    rng = np.random.default_rng(36)
-    ref, hist, sim = gen(rng, 1, 3 * 365)
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_grouped_cubic(kind):
+    """dqm_adjust with interp="cubic" on monthly groups (_adjustment.py:748-773): the scaling table shares `lat` with the
+    series, so utils.broadcast falls back to linear with a warning (utils.py:228-234); then fit / detrend / Clough-Tocher
+    mapping / retrend"""
+    rng = np.random.default_rng(37)
+    C, T, Q = 2, 6 * 365, 12
+    ref, hist, sim = gen(rng, C, T)
+    sim = (sim + np.linspace(0, 3, T)[None]).astype(np.float32)
     dims = ("lat", "time")
+    gr = xs.Grouper("time.month")
     with pytest.warns(UserWarning):
-        dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group="time.month", nquantiles=8)
-    with pytest.raises(ValueError) as err:  # in-block failures are re-wrapped like the reference does (base.py:701-702)
-        dqm.adjust(cube(sim, dims), interp="cubic")
-    assert isinstance(err.value.__cause__, NotImplementedError)
+        dqm = xs.DetrendedQuantileMapping.train(cube(ref, dims), cube(hist, dims), group=gr, kind=kind, nquantiles=Q)
+    from xsdba_amd._adjustment import _group_interp_nodes, dqm_adjust
+
+    with pytest.warns(UserWarning, match="not cubic. Using linear"):
+        out = dqm_adjust(dqm.ds.assign(sim=cube(sim, dims)), group=gr, interp="cubic", kind=kind, extrapolation="constant", detrend=1)
+    af = np.ascontiguousarray(dqm.ds.af.transpose("lat", "month", "quantiles").values)
+    hq = np.ascontiguousarray(dqm.ds.hist_q.transpose("lat", "month", "quantiles").values)
+    sc = np.ascontiguousarray(dqm.ds.scaling.transpose("lat", "month").values)
+    gidx, G = gr.group_index(cube(sim, dims))
+    g_lo, g_hi, frac = _group_interp_nodes(gr, cube(sim, dims), gidx, G, "linear")
+    scaled = oracle.scaling_adjust(sim, sc, g_lo, kind, g_hi=g_hi, frac=frac)
+    tnum = gr._time_index(cube(sim, dims)).numeric_ns
+    trend = oracle.polydetrend_trend(scaled, gidx, G, 1, tnum, 1)
+    np.testing.assert_allclose(out.trend.transpose(*dims).values, trend, rtol=3e-6)
+    gcoord = np.arange(0, 14.0)
+    newg = np.asarray(gr.get_index(cube(sim, dims), interp=True).values, np.float64)
+    exp = expected_cubic(scaled, af, hq, gcoord, newg, "constant", kind, trend=trend.astype(np.float32))
+    got = out.scen.transpose(*dims).values
+    both = ~np.isnan(got) & ~np.isnan(exp)
+    assert (np.isnan(got) != np.isnan(exp)).sum() <= 2e-3 * got.size
+    assert (~np.isclose(got[both], exp[both], rtol=3e-5, atol=3e-4)).sum() <= 2e-3 * got.size
+
+
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_scaling_cubic_on_a_lone_series(kind):
+    """Scaling.adjust(interp="cubic") on a series without other dimensions: utils.broadcast interpolates the monthly factors
+    with xarray's .interp(method="cubic") = scipy's interp1d(kind="cubic") through the table wrapped with its cyclic rows
+    (utils.py:222-246)"""
+    from scipy.interpolate import interp1d
+
+    rng = np.random.default_rng(38)
+    T = 4 * 365
+    ref, hist, sim = (a[0] + (5 if kind == "*" else 0) for a in gen(rng, 1, T))
+    dims = ("time",)
+    sc = xs.Scaling.train(cube(ref, dims), cube(hist, dims), group="time.month", kind=kind)
+    got = sc.adjust(cube(sim, dims), interp="cubic").values
+    af = sc.ds.af.values.astype(np.float64)
+    i = xs.Grouper("time.month").get_index(cube(sim, dims), interp=True).values
+    fac = interp1d(np.arange(14.0), np.concatenate([af[-1:], af, af[:1]]), kind="cubic")(i).astype(np.float32)
+    exp = sim + fac if kind == "+" else sim * fac
+    np.testing.assert_allclose(got, exp, rtol=2e-6)
+    lin = sc.adjust(cube(sim, dims), interp="linear").values
+    assert np.abs(lin - got).max() > 1e-4

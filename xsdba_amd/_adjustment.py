@@ -392,10 +392,6 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     if not 0 <= degree <= 6:
         raise NotImplementedError(f"PolyDetrend(degree={degree}) is not implemented on the HIP path (0..6)")
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, interp, grouped_linear=True)
-    if interp == "cubic" and G > 1:
-        raise NotImplementedError("dqm_adjust with a grouped interp='cubic' is not implemented on the HIP path (the reference then "
-                                  "also broadcasts the scaling with a cubic spline between the group centres, _adjustment.py:748-757); "
-                                  "EQM and QDM accept it")
     s2 = _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thresh, cell_shape)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
     hq = table_view(as_dataarray(ds["hist_q"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
@@ -403,7 +399,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     tnum = group._time_index(sim).numeric_ns
     P = _n_pooled(group, cell_dims, cell_shape)
     if own is not None:
-        if (interp == "linear" and G > 1) or P > 1 or own.group.add_dims:
+        if (interp in ("linear", "cubic") and G > 1) or P > 1 or own.group.add_dims:
             raise NotImplementedError("a PolyDetrend with its own group / kind / options together with `add_dims` or a grouped "
                                       "interp='linear' is not implemented on the HIP path")
         if own.mult_skip_zeros and own.kind != "*":  # detrending.py:107-110
@@ -425,17 +421,17 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
             trend_in = hip.polydetrend_trend(scaled, gidx_d, G_d, own.group.window, tnum, degree, bool(own.preserve_mean), own.kind)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in,
                                      trend_kind=own_kind, mult_skip_zeros=bool(own.mult_skip_zeros) and own_kind == "*")
-    elif interp == "linear" and G > 1:
-        # the scaling is broadcast linearly between the group centres too, except on day-of-year groups (:748-757); then
-        # fit / detrend / grouped-linear mapping / retrend (:759-773) as separate device steps
+    elif interp in ("linear", "cubic") and G > 1:
+        # the scaling is broadcast between the group centres with the same method, except on day-of-year groups (:748-757);
+        # then fit / detrend / grouped-linear (or Clough-Tocher) mapping / retrend (:759-773) as separate device steps
         _no_linear_tail_mask(group, max_tail_factor)
         if P > 1:
-            raise NotImplementedError("dqm_adjust with `add_dims` and a grouped interp='linear' is not implemented on the HIP path")
-        g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, "linear" if group.prop != "dayofyear" else "nearest")
-        scaled = hip.scaling_adjust(s2, sc, g_lo, kind, g_hi=g_hi, frac=frac)
+            raise NotImplementedError("dqm_adjust with `add_dims` and a grouped interp='linear' / 'cubic' is not implemented on the HIP path")
+        scaled = _broadcast_correct(group, sim, as_dataarray(ds["scaling"]), s2, sc, gidx, G, kind,
+                                    interp if group.prop != "dayofyear" else "nearest")
         trend = hip.polydetrend_trend(scaled, gidx, G, group.window, tnum, degree)
         gcoord, newg = _linear_group_coords(group, sim)
-        scen = hip.qm_adjust_linear2d(scaled, af, hq, gcoord, newg, extrapolation, kind, trend=trend)
+        scen = hip.qm_adjust_linear2d(scaled, af, hq, gcoord, newg, extrapolation, kind, trend=trend, cubic=interp == "cubic")
     elif P > 1:
         trend_in = _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
@@ -532,14 +528,37 @@ def _group_interp_nodes(group: Grouper, sim: DataArray, gidx, G: int, interp: st
     return g_lo, g_hi, frac
 
 
+def _broadcast_correct(group: Grouper, sim: DataArray, table: DataArray, s2, tab, gidx, G: int, kind: str, interp: str):
+    """apply_correction(sim, utils.broadcast(table, sim, group=group, interp=interp), kind) (utils.py:180-248) -> [C, T].
+    'nearest' / 'linear' between the group centres run in ``hip.scaling_adjust``.  'cubic': the reference falls back to
+    'linear' with a warning as soon as the table shares a dimension with the series (:228-234); for a lone series
+    xarray's ``.interp(method="cubic")`` is scipy's interp1d(kind="cubic") through the G + 2 values of the table wrapped with
+    its cyclic rows (add_cyclic_bounds :284-314) — a table-sized spline evaluated once per time step here, applied to the
+    series on the device."""
+    if interp == "cubic" and G > 1 and set(table.dims) & set(sim.dims):
+        warnings.warn("Broadcasting operations in multiple dimensions can only be done with linear and nearest-neighbor"
+                      " interpolation, not cubic. Using linear.", stacklevel=2)
+        interp = "linear"
+    if interp == "cubic" and G > 1:
+        from scipy.interpolate import interp1d
+
+        i = np.asarray(group.get_index(sim, interp=True).values, np.float64)
+        c0 = 0 if group.prop == "season" else 1  # coordinate of the first group
+        row = np.asarray(tab, np.float64).reshape(G)
+        ext = np.concatenate([row[-1:], row, row[:1]])
+        fac = interp1d(np.arange(c0 - 1, c0 + G + 1, dtype=np.float64), ext, kind="cubic", bounds_error=False)(i)
+        return hip.series_correction(s2, fac.astype(np.asarray(tab).dtype), kind)
+    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
+    return hip.scaling_adjust(s2, tab, g_lo if G > 1 else None, kind, g_hi=g_hi, frac=frac)
+
+
 @map_blocks(reduces=[Grouper.PROP], scen=[])
 def scaling_adjust(ds, *, group, interp, kind) -> Dataset:
     """Scaling: adjust on one block (_adjustment.py:961-974); the factors are broadcast on the group of each time step
     (utils.broadcast :180-248), "nearest" or linearly interpolated between group centres."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
-    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
-    scen = hip.scaling_adjust(s2, af, g_lo if G > 1 else None, kind, g_hi=g_hi, frac=frac)
+    scen = _broadcast_correct(group, sim, as_dataarray(ds["af"]), s2, af, gidx, G, kind, interp)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
 
