@@ -37,7 +37,8 @@ else:
 gcoord = np.arange(0, G + 2.0)
 res = {}
 for name, fn in (("nearest", lambda: hip.qm_adjust(sim, af, hq, gidx, "nearest", "constant", "+", ctx=ctx)),
-                 ("linear", lambda: hip.qm_adjust_linear2d(sim, af, hq, gcoord, newg, "constant", "+", ctx=ctx))):
+                 ("linear", lambda: hip.qm_adjust_linear2d(sim, af, hq, gcoord, newg, "constant", "+", ctx=ctx)),
+                 ("cubic", lambda: hip.qm_adjust_linear2d(sim, af, hq, gcoord, newg, "constant", "+", ctx=ctx, cubic=True))):
     fn(); ctx.synchronize()
     ctx.profile_enable(True); ctx.profile_read()
     t0 = time.perf_counter()
