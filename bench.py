@@ -17,6 +17,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 from pathlib import Path
@@ -252,7 +253,12 @@ def pmc_traffic(workload, cells, days, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very configuration
     (profiles/*traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None when
     no PMC run matches the workload being benchmarked."""
-    for f in sorted((ROOT / "profiles").glob("*traffic*.json"), reverse=True):
+    # the newest set first: "<round>_final_*", then the versioned sets in descending order (v10 before v9)
+    def age(f):
+        m = re.search(r"r(\d+)_(final|v(\d+))", f.name)
+        return (int(m.group(1)), 10**6 if m.group(2) == "final" else int(m.group(3))) if m else (-1, -1)
+
+    for f in sorted((ROOT / "profiles").glob("*traffic*.json"), key=age, reverse=True):
         try:
             d = json.loads(f.read_text())
         except Exception:

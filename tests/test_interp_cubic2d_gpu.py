@@ -191,3 +191,16 @@ def test_scaling_cubic_on_a_lone_series(kind):
     np.testing.assert_allclose(got, exp, rtol=2e-6)
     lin = sc.adjust(cube(sim, dims), interp="linear").values
     assert np.abs(lin - got).max() > 1e-4
+
+
+def test_loci_cubic_falls_back_to_linear_on_a_grid():
+    """utils.broadcast (utils.py:228-234): with a dimension shared between the tables and the series the reference warns and
+    interpolates linearly"""
+    rng = np.random.default_rng(39)
+    ref, hist, sim = (np.abs(a - 280).astype(np.float32) for a in gen(rng, 2, 4 * 365))
+    dims = ("lat", "time")
+    loci = xs.LOCI.train(cube(ref, dims, "mm/d"), cube(hist, dims, "mm/d"), group="time.month", thresh="1 mm/d")
+    lin = loci.adjust(cube(sim, dims, "mm/d"), interp="linear").values
+    with pytest.warns(UserWarning, match="not cubic. Using linear"):
+        cub = loci.adjust(cube(sim, dims, "mm/d"), interp="cubic").values
+    np.testing.assert_array_equal(cub, lin)

@@ -578,6 +578,11 @@ def loci_adjust(ds, *, group, thresh, interp) -> Dataset:
     """LOCI: adjust on one block (_adjustment.py:922-939); factors and thresholds of the group of each time step, "nearest"
     or linearly interpolated between group centres (the reference's default)."""
     sim, s2, gidx, G, cell_dims, cell_shape, dt = _prep_adjust(ds, group, "nearest")
+    if interp == "cubic" and G > 1 and set(as_dataarray(ds["af"]).dims) & set(sim.dims):
+        # utils.broadcast (utils.py:228-234): tables sharing a dimension with the series are interpolated linearly
+        warnings.warn("Broadcasting operations in multiple dimensions can only be done with linear and nearest-neighbor"
+                      " interpolation, not cubic. Using linear.", stacklevel=2)
+        interp = "linear"
     g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
