@@ -40,12 +40,7 @@ extern "C" int dt_host_eval_ct(int n, const double *px, const double *py, const 
     std::vector<int> ap(n + 1);
     std::vector<uint16_t> ai(6 * (size_t)n + 8), fill(n);
     xs::dt_adjacency(d, ap.data(), ai.data(), fill.data());
-    std::vector<double> qmat(3 * (size_t)n), g2(2 * (size_t)n);
-    const int iters = xs::dt_gradients(d, val, ap.data(), ai.data(), grad, qmat.data());
-    // the per-sweep form gives the very same numbers
-    if (xs::dt_gradients(d, val, ap.data(), ai.data(), g2.data()) != iters) return -1;
-    for (int i = 0; i < 2 * n; i++)
-        if (g2[i] != grad[i] && !(g2[i] != g2[i] && grad[i] != grad[i])) return -2;
+    const int iters = xs::dt_gradients(d, val, ap.data(), ai.data(), grad);
     int t = 0;
     for (int i = 0; i < nq; i++) {
         const int f = xs::dt_locate(d, qx[i], qy[i], t);

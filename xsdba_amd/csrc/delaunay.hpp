@@ -289,27 +289,12 @@ XS_HD void dt_adjacency(const Tri2D &d, int *adj_ptr, uint16_t *adj_idx, uint16_
         }
 }
 
-// Gauss-Seidel estimate of the nodal gradients grad[2 n] (interpnd._estimate_gradients_2d_global).  The 2 x 2 matrix of a
-// node depends on the geometry alone: with qmat [3 n] it is summed once (same terms, same order as in every sweep of the
-// original, so the sweeps — and the sweep at which they stop — are unchanged); qmat == nullptr recomputes it per sweep.
+// Gauss-Seidel estimate of the nodal gradients grad[2 n] (interpnd._estimate_gradients_2d_global)
 XS_HD int dt_gradients(const Tri2D &d, const double *val, const int *adj_ptr, const uint16_t *adj_idx, double *grad,
-                       double *qmat = nullptr, int maxiter = 400, double tol = 1e-6)
+                       int maxiter = 400, double tol = 1e-6)
 {
     const int n = d.n;
     for (int i = 0; i < 2 * n; i++) grad[i] = 0.0;
-    if (qmat)
-        for (int ip = 0; ip < n; ip++) {
-            double Q0 = 0.0, Q1 = 0.0, Q3 = 0.0;
-            for (int j = adj_ptr[ip]; j < adj_ptr[ip + 1]; j++) {
-                const int ip2 = adj_idx[j];
-                const double ex = d.px[ip2] - d.px[ip], ey = d.py[ip2] - d.py[ip];
-                const double L = sqrt(ex * ex + ey * ey), L3 = L * L * L;
-                Q0 += 4.0 * ex * ex / L3;
-                Q1 += 4.0 * ex * ey / L3;
-                Q3 += 4.0 * ey * ey / L3;
-            }
-            qmat[3 * ip] = Q0; qmat[3 * ip + 1] = Q1; qmat[3 * ip + 2] = Q3;
-        }
     for (int iter = 0; iter < maxiter; iter++) {
         double err = 0.0;
         for (int ip = 0; ip < n; ip++) {
@@ -322,15 +307,12 @@ XS_HD int dt_gradients(const Tri2D &d, const double *val, const int *adj_ptr, co
                 const double L = sqrt(ex * ex + ey * ey), L3 = L * L * L;
                 const double f2 = val[ip2];
                 const double df2 = -ex * grad[2 * ip2] - ey * grad[2 * ip2 + 1];
-                if (!qmat) {
-                    Q0 += 4.0 * ex * ex / L3;
-                    Q1 += 4.0 * ex * ey / L3;
-                    Q3 += 4.0 * ey * ey / L3;
-                }
+                Q0 += 4.0 * ex * ex / L3;
+                Q1 += 4.0 * ex * ey / L3;
+                Q3 += 4.0 * ey * ey / L3;
                 s0 += (6.0 * (f1 - f2) - 2.0 * df2) * ex / L3;
                 s1 += (6.0 * (f1 - f2) - 2.0 * df2) * ey / L3;
             }
-            if (qmat) { Q0 = qmat[3 * ip]; Q1 = qmat[3 * ip + 1]; Q3 = qmat[3 * ip + 2]; }
             const double det = Q0 * Q3 - Q1 * Q1;
             const double r0 = (Q3 * s0 - Q1 * s1) / det, r1 = (-Q1 * s0 + Q0 * s1) / det;
             double change = fmax(fabs(grad[2 * ip] + r0), fabs(grad[2 * ip + 1] + r1));

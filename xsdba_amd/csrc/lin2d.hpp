@@ -20,7 +20,7 @@ namespace xs {
 
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
-    size_t grad, adjp, adji, qmat;  // cubic only: nodal gradients (staged); vertex adjacency (CSR) and the nodes' 2 x 2 matrices (build only)
+    size_t grad, adjp, adji;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form (build only)
 };
 
 __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = false)
@@ -43,7 +43,6 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = f
     L.staged = o;
     L.hull = o; o += sizeof(uint16_t) * 4 * N;  // hull ring (3N) + insertion order (N): build only
     o = (o + 7) & ~(size_t)7;
-    L.qmat = o; if (cubic) o += sizeof(double) * 3 * N;
     L.adjp = o; if (cubic) o += sizeof(int) * (N + 2);
     L.adji = o; if (cubic) o += sizeof(uint16_t) * (6 * N + 8);
     L.total = (o + 15) & ~(size_t)15;
@@ -113,7 +112,7 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
         int *adjp = reinterpret_cast<int *>(base + L.adjp);
         uint16_t *adji = reinterpret_cast<uint16_t *>(base + L.adji);
         dt_adjacency(d, adjp, adji, d.hnext);
-        dt_gradients(d, pv, adjp, adji, reinterpret_cast<double *>(base + L.grad), reinterpret_cast<double *>(base + L.qmat));
+        dt_gradients(d, pv, adjp, adji, reinterpret_cast<double *>(base + L.grad));
     }
 }
 
