@@ -225,6 +225,12 @@ def main():
             "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
             "kernels": {k: {"count": v["count"], "avg_ms": round(v["total_ms"] / v["count"], 4)} for k, v in kern.items()},
         }
+        if dom.startswith("k_train") and W > 1:
+            # secondary figure of SURVEY §8d, NOT the roofline fraction: the bytes the reference's formulation of the same
+            # step touches (every element enters `window` group rows: 2*T*W*itemsize per cell), as a rate over the same launch
+            wb = C * 2 * T * W * 4
+            roof["windowed_bytes_equivalent"] = {"bytes_per_launch": wb, "GB/s": round(wb / (dom_avg_ms * 1e-3) / 1e9, 1),
+                                                 "note": "rows are never materialised: one sort per series + rank-space selection"}
         out = {
             "metric": "grid-cells/sec for EQM train+adjust, DOY-grouped, 30yr daily; 1/2/4/8 GPU",
             "value": round(value, 2), "unit": "grid-cells/s", "n_gpus": world, "steps": args.steps,
