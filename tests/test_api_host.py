@@ -179,3 +179,35 @@ def test_equally_spaced_nodes_and_corrections():
     assert u.invert(a, "+").values.tolist() == [-1.0, -2.0]
     with pytest.raises(ValueError):
         u.get_correction(a, b, "/")
+
+
+def test_broadcast_nearest_linear_cubic():
+    """utils.broadcast (utils.py:180-248) on a monthly table: 'nearest' picks the month, 'linear' / 'cubic' interpolate on
+    the table wrapped with its cyclic rows (xarray .interp = scipy interp1d); 'cubic' falls back to 'linear' with the
+    reference's warning as soon as the table shares a dimension with the series (:228-234)"""
+    from scipy.interpolate import interp1d
+
+    from xsdba_amd import utils as u
+
+    T = 2 * 365
+    t = xs.date_range("2000-01-01", T, "noleap")
+    x = DataArray(np.zeros(T), ("time",), {"time": t.values}, {"units": "K"})
+    tab = np.array([3.0, 2.5, 1.0, 0.2, -1.0, -2.5, -3.0, -2.0, -0.5, 0.8, 2.0, 2.8])
+    grouped = DataArray(tab, ("month",), {"month": np.arange(1, 13)})
+    gr = xs.Grouper("time.month")
+    near = u.broadcast(grouped, x, group=gr, interp="nearest").values
+    np.testing.assert_array_equal(near, tab[t.month - 1])
+    i = gr.get_index(x, interp=True).values
+    ext = np.concatenate([tab[-1:], tab, tab[:1]])
+    lin = u.broadcast(grouped, x, group=gr, interp="linear").values
+    np.testing.assert_allclose(lin, np.interp(i, np.arange(14.0), ext), rtol=1e-13)
+    cub = u.broadcast(grouped, x, group=gr, interp="cubic").values
+    np.testing.assert_allclose(cub, interp1d(np.arange(14.0), ext, kind="cubic")(i), rtol=1e-13)
+    assert np.abs(cub - lin).max() > 1e-3
+    # shared dimension: linear, with a warning
+    x2 = DataArray(np.zeros((2, T)), ("lat", "time"), {"time": t.values, "lat": [0, 1]}, {"units": "K"})
+    g2 = DataArray(np.stack([tab, 2 * tab]), ("lat", "month"), {"month": np.arange(1, 13), "lat": [0, 1]})
+    with pytest.warns(UserWarning, match="not cubic. Using linear"):
+        c2 = u.broadcast(g2, x2, group=gr, interp="cubic")
+    np.testing.assert_allclose(c2.values, u.broadcast(g2, x2, group=gr, interp="linear").values)
+    np.testing.assert_allclose(c2.values[1], 2 * lin, rtol=1e-13)

@@ -3,6 +3,8 @@
 labelled inputs/outputs."""
 from __future__ import annotations
 
+from warnings import warn
+
 import numpy as np
 
 from . import hip
@@ -158,13 +160,26 @@ def broadcast(grouped, x, *, group: str | Grouper = "time", interp: str = "neare
     group ("nearest") or the linear interpolation between the two neighbouring group centres on the cyclically extended
     table (a small host-side gather on the [.., group] table; the adjust kernels do the same on the device)."""
     grouped, x = as_dataarray(grouped), as_dataarray(x)
-    if interp not in ("nearest", "linear") and group.prop != "group":
-        raise NotImplementedError(f"broadcast(interp={interp!r}) is not implemented ('nearest' or 'linear')")
+    if interp not in ("nearest", "linear", "cubic"):
+        raise ValueError(f"interp must be 'nearest', 'linear' or 'cubic', got {interp!r}")
     if group.prop == "group":
         return grouped.squeeze("group") if "group" in grouped.dims else grouped
     gidx, G = group.group_index(x)
     ax = grouped.dims.index(group.prop)
-    if interp == "linear":
+    if interp == "cubic" and set(grouped.dims) & set(x.dims):  # utils.py:228-234
+        warn("Broadcasting operations in multiple dimensions can only be done with linear and nearest-neighbor"
+             " interpolation, not cubic. Using linear.", stacklevel=2)
+        interp = "linear"
+    if interp == "cubic":
+        # xarray's .interp(method="cubic") = scipy's interp1d(kind="cubic") through the table wrapped with its cyclic rows
+        from scipy.interpolate import interp1d
+
+        i = np.asarray(group.get_index(x, interp=True).values, np.float64)
+        c0 = 0 if group.prop == "season" else 1
+        ext = np.concatenate([np.take(grouped.values, [G - 1], axis=ax), grouped.values, np.take(grouped.values, [0], axis=ax)], axis=ax)
+        data = interp1d(np.arange(c0 - 1, c0 + G + 1, dtype=np.float64), ext.astype(np.float64), kind="cubic", axis=ax,
+                        bounds_error=False)(i).astype(grouped.values.dtype)
+    elif interp == "linear":
         i = np.asarray(group.get_index(x, interp=True).values, np.float64)
         c0 = 0 if group.prop == "season" else 1
         hi = np.ceil(i)
