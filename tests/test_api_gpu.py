@@ -307,6 +307,35 @@ def test_max_tail_factor(random, cls, group):
     assert "max_tail_factor=10" in adj.ds.attrs["adj_params"]
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_max_tail_factor_with_interpolated_groups(random, interp):
+    """_adjustment.py:648-658 with a grouped interp: the last raw hist quantile is broadcast between the month centres with the
+    same method (utils.broadcast; 'cubic' falls back to 'linear' there because the table shares `lat` with the series)"""
+    n = 6 * 365
+    t = xs.date_range("2000-01-01", n, "noleap").values
+    mk = lambda v: DataArray(v, ("time", "lat"), {"time": t, "lat": np.arange(2)}, {"units": "mm d-1"})  # noqa: E731
+    season = (1.5 + np.cos(2 * np.pi * (np.arange(n) % 365) / 365))[:, None]
+    ref, hist = mk(random.uniform(0.001, 20, (n, 2)) * season), mk(random.uniform(0.001, 10, (n, 2)) * season)
+    simv = random.uniform(0.001, 10, (n, 2)) * season
+    simv[::97] *= 4.0  # a good number of values around 2 x the largest hist quantile of their month
+    sim = mk(simv)
+    factor = 2.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plain = xs.EmpiricalQuantileMapping.train(ref, hist, kind="*", group="time.month").adjust(sim, interp=interp)
+        adj = xs.EmpiricalQuantileMapping.train(ref, hist, kind="*", group="time.month", max_tail_factor=factor)
+        got = adj.adjust(sim, interp=interp).transpose("time", "lat").values
+        thr = u.broadcast(adj.ds.hist_q_raw.isel(quantiles=-1), sim, group=xs.Grouper("time.month"), interp=interp)
+    thr = thr.transpose("time", "lat").values.astype(np.float32)
+    mask = simv.astype(np.float32) > np.float32(factor) * thr
+    assert 5 < mask.sum() < 0.2 * mask.size
+    near = simv > factor * adj.ds.hist_q_raw.isel(quantiles=-1).transpose("month", "lat").values[xs.date_range("2000-01-01", n, "noleap").month - 1]
+    assert (near != mask).any()  # the interpolated threshold decides differently from the month's own value somewhere
+    exp = np.where(mask, simv, plain.transpose("time", "lat").values)
+    edge = np.isclose(simv, factor * thr, rtol=1e-6)  # float32 rounding of the threshold may flip exact ties
+    np.testing.assert_array_equal(got[~edge], exp[~edge])
+
+
 def _cannon_2015_rvs(n, random=True, rng=None):
     """testing/helpers.py:23-35 (Cannon et al. 2015): ref ~ gamma(4, 7.5), hist ~ gamma(8.15, 3.68), sim ~ gamma(16, 2.63)"""
     from scipy.stats import gamma

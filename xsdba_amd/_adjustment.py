@@ -318,19 +318,22 @@ def _adapt_freq_sim(ds, sim, s2, gidx, G, cell_dims, group, dt, adapt_freq_thres
     return out[0]
 
 
-def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape=None):
+def _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape=None, sim=None, interp="nearest"):
     """mask no bias adjustment where sim is larger than n times the largest raw hist quantile (_adjustment.py:648-658,
-    672-673); the group broadcast of the reference is "nearest" for every grouping this path accepts"""
+    672-673).  The last raw quantile is broadcast on the time steps like the reference does (:650-657): the value of the
+    step's group ("nearest", and always on day-of-year groups), or interpolated between the group centres with ``interp``
+    — then the broadcast table is formed as a series on the device (0 + factor) and the mask runs with one "group" per
+    time step."""
     if max_tail_factor is None:
         return scen
     hq_raw = table_view(as_dataarray(ds["hist_q_raw"]), cell_dims, group.prop, cell_shape=cell_shape).astype(dt, copy=False)
-    return hip.tail_mask(s2, np.ascontiguousarray(scen), hq_raw, gidx if G > 1 else None, max_tail_factor)
-
-
-def _no_linear_tail_mask(group, max_tail_factor):
-    if max_tail_factor is not None and group.prop != "dayofyear":
-        raise NotImplementedError("max_tail_factor with a grouped interp='linear' is not implemented on the HIP path (the "
-                                  "reference then broadcasts the last raw quantile linearly between groups, _adjustment.py:650-657)")
+    if interp == "nearest" or G == 1 or group.prop == "dayofyear":
+        return hip.tail_mask(s2, np.ascontiguousarray(scen), hq_raw, gidx if G > 1 else None, max_tail_factor)
+    Cn, Tn = s2.shape
+    last = np.ascontiguousarray(hq_raw[:, :, -1])
+    thr = _broadcast_correct(group, sim, as_dataarray(ds["hist_q_raw"]), np.zeros((Cn, Tn), dt), last, gidx, G, "+", interp)
+    return hip.tail_mask(s2, np.ascontiguousarray(scen), np.ascontiguousarray(thr).reshape(Cn, Tn, 1),
+                         np.arange(Tn, dtype=np.int32), max_tail_factor)
 
 
 def _series_like(sim: DataArray, arr, cell_dims, cell_shape, dim, name, attrs=None):
@@ -348,12 +351,11 @@ def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None,
     if interp in ("linear", "cubic") and G > 1:
         # the reference's griddata path (utils.py:391-396): "linear" = piecewise-linear on the Delaunay triangulation of the
         # cell's table nodes, "cubic" = the Clough-Tocher interpolant on the same triangulation (csrc/lin2d.hpp)
-        _no_linear_tail_mask(group, max_tail_factor)
         gcoord, newg = _linear_group_coords(group, sim)
         scen = hip.qm_adjust_linear2d(s2, af, hq, gcoord, newg, extrapolation, kind, cubic=interp == "cubic")
     else:
         scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
 
 
@@ -424,7 +426,6 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
     elif interp in ("linear", "cubic") and G > 1:
         # the scaling is broadcast between the group centres with the same method, except on day-of-year groups (:748-757);
         # then fit / detrend / grouped-linear (or Clough-Tocher) mapping / retrend (:759-773) as separate device steps
-        _no_linear_tail_mask(group, max_tail_factor)
         if P > 1:
             raise NotImplementedError("dqm_adjust with `add_dims` and a grouped interp='linear' / 'cubic' is not implemented on the HIP path")
         scaled = _broadcast_correct(group, sim, as_dataarray(ds["scaling"]), s2, sc, gidx, G, kind,
@@ -437,7 +438,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
     else:
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "trend": _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")})
 
@@ -469,7 +470,6 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
         # the factors interpolated at (sim_q, fractional group) over the regular (quantile, group) grid (:873-881).  Every
         # cell of that grid is a cocircular quadruple: which diagonal splits it is the triangulator's choice (Qhull's in
         # the reference, the sweep's here), so the two agree exactly only where the four corner factors are coplanar.
-        _no_linear_tail_mask(group, max_tail_factor)
         if P > 1 and rank_window:
             raise NotImplementedError("qdm_adjust with `add_dims`, rank_window and a grouped interp='linear' / 'cubic' is not implemented on the HIP path")
         sim_q = hip.rank_groups(s2, gidx, G, group.window, bool(rank_window))
@@ -484,7 +484,7 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
         scen, sim_q = _unfold(scen, P, T), _unfold(sim_q, P, T)
     else:
         scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
-    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape)
+    scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
     return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
                     "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})
 
