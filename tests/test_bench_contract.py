@@ -1,0 +1,59 @@
+"""The bench line's contract, checked on the committed lines of the current round (profiles/r01_final*_bench.json, written by
+bench.py on the GPU box): the keys the driver reads, the metric of BASELINE.json, and the arithmetic that ties
+`roofline.achieved` to the algorithmic bytes and the dominant kernel's measured launch time."""
+from __future__ import annotations
+
+import importlib.util
+import json
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+LINES = sorted((ROOT / "profiles").glob("r01_final*_bench.json"))
+
+
+def _bench_module():
+    spec = importlib.util.spec_from_file_location("bench_contract", ROOT / "bench.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_lines_exist():
+    assert LINES, "no committed bench line of the current round under profiles/"
+
+
+@pytest.mark.parametrize("path", LINES, ids=lambda p: p.name)
+def test_bench_line_contract(path):
+    d = json.loads(path.read_text())
+    base = json.loads((ROOT / "BASELINE.json").read_text())
+    assert d["metric"] == base["metric"] and d["unit"] == "grid-cells/s"
+    for k in ("value", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "synthetic" in d["data"] and "workload" in d["config"] and "model" not in d["config"]
+    cells = d["config"]["cells_per_gpu"] * d["n_gpus"]
+    assert d["value"] == pytest.approx(cells / (d["ms_per_step"] * 1e-3), rel=1e-3)
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4)
+    assert r["achieved"] == pytest.approx(r["algorithmic_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9, rel=1e-4)
+    assert r["traffic"] is None or r["traffic"] >= 0.9 * r["algorithmic_bytes_per_launch"]
+    # the algorithmic bytes are SURVEY §8d's per-cell figure times the cells of one launch
+    b = _bench_module()
+    method = d["config"]["workload"].split(":")[0].split("_")[0]
+    tb, ab = b.algorithmic_bytes_per_cell(method, d["config"]["days"], d["config"]["groups"], 20)
+    per_cell = tb if r["kernel"].startswith("k_train") else ab
+    assert r["algorithmic_bytes_per_launch"] == per_cell * d["config"]["cells_per_gpu"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "grid-cells/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_algorithmic_bytes_match_the_survey():
+    b = _bench_module()
+    # cfg3-like EQM/DQM doy tables, T = 10950, G = 365, Q = 20
+    assert b.algorithmic_bytes_per_cell("eqm", 10950, 365, 20) == (146000, 146000)
+    assert b.algorithmic_bytes_per_cell("dqm", 10950, 365, 20) == (147460, 191260)
+    assert b.algorithmic_bytes_per_cell("qdm", 10950, 365, 20) == (146000, 116800)
+    assert b.algorithmic_bytes_per_cell("eqm", 10950, 12, 20) == (89520, 89520)
