@@ -174,8 +174,9 @@ def qm_adjust(sim, af, hist_q, gidx, interp="nearest", extrap="constant", kind="
 def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant", kind="+", trend=None, lookup=None, ctx=None,
                        cubic=False):
     """qm_adjust with grouped interp="linear" (utils._interp_on_quantiles_2d through scipy.griddata, utils.py:380-400) -> scen
-    [C, T]; ``cubic=True``: grouped interp="cubic" (griddata's Clough-Tocher interpolant, ``xsdba_hip_qm_adjust_cubic2d``).  ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the
-    fractional group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping.
+    [C, T]; ``cubic=True``: grouped interp="cubic" (griddata's Clough-Tocher interpolant, ``xsdba_hip_qm_adjust_cubic2d``).
+    ``group_coord`` [G + 2]: coordinates of the table rows wrapped with the cyclic ones; ``new_group`` [T]: the fractional
+    group coordinate of every time step; ``trend`` [C, T]: detrend before / retrend after the mapping.
     QDM form: ``hist_q`` a single row [Q] (the quantile nodes) and ``lookup`` [C, T] float64 (sim_q) to look up instead of sim."""
     ctx = ctx or default_context()
     s = _Series(sim)
