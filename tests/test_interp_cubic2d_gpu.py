@@ -204,3 +204,23 @@ def test_loci_cubic_falls_back_to_linear_on_a_grid():
     with pytest.warns(UserWarning, match="not cubic. Using linear"):
         cub = loci.adjust(cube(sim, dims, "mm/d"), interp="cubic").values
     np.testing.assert_array_equal(cub, lin)
+
+
+def test_loci_cubic_on_a_lone_series():
+    """LOCI.adjust(interp="cubic") without other dimensions (_adjustment.py:930-933): factor and threshold of every time step
+    from xarray's .interp(method="cubic") = scipy's interp1d(kind="cubic") through the tables wrapped with their cyclic rows"""
+    from scipy.interpolate import interp1d
+
+    rng = np.random.default_rng(40)
+    T = 4 * 365
+    ref, hist, sim = (np.abs(a[0] - 280).astype(np.float32) for a in gen(rng, 1, T))
+    dims = ("time",)
+    loci = xs.LOCI.train(cube(ref, dims, "mm/d"), cube(hist, dims, "mm/d"), group="time.month", thresh="1 mm/d")
+    got = loci.adjust(cube(sim, dims, "mm/d"), interp="cubic").values
+    i = xs.Grouper("time.month").get_index(cube(sim, dims), interp=True).values
+    w = lambda a: np.concatenate([a[-1:], a, a[:1]]).astype(np.float64)  # noqa: E731
+    fac = interp1d(np.arange(14.0), w(loci.ds.af.values), kind="cubic")(i).astype(np.float32)
+    sth = interp1d(np.arange(14.0), w(loci.ds.hist_thresh.values), kind="cubic")(i).astype(np.float32)
+    exp = np.clip(fac * (sim - sth) + np.float32(1), 0, None)
+    np.testing.assert_allclose(got, exp, rtol=3e-6, atol=1e-6)
+    assert np.abs(got - loci.adjust(cube(sim, dims, "mm/d"), interp="linear").values).max() > 1e-4

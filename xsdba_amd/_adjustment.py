@@ -528,6 +528,19 @@ def _group_interp_nodes(group: Grouper, sim: DataArray, gidx, G: int, interp: st
     return g_lo, g_hi, frac
 
 
+def _cubic_group_series(group: Grouper, sim: DataArray, tab, G: int):
+    """the [1, G] table of a lone series interpolated on its time steps like xarray's .interp(method="cubic") does inside
+    utils.broadcast (utils.py:222-246): scipy's interp1d(kind="cubic") through the G + 2 values of the table wrapped with
+    its cyclic rows, evaluated at Grouper.get_index(interp=True) -> [T] in the dtype of the table"""
+    from scipy.interpolate import interp1d
+
+    i = np.asarray(group.get_index(sim, interp=True).values, np.float64)
+    c0 = 0 if group.prop == "season" else 1  # coordinate of the first group
+    row = np.asarray(tab, np.float64).reshape(G)
+    ext = np.concatenate([row[-1:], row, row[:1]])
+    return interp1d(np.arange(c0 - 1, c0 + G + 1, dtype=np.float64), ext, kind="cubic", bounds_error=False)(i).astype(np.asarray(tab).dtype)
+
+
 def _broadcast_correct(group: Grouper, sim: DataArray, table: DataArray, s2, tab, gidx, G: int, kind: str, interp: str):
     """apply_correction(sim, utils.broadcast(table, sim, group=group, interp=interp), kind) (utils.py:180-248) -> [C, T].
     'nearest' / 'linear' between the group centres run in ``hip.scaling_adjust``.  'cubic': the reference falls back to
@@ -540,14 +553,7 @@ def _broadcast_correct(group: Grouper, sim: DataArray, table: DataArray, s2, tab
                       " interpolation, not cubic. Using linear.", stacklevel=2)
         interp = "linear"
     if interp == "cubic" and G > 1:
-        from scipy.interpolate import interp1d
-
-        i = np.asarray(group.get_index(sim, interp=True).values, np.float64)
-        c0 = 0 if group.prop == "season" else 1  # coordinate of the first group
-        row = np.asarray(tab, np.float64).reshape(G)
-        ext = np.concatenate([row[-1:], row, row[:1]])
-        fac = interp1d(np.arange(c0 - 1, c0 + G + 1, dtype=np.float64), ext, kind="cubic", bounds_error=False)(i)
-        return hip.series_correction(s2, fac.astype(np.asarray(tab).dtype), kind)
+        return hip.series_correction(s2, _cubic_group_series(group, sim, tab, G), kind)
     g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     return hip.scaling_adjust(s2, tab, g_lo if G > 1 else None, kind, g_hi=g_hi, frac=frac)
 
@@ -583,8 +589,15 @@ def loci_adjust(ds, *, group, thresh, interp) -> Dataset:
         warnings.warn("Broadcasting operations in multiple dimensions can only be done with linear and nearest-neighbor"
                       " interpolation, not cubic. Using linear.", stacklevel=2)
         interp = "linear"
-    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     af = table_view(as_dataarray(ds["af"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
     sth = table_view(as_dataarray(ds["hist_thresh"]), cell_dims, group.prop, last=None, cell_shape=cell_shape).astype(dt, copy=False)
+    if interp == "cubic" and G > 1:
+        # a lone series: factor and threshold of every time step from the cubic spline through the wrapped tables, handed to
+        # the kernel as tables with one "group" per time step
+        Tn = s2.shape[1]
+        scen = hip.loci_adjust(s2, _cubic_group_series(group, sim, af, G).reshape(1, Tn), _cubic_group_series(group, sim, sth, G).reshape(1, Tn),
+                               np.arange(Tn, dtype=np.int32), thresh)
+        return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
+    g_lo, g_hi, frac = _group_interp_nodes(group, sim, gidx, G, interp)
     scen = hip.loci_adjust(s2, af, sth, g_lo if G > 1 else None, thresh, g_hi=g_hi, frac=frac)
     return _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen").to_dataset()
