@@ -216,17 +216,21 @@ XS_HD int dt_locate(const Tri2D &d, double qx, double qy, int start)
     int t = start >= 0 && start < d.ntri ? start : 0;
     int from = -1;
     for (int steps = 0; steps < 2 * d.ntri + 8; steps++) {
+        // the three corners are fetched once per triangle (not once per edge test)
+        const int v[3] = {d.tv[3 * t], d.tv[3 * t + 1], d.tv[3 * t + 2]};
+        const double vx[3] = {d.px[v[0]], d.px[v[1]], d.px[v[2]]}, vy[3] = {d.py[v[0]], d.py[v[1]], d.py[v[2]]};
         int go = -1;
         bool moved = false;
+#pragma unroll
         for (int k = 0; k < 3; k++) {
-            const int a = d.tv[3 * t + (k + 1) % 3], b = d.tv[3 * t + (k + 2) % 3];
+            const int ia = (k + 1) % 3, ib = (k + 2) % 3;
             const int nb = d.tn[3 * t + k];
             if (nb == from && from >= 0) continue;
-            const double o = dt_orient_q(d, a, b, qx, qy);
+            const double o = (vx[ib] - vx[ia]) * (qy - vy[ia]) - (vy[ib] - vy[ia]) * (qx - vx[ia]);  // dt_orient_q(a, b, q)
             if (o < 0.0) {
                 if (nb == DT_NONE) {
                     // a hull edge: only a point clearly beyond it is outside (the tolerance is evaluated here alone)
-                    const double scale = (fabs(d.px[b] - d.px[a]) + fabs(d.py[b] - d.py[a])) * (fabs(qx - d.px[a]) + fabs(qy - d.py[a]) + 1.0);
+                    const double scale = (fabs(vx[ib] - vx[ia]) + fabs(vy[ib] - vy[ia])) * (fabs(qx - vx[ia]) + fabs(qy - vy[ia]) + 1.0);
                     if (o < -2.3e-14 * scale) return -1;
                     continue;
                 }
