@@ -22,6 +22,7 @@
 #include "qdm_cell.hpp"
 #include "train_long.hpp"
 #include "train_cell_f64.hpp"
+#include "train_select.hpp"
 #include "preproc.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
@@ -434,7 +435,45 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     };
     bool fast = false;
     if constexpr (std::is_same<R, float>::value) {
-        const char *force = getenv("XSDBA_HIP_TRAIN");  // "rows" pins the generic kernel (A/B runs, tests)
+        // un-windowed groups (group="time" / "time.month" / "time.season" ...): histogram multi-select, train_select.hpp.
+        // XSDBA_HIP_TRAIN=rows pins the generic kernel, =sort the per-cell sort kernels (A/B runs, tests).
+        const char *force = getenv("XSDBA_HIP_TRAIN");
+        const bool sel = (mode == 0 || mode == 1) && pl->W == 1 && pl->simple && G <= xs::SEL_MAXG &&
+                         (int64_t)G * (2 * Q + 1) <= xs::SEL_MAXTGT && T >= 64 && T <= 22 * 1024 &&
+                         !(force && (!strcmp(force, "rows") || !strcmp(force, "sort")));
+        if (sel) {
+            void *flags;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            auto go = [&](auto cfg) -> int {
+                constexpr int EPT2 = decltype(cfg)::value;
+                constexpr int TP = 2 * EPT2 * xs::SEL_NT;
+                // candidate slots: what two blocks per CU leave room for (at least 1024, at most 4096)
+                const size_t fixed = xs::sel_layout(TP, G, Q, 0).fixed_bytes;
+                const int64_t room = ((int64_t)ctx->lds_limit / 2 - (int64_t)fixed - 64) / 6;
+                const int cap = (int)std::max<int64_t>(1024, std::min<int64_t>(4096, room));
+                const size_t lds = xs::sel_layout(TP, G, Q, cap).bytes;
+                int rc2;
+                if ((rc2 = set_lds(xs::k_train_sel<EPT2>, lds, ctx, "the multi-select tables"))) return rc2;
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_limit / lds));
+                const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)per_cu * ctx->n_cu);  // blocks walk the cells grid-stride
+                LaunchScope ls(ctx, "k_train_sel");
+                hipLaunchKernelGGL((xs::k_train_sel<EPT2>), dim3(nblk), dim3(xs::SEL_NT), lds, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_gidx, G, (const float *)dq, Q, (int)kind, mode,
+                                   (float *)oaf.dev, (float *)ohq.dev, flag_count, flag_list, C, cap);
+                return check_launch("k_train_sel");
+            };
+            using std::integral_constant;
+            rc = T <= 2048 ? go(integral_constant<int, 2>{}) : T <= 4096 ? go(integral_constant<int, 4>{})
+               : T <= 8192 ? go(integral_constant<int, 8>{}) : T <= 11264 ? go(integral_constant<int, 11>{})
+               : T <= 16384 ? go(integral_constant<int, 16>{}) : go(integral_constant<int, 22>{});
+            if (rc) return rc;
+            // cells the select could not finish (long runs of unequal keys in one bin, candidate overflow): generic kernel
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
+            if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
+            return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
+        }
         fast = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
         if (fast) {
             void *flags;
