@@ -439,35 +439,38 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         // XSDBA_HIP_TRAIN=rows pins the generic kernel, =sort the per-cell sort kernels (A/B runs, tests).
         const char *force = getenv("XSDBA_HIP_TRAIN");
         const bool sel = (mode == 0 || mode == 1) && pl->W == 1 && pl->simple && G <= xs::SEL_MAXG &&
-                         (int64_t)G * (2 * Q + 1) <= xs::SEL_MAXTGT && T >= 64 && T <= 22 * 1024 &&
+                         (int64_t)G * Q <= 4096 && T >= 64 && T <= 22 * 1024 &&
                          !(force && (!strcmp(force, "rows") || !strcmp(force, "sort")));
         if (sel) {
             void *flags;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
-            auto go = [&](auto cfg) -> int {
-                constexpr int EPT2 = decltype(cfg)::value;
+            // histogram bins over all groups: 2^14 while two blocks per CU still fit in the LDS next to the scattered keys (the
+            // kernel lives on its 16 waves per CU), else 2^13
+            auto go = [&](auto cfg, auto lt) -> int {
+                constexpr int EPT2 = decltype(cfg)::value, LT = decltype(lt)::value;
                 constexpr int TP = 2 * EPT2 * xs::SEL_NT;
-                // candidate slots: what two blocks per CU leave room for (at least 1024, at most 4096)
-                const size_t fixed = xs::sel_layout(TP, G, Q, 0).fixed_bytes;
-                const int64_t room = ((int64_t)ctx->lds_limit / 2 - (int64_t)fixed - 64) / 6;
-                const int cap = (int)std::max<int64_t>(1024, std::min<int64_t>(4096, room));
-                const size_t lds = xs::sel_layout(TP, G, Q, cap).bytes;
+                const size_t lds = xs::sel_layout(TP, G, Q, LT).bytes;
                 int rc2;
-                if ((rc2 = set_lds(xs::k_train_sel<EPT2>, lds, ctx, "the multi-select tables"))) return rc2;
-                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_limit / lds));
+                if ((rc2 = set_lds(xs::k_train_sel<EPT2, LT>, lds, ctx, "the multi-select tables"))) return rc2;
+                const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(EPT2 <= 11 ? 2 : 1, (size_t)ctx->lds_limit / lds));
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)per_cu * ctx->n_cu);  // blocks walk the cells grid-stride
                 LaunchScope ls(ctx, "k_train_sel");
-                hipLaunchKernelGGL((xs::k_train_sel<EPT2>), dim3(nblk), dim3(xs::SEL_NT), lds, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_sel<EPT2, LT>), dim3(nblk), dim3(xs::SEL_NT), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_gidx, G, (const float *)dq, Q, (int)kind, mode,
-                                   (float *)oaf.dev, (float *)ohq.dev, flag_count, flag_list, C, cap);
+                                   (float *)oaf.dev, (float *)ohq.dev, flag_count, flag_list, C);
                 return check_launch("k_train_sel");
             };
             using std::integral_constant;
-            rc = T <= 2048 ? go(integral_constant<int, 2>{}) : T <= 4096 ? go(integral_constant<int, 4>{})
-               : T <= 8192 ? go(integral_constant<int, 8>{}) : T <= 11264 ? go(integral_constant<int, 11>{})
-               : T <= 16384 ? go(integral_constant<int, 16>{}) : go(integral_constant<int, 22>{});
+            auto pick = [&](auto cfg) -> int {
+                constexpr int TP = 2 * decltype(cfg)::value * xs::SEL_NT;
+                const bool fits14 = xs::sel_layout(TP, G, Q, 14).bytes <= (size_t)ctx->lds_limit / 2 || decltype(cfg)::value > 11;
+                return fits14 ? go(cfg, integral_constant<int, 14>{}) : go(cfg, integral_constant<int, 13>{});
+            };
+            rc = T <= 2048 ? pick(integral_constant<int, 2>{}) : T <= 4096 ? pick(integral_constant<int, 4>{})
+               : T <= 8192 ? pick(integral_constant<int, 8>{}) : T <= 11264 ? pick(integral_constant<int, 11>{})
+               : T <= 16384 ? pick(integral_constant<int, 16>{}) : pick(integral_constant<int, 22>{});
             if (rc) return rc;
             // cells the select could not finish (long runs of unequal keys in one bin, candidate overflow): generic kernel
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;

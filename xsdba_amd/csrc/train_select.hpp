@@ -1,70 +1,58 @@
 // train_select.hpp — training kernel for UN-WINDOWED groups (group="time", "time.month", "time.season", any grouping with
-// window == 1 and a few groups): histogram multi-select instead of a sort.
+// window == 1 and a few groups): a one-level bucket pass + selection inside the few buckets that matter, instead of a sort.
 //
 // The reference sorts every group row to read 2*Q order statistics off it (nbutils.py:113-148: arr.sort(), then the
-// neighbours of Q virtual indexes).  Only those 2*Q (+1: a[n-1] for the NaN rule) order statistics per group are needed,
-// so the kernel never sorts:
-//   A. the cell's series goes from HBM into REGISTERS (order-preserving keys, 2*EPT2 per thread), min / max / count;
-//   B. one counting pass: hist[group][bin] (packed u16 LDS atomics), bin = (key - kmin) >> shift over the occupied key
-//      range (equal-width bins in key space); the values equal to kmin or kmax are counted apart per group (zero-inflated
-//      precipitation, capped humidity: their bins would be long runs of equal keys);
-//   C. exclusive scan of every group's histogram (each thread 32 bins, block scan of the thread totals);
-//   D. every target ordinal (group, j) finds its bin by bisection on the scanned histogram; shift == 0 bins are exact
-//      values; otherwise the bin is marked and given a slice of a small candidate buffer;
-//   E. second pass over the registers: the elements of marked bins are appended to their bin's slice;
-//   F. every candidate ranks itself inside its slice (key, then slot: equal keys own distinct ranks), every target reads
-//      the candidate holding its residual rank;
-//   G. type-7 interpolation exactly as device_math.hpp::quantile_sorted, hist_q kept in LDS to form af in the ref pass
-//      (every output byte is written once, nothing is read back).
-// Exact and bit-identical to the sort-based kernels.  Bins that hold more than CAPBIN values are resolved only when all
-// their keys are equal (min/max atomics); cells where that fails or whose candidates overflow the buffer are appended to
-// flag_list and redone by the generic kernel.
+// neighbours of Q virtual indexes).  Only those order statistics are needed, so the kernel
+//   A. brings the cell's series from HBM into REGISTERS (order-preserving keys, 2*EPT2 per thread), min / max;
+//   B. counts: hist[group][bin] (packed u16 LDS atomics), bin = (key - kmin) >> shift over the occupied key range
+//      (equal-width bins in key space); the values equal to kmin or kmax are counted apart per group (zero-inflated
+//      precipitation, capped humidity: they would be long runs of equal keys inside one bin);
+//   C. scans the histogram into absolute start positions (each thread a run of bins, block scan of the thread totals);
+//   D. scatters every key to its bin's place in an LDS array (returning LDS atomics on the scanned entries, all requests
+//      of a thread in flight together): a counting sort by bin — keys inside a bin stay unordered;
+//   E. one thread per (group, quantile): the bin holding the ordinal by bisection on the table (which now holds the bins'
+//      END positions), the bin's keys sorted in registers (Batcher's network for up to 8 / 16 / 32 / 64 keys, an
+//      all-equal test beyond), the upper neighbour from the same bin or the minimum of the next one; type-7
+//      interpolation exactly as device_math.hpp::quantile_sorted; hist_q stays in LDS to form af in the ref pass.
+// Exact and bit-identical to the sort-based kernels: any monotone binning gives the same order statistics.  A bin with
+// more than CAPBIN keys that are not all equal cannot be resolved here: the cell is appended to flag_list and redone by
+// the generic kernel.  shift == 0 (few distinct keys) makes every bin one key: nothing to sort.
 // HBM traffic per cell = the series once + the tables once = the algorithmic bytes.
 #pragma once
 #include "train_cell.hpp"
 
+// timing aid for experiment builds only (-DXS_SEL_STOP=n stops every array pass after phase n: A=1 .. D=4); the release
+// library is built without it
+#ifndef XS_SEL_STOP
+#define XS_SEL_STOP 0
+#endif
+
 namespace xs {
 
 struct SelLayout {
-    int NT, TP, G, Q, NB, log2nb, NTG, NTGT, NTGTP, cap;
-    size_t off_hist, off_gc, off_pre, off_tkey, off_tbin, off_tr, off_tlead, off_tcnt, off_ltbase, off_ltcur, off_ltmin,
-        off_ltmax, off_ckey, off_cinfo, off_hq, off_gmass, off_red, fixed_bytes, bytes;
+    int NT, TP, G, Q, NB, log2nb;
+    size_t off_hist, off_skeys, off_pre, off_hq, off_gmass, off_red, bytes;
 };
 
-constexpr int SEL_NT = 512, SEL_LOG2TOT = 14, SEL_CAPBIN = 64, SEL_MAXG = 32, SEL_MAXTGT = 2048;
+constexpr int SEL_NT = 512, SEL_CAPBIN = 61, SEL_MAXG = 32;
 
-// LDS layout, shared by the host (sizing) and the kernel.  cap = candidate slots (6 B each).
-__host__ __device__ inline SelLayout sel_layout(int TP, int G, int Q, int cap)
+// LDS layout, shared by the host (sizing) and the kernel.  log2tot: log2 of the number of bins over all groups.
+__host__ __device__ inline SelLayout sel_layout(int TP, int G, int Q, int log2tot)
 {
     SelLayout L;
-    L.NT = SEL_NT; L.TP = TP; L.G = G; L.Q = Q; L.cap = cap;
+    L.NT = SEL_NT; L.TP = TP; L.G = G; L.Q = Q;
     int lg = 0;
     while ((1 << lg) < G) lg++;
-    L.log2nb = SEL_LOG2TOT - lg;
+    L.log2nb = log2tot - lg;
     L.NB = 1 << L.log2nb;
-    L.NTG = 2 * Q + 1;
-    L.NTGT = G * L.NTG;
-    L.NTGTP = ((L.NTGT + SEL_NT - 1) / SEL_NT) * SEL_NT;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = (o + bytes + 15) & ~(size_t)15; return r; };
     L.off_hist = take((size_t)G * L.NB * 2);
-    L.off_gc = take((size_t)TP);
+    L.off_skeys = take((size_t)TP * 4 + 256);  // (+256: slices are read in whole groups of four keys, up to 64 past a start)
     L.off_pre = take((size_t)(SEL_NT + 1) * 4);
-    L.off_tkey = take((size_t)L.NTGTP * 4);
-    L.off_tbin = take((size_t)L.NTGTP * 2);
-    L.off_tr = take((size_t)L.NTGTP * 2);
-    L.off_tlead = take((size_t)L.NTGTP * 2);
-    L.off_tcnt = take((size_t)L.NTGTP * 2);
-    L.off_ltbase = take((size_t)L.NTGTP * 2);
-    L.off_ltcur = take((size_t)L.NTGTP * 4);
-    L.off_ltmin = take((size_t)L.NTGTP * 4);
-    L.off_ltmax = take((size_t)L.NTGTP * 4);
     L.off_hq = take((size_t)G * Q * 4);
     L.off_gmass = take((size_t)2 * SEL_MAXG * 4);
     L.off_red = take(64 * 4);
-    L.fixed_bytes = o;
-    L.off_ckey = take((size_t)cap * 4);
-    L.off_cinfo = take((size_t)cap * 2);
     L.bytes = o;
     return L;
 }
@@ -96,48 +84,82 @@ __device__ __forceinline__ int sel_block_excl_scan(int v, uint32_t *red, int lan
     return woff + incl - v;
 }
 
+// Keys number rr and rr + 1 (0-based, ascending) among places [lead, mm) of the N keys at `sla` (16-byte aligned; a slice
+// starts anywhere, so it is read from its aligned base: the `lead` places in front of it belong to the previous bin and
+// count as 0 — they sort first, which is why rr includes them — and the places from mm on count as 0xFFFFFFFF).
+// Batcher's odd-even merge sorting network on registers, then a scan for the two places.  Equal keys are equal values,
+// so no tie rule is needed.
+template <int N> __device__ __forceinline__ void sel_sorted_pick2(const uint32_t *sla, int lead, int mm, int rr, uint32_t &k0, uint32_t &k1)
+{
+    uint32_t a[N];
+#pragma unroll
+    for (int i = 0; i < N / 4; i++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(sla + 4 * i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int p = 4 * i + u; a[p] = p < lead ? 0u : (p < mm ? w[u] : 0xFFFFFFFFu); }
+    }
+#pragma unroll
+    for (int p = 1; p < N; p *= 2)
+#pragma unroll
+        for (int k = p; k >= 1; k /= 2)
+#pragma unroll
+            for (int j = k % p; j <= N - 1 - k; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i <= (k - 1 < N - j - k - 1 ? k - 1 : N - j - k - 1); i++)
+                    if ((i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const uint32_t lo = min(a[i + j], a[i + j + k]), hi = max(a[i + j], a[i + j + k]);
+                        a[i + j] = lo;
+                        a[i + j + k] = hi;
+                    }
+    k0 = k1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        k0 = i == rr ? a[i] : k0;
+        k1 = i == rr + 1 ? a[i] : k1;
+    }
+}
+
 // mode 0: quantiles of x0 -> out_hq.  mode 1 (eqm_train): x1 = hist -> out_hq, x0 = ref -> af = corr(hist_q, ref_q).
-template <int EPT2>
-__global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc,
-                                                       const int *__restrict__ gidx, int G, const float *__restrict__ q, int Q, int kind,
-                                                       int mode, float *__restrict__ af, float *__restrict__ out_hq,
-                                                       int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C, int cap)
+// LT: log2 of the number of histogram bins over all groups (14: 32 KB of LDS)
+template <int EPT2, int LT>
+__global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
+    const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ gidx, int G,
+    const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *__restrict__ out_hq,
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C)
 {
     constexpr int NT = SEL_NT, NE = 2 * EPT2, TP = NE * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const SelLayout L = sel_layout(TP, G, Q, cap);
+    const SelLayout L = sel_layout(TP, G, Q, LT);
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L.off_hist);
     uint16_t *hist16 = reinterpret_cast<uint16_t *>(smem + L.off_hist);
-    uint8_t *gc = smem + L.off_gc;
+    uint32_t *skeys = reinterpret_cast<uint32_t *>(smem + L.off_skeys);
     uint32_t *pre = reinterpret_cast<uint32_t *>(smem + L.off_pre);
-    uint32_t *tkey = reinterpret_cast<uint32_t *>(smem + L.off_tkey);
-    uint16_t *tbin = reinterpret_cast<uint16_t *>(smem + L.off_tbin);
-    uint16_t *tr = reinterpret_cast<uint16_t *>(smem + L.off_tr);
-    uint16_t *tlead = reinterpret_cast<uint16_t *>(smem + L.off_tlead);
-    uint16_t *tcnt = reinterpret_cast<uint16_t *>(smem + L.off_tcnt);
-    uint16_t *ltbase = reinterpret_cast<uint16_t *>(smem + L.off_ltbase);
-    uint32_t *ltcur = reinterpret_cast<uint32_t *>(smem + L.off_ltcur);
-    uint32_t *ltmin = reinterpret_cast<uint32_t *>(smem + L.off_ltmin);
-    uint32_t *ltmax = reinterpret_cast<uint32_t *>(smem + L.off_ltmax);
-    uint32_t *ckey = reinterpret_cast<uint32_t *>(smem + L.off_ckey);
-    uint16_t *cinfo = reinterpret_cast<uint16_t *>(smem + L.off_cinfo);
     float *hqk = reinterpret_cast<float *>(smem + L.off_hq);
     uint32_t *gmass = reinterpret_cast<uint32_t *>(smem + L.off_gmass);  // [g][0: == kmin, 1: == kmax]
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + L.off_red);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int NB = L.NB, log2nb = L.log2nb, NTG = L.NTG, NTGT = L.NTGT, NTGTP = L.NTGTP;
-    const int ND = G * NB / 2;      // histogram dwords in use
-    const int tpg = NB >> 5;        // scan threads per group (32 bins each)
+    const int NB = L.NB, log2nb = L.log2nb;
+    const int ND = G * NB / 2;               // histogram dwords in use
+    constexpr int DPT = (1 << LT) / 2 / NT;  // histogram dwords per scan thread
+    const int tpg = NB / (2 * DPT);          // scan threads per group (2 * DPT bins each)
     const int Ti = (int)T;
     constexpr uint32_t MAXK = 0xFFFFFFFFu;
 
-    // the group of every time step, once per block (255: none)
-    for (int i = tid; i < TP; i += NT) {
+    // the group of each of the thread's elements, 8 bits per element (255: none), once per block: the same for every cell
+    uint32_t gpk[(NE + 3) / 4];
+    int ung = 0;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const int i = 2 * tid + (e >> 1) * 2 * NT + (e & 1);
         const int g = i < Ti ? gidx[i] : -1;
-        gc[i] = (uint8_t)((g >= 0 && g < G) ? g : 255);
+        const bool ok = g >= 0 && g < G;
+        const uint32_t g8 = ok ? (uint32_t)g : 255u;
+        if (e & 3) gpk[e >> 2] |= g8 << (8 * (e & 3)); else gpk[e >> 2] = g8;
+        ung |= (i < Ti && !ok) ? 1 : 0;
     }
-    __syncthreads();
+    const bool ungrouped = __syncthreads_or(ung) != 0;  // some time step belongs to no group
 
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         bool flag_cell = false;
@@ -150,25 +172,28 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(cons
             int t2 = 2 * tid;
             __asm__ volatile("" : "+v"(t2));
             uint32_t key[NE];
-            if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {
-                const int Te = Ti & ~1;
-                const float xlast = x[Ti - 1];
+            uint32_t kmin = MAXK, kmx1 = 0u;  // kmx1 = max(key + 1): a missing value (MAXK) wraps to 0 and never wins
+            // key of a value that is kept only when `keep` (three-operation sign fold: ~u for negatives, u | msb otherwise)
+            auto mkkey = [](float v, bool keep) {
+                const uint32_t u = __float_as_uint(v);
+                const uint32_t m = (uint32_t)((int32_t)u >> 31) | 0x80000000u;
+                return (v == v && keep) ? (u ^ m) : 0xFFFFFFFFu;
+            };
+            if ((reinterpret_cast<uintptr_t>(x) & 7) == 0 && (Ti & 1) == 0) {  // 8-byte aligned rows of even length
                 float2 v2[EPT2];
 #pragma unroll
                 for (int j = 0; j < EPT2; j++) {
                     const int i = t2 + j * 2 * NT;
-                    v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
+                    v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Ti - 2));
                 }
                 // the LDS tables are cleared while the loads are in flight
                 for (int i = tid; i < ND / 4; i += NT) reinterpret_cast<uint4 *>(hist)[i] = make_uint4(0u, 0u, 0u, 0u);
                 if (tid < 2 * G) gmass[tid] = 0u;
 #pragma unroll
                 for (int j = 0; j < EPT2; j++) {
-                    const int i = t2 + j * 2 * NT;
-                    float a = v2[j].x, b = v2[j].y;
-                    if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
-                    key[2 * j] = to_key(a);
-                    key[2 * j + 1] = to_key(b);
+                    const bool inr = t2 + j * 2 * NT < Ti;  // (pairs never straddle the end: both even)
+                    key[2 * j] = mkkey(v2[j].x, inr);
+                    key[2 * j + 1] = mkkey(v2[j].y, inr);
                 }
             } else {
                 float v[NE];
@@ -182,254 +207,203 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(cons
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
                     const int i = t2 + (e >> 1) * 2 * NT + (e & 1);
-                    key[e] = i < Ti ? to_key(v[e]) : MAXK;
+                    key[e] = mkkey(v[e], i < Ti);
                 }
             }
-            // the group of each element, 8 bits per element (time steps without a group count as missing)
-            uint32_t gpk[(NE + 3) / 4];
+            if (ungrouped) {  // (block-uniform) time steps without a group count as missing
+#pragma unroll
+                for (int e = 0; e < NE; e++)
+                    if (((gpk[e >> 2] >> (8 * (e & 3))) & 255u) == 255u) key[e] = MAXK;
+            }
 #pragma unroll
             for (int j = 0; j < EPT2; j++) {
-                const int i = t2 + j * 2 * NT;
-                const uint32_t g2 = *reinterpret_cast<const uint16_t *>(gc + i);
-                if (j & 1) gpk[j >> 1] |= g2 << 16; else gpk[j >> 1] = g2;
-            }
-            uint32_t kmin = MAXK, kmax = 0u;
-#pragma unroll
-            for (int e = 0; e < NE; e++) {
-                const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
-                if (g == 255u) key[e] = MAXK;
-                if (key[e] != MAXK) { kmin = min(kmin, key[e]); kmax = max(kmax, key[e]); }
+                kmin = min(kmin, min(key[2 * j], key[2 * j + 1]));
+                kmx1 = max(kmx1, max(key[2 * j] + 1u, key[2 * j + 1] + 1u));
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64));
+                kmx1 = max(kmx1, (uint32_t)__shfl_xor((int)kmx1, o, 64));
             }
-            if (lane == 0) { red[16 + 2 * wid] = kmin; red[16 + 2 * wid + 1] = kmax; }
+            if (lane == 0) { red[16 + 2 * wid] = kmin; red[16 + 2 * wid + 1] = kmx1; }
             __syncthreads();  // (also: tables cleared)
 #pragma unroll
-            for (int w = 0; w < NT / 64; w++) { kmin = min(kmin, red[16 + 2 * w]); kmax = max(kmax, red[16 + 2 * w + 1]); }
-            const bool any_valid = kmin != MAXK;
+            for (int w = 0; w < NT / 64; w++) { kmin = min(kmin, red[16 + 2 * w]); kmx1 = max(kmx1, red[16 + 2 * w + 1]); }
+            // (uniform values: kept in scalar registers)
+            kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmin);
+            kmx1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmx1);
+            const bool any_valid = kmx1 != 0u;
+            const uint32_t kmax = kmx1 - 1u;
             const uint32_t range = any_valid ? kmax - kmin : 0u;
             const int nbits = range ? 32 - __clz((int)range) : 0;
             const int shift = max(0, nbits - log2nb);
+            // an element lies strictly between the extremes <=> (key - kmin) - 1 < hi (unsigned: kmin itself wraps around,
+            // kmax and the missing values are >= hi)
+            const uint32_t hi = range ? range - 1u : 0u;
+            if (XS_SEL_STOP == 1) { if (kmin == 12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
             // ---------------- B. counting pass ----------------
+            // (the group bytes are made opaque per pass: what derives from them — table rows, counter addresses — is recomputed
+            //  here instead of being hoisted out of the cell loop and spilled)
 #pragma unroll
             for (int i = 0; i < (NE + 3) / 4; i++) __asm__ volatile("" : "+v"(gpk[i]));
 #pragma unroll
             for (int e = 0; e < NE; e++) {
-                uint32_t k = key[e];
-                __asm__ volatile("" : "+v"(k));
-                const int g = (int)((gpk[e >> 2] >> (8 * (e & 3))) & 255u);
+                __asm__ volatile("" : "+v"(key[e]));  // (nothing derived from the keys stays live from pass to pass)
+                const uint32_t k = key[e];
+                const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
                 const uint32_t rel = k - kmin;
-                const bool valid = k != MAXK;
-                const bool mass = valid && (rel == 0u || rel == range);
-                if (valid && !mass) {
-                    const uint32_t b = (uint32_t)(g << log2nb) + (rel >> shift);
-                    (void)__hip_atomic_fetch_add(&hist[b >> 1], 1u << (16u * (b & 1u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rel - 1u < hi) {
+                    const uint32_t b = (g << log2nb) + (rel >> shift);
+                    (void)__hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else if (k != MAXK) {
+                    // the extreme values (plain atomics: long runs of them serialise on one LDS word — about twice the time
+                    // of a run-free cell on zero-inflated data, still several times faster than sorting)
+                    (void)__hip_atomic_fetch_add(&gmass[2 * g + (rel != 0u ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                // (plain atomics: long runs of the extreme value serialise on one LDS word — twice the time of a
-                //  run-free cell on zero-inflated data, still several times faster than sorting)
-                if (mass) (void)__hip_atomic_fetch_add(&gmass[2 * g + (rel != 0u ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             __syncthreads();
+            if (XS_SEL_STOP == 2) { if (hist[tid] == 0x12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
-            // ---------------- C. exclusive scan of every group's histogram ----------------
+            // ---------------- C. the histogram -> absolute start positions (all groups end to end) ----------------
             {
-                uint32_t w[16];
-                const bool own = 16 * tid < ND;
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const uint4 v = own ? reinterpret_cast<const uint4 *>(hist)[4 * tid + d] : make_uint4(0u, 0u, 0u, 0u);
-                    w[4 * d] = v.x; w[4 * d + 1] = v.y; w[4 * d + 2] = v.z; w[4 * d + 3] = v.w;
-                }
+                // (the thread's run of bins is read twice — totals, then prefixes — rather than held in registers across the block scan)
+                const bool own = DPT * tid < ND;
                 uint32_t s2 = 0u;  // both halves summed at once (each half-sum <= T < 65536)
 #pragma unroll
-                for (int d = 0; d < 16; d++) s2 += w[d];
+                for (int d = 0; d < DPT / 4; d++) {
+                    const uint4 v = own ? reinterpret_cast<const uint4 *>(hist)[DPT / 4 * tid + d] : make_uint4(0u, 0u, 0u, 0u);
+                    s2 += v.x + v.y + v.z + v.w;
+                }
                 const int total = (int)(s2 & 0xFFFFu) + (int)(s2 >> 16);
                 int btot;
-                const int excl = sel_block_excl_scan(total, red, lane, wid, btot);
-                pre[tid] = (uint32_t)excl;
+                int run = sel_block_excl_scan(total, red, lane, wid, btot);
+                pre[tid] = (uint32_t)run;
                 if (tid == NT - 1) pre[NT] = (uint32_t)btot;
-                __syncthreads();
                 if (own) {
-                    const int gth = tid / tpg;
-                    int run = excl - (int)pre[gth * tpg];
 #pragma unroll
-                    for (int d = 0; d < 16; d++) {
-                        const int c0 = (int)(w[d] & 0xFFFFu), c1 = (int)(w[d] >> 16);
-                        w[d] = (uint32_t)run | ((uint32_t)(run + c0) << 16);
-                        run += c0 + c1;
+                    for (int d = 0; d < DPT / 4; d++) {
+                        uint4 v = reinterpret_cast<const uint4 *>(hist)[DPT / 4 * tid + d];
+                        auto step = [&](uint32_t &w) {
+                            const int c0 = (int)(w & 0xFFFFu), c1 = (int)(w >> 16);
+                            w = (uint32_t)run | ((uint32_t)(run + c0) << 16);
+                            run += c0 + c1;
+                        };
+                        step(v.x); step(v.y); step(v.z); step(v.w);
+                        reinterpret_cast<uint4 *>(hist)[DPT / 4 * tid + d] = v;
                     }
-#pragma unroll
-                    for (int d = 0; d < 4; d++)
-                        reinterpret_cast<uint4 *>(hist)[4 * tid + d] = make_uint4(w[4 * d], w[4 * d + 1], w[4 * d + 2], w[4 * d + 3]);
                 }
             }
             __syncthreads();
+            if (XS_SEL_STOP == 3) { if (hist[tid] == 0x12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
-            // ---------------- D. targets: ordinal -> bin (bisection on the scanned histogram) ----------------
-            for (int tt = tid; tt < NTGTP; tt += NT) {
-                uint32_t kres = MAXK;   // resolved key (MAXK: none / pending)
-                uint32_t bsel = 0xFFFFu;  // pending: the bin
-                int rres = 0, cres = 0;
-                if (tt < NTGT) {
-                    const int g = tt / NTG, j = tt - g * NTG;
-                    const int nh = (int)pre[(g + 1) * tpg] - (int)pre[g * tpg];
-                    const int nlo = (int)gmass[2 * g], nhi = (int)gmass[2 * g + 1];
-                    const int n = nlo + nh + nhi;
-                    if (n > 0) {
-                        int o;
-                        if (j == 2 * Q) o = n - 1;
-                        else {
-                            bool two;
-                            float gm;
-                            sel_ordinals(n, q[j >> 1], o, two, gm);
-                            if (two) o += j & 1;
-                        }
-                        if (o < nlo) kres = kmin;
-                        else if (o >= n - nhi) kres = kmax;
-                        else {
-                            const int oh = o - nlo;
-                            const uint16_t *ex = hist16 + ((size_t)g << log2nb);
-                            int b = 0;
-                            for (int s = NB >> 1; s > 0; s >>= 1) {
-                                const int cand = b + s;
-                                b = (int)ex[cand] <= oh ? cand : b;
-                            }
-                            const int eb = (int)ex[b];
-                            const int en = b + 1 < NB ? (int)ex[b + 1] : nh;
-                            if (shift == 0) kres = kmin + (uint32_t)b;  // one key per bin
-                            else { bsel = (uint32_t)b; rres = oh - eb; cres = en - eb; }
-                        }
-                    }
-                }
-                tkey[tt] = kres;
-                tbin[tt] = (uint16_t)bsel;
-                tr[tt] = (uint16_t)rres;
-                tcnt[tt] = (uint16_t)cres;
-            }
-            __syncthreads();
-            // every pending target claims its bin; the claim that survives names the bin's leader
-            for (int tt = tid; tt < NTGT; tt += NT) {
-                const uint32_t b = tbin[tt];
-                if (b != 0xFFFFu) hist16[((size_t)(tt / NTG) << log2nb) + b] = (uint16_t)(0x8000u | (uint32_t)tt);
-            }
-            __syncthreads();
-            int ctot = 0;  // candidate slots handed out so far
-            for (int t0 = 0; t0 < NTGTP; t0 += NT) {
-                const int tt = t0 + tid;
-                int need = 0;
-                bool leader = false, fat = false;
-                if (tt < NTGT) {
-                    const uint32_t b = tbin[tt];
-                    if (b != 0xFFFFu) {
-                        const int ld = (int)(hist16[((size_t)(tt / NTG) << log2nb) + b] & 0x7FFFu);
-                        tlead[tt] = (uint16_t)ld;
-                        leader = ld == tt;
-                        fat = (int)tcnt[tt] > SEL_CAPBIN;
-                        need = (leader && !fat) ? (int)tcnt[tt] : 0;
-                    }
-                }
-                int rtot;
-                const int base = ctot + sel_block_excl_scan(need, red, lane, wid, rtot);
-                ctot += rtot;
-                if (leader) {
-                    ltbase[tt] = fat ? (uint16_t)0xFFFFu : (uint16_t)min(base, 0xFFFE);
-                    ltcur[tt] = 0u;
-                    ltmin[tt] = MAXK;
-                    ltmax[tt] = 0u;
-                }
-            }
-            const bool overflow = ctot > cap || ctot > 0xFFF0;  // block-uniform
-            if (overflow) flag_cell = true;
-            __syncthreads();
-
-            // ---------------- E. second pass: the elements of marked bins -> candidate slices ----------------
-            if (shift != 0 && !overflow) {
-                // (the registers are made opaque: everything derived from them is recomputed here instead of being kept live —
-                //  spilled — from the counting pass on)
+            // ---------------- D. scatter: every key to its bin's place (counting sort by bin) ----------------
+            if (shift != 0) {  // (shift == 0: a bin is one key, the table alone answers)
+                uint32_t ret[NE];
 #pragma unroll
                 for (int i = 0; i < (NE + 3) / 4; i++) __asm__ volatile("" : "+v"(gpk[i]));
 #pragma unroll
                 for (int e = 0; e < NE; e++) {
-                    uint32_t k = key[e];
-                    __asm__ volatile("" : "+v"(k));
-                    const int g = (int)((gpk[e >> 2] >> (8 * (e & 3))) & 255u);
+                    __asm__ volatile("" : "+v"(key[e]));
+                    const uint32_t k = key[e];
+                    const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
                     const uint32_t rel = k - kmin;
-                    if (k != MAXK && rel != 0u && rel != range) {
-                        const uint32_t e16 = hist16[((size_t)g << log2nb) + (rel >> shift)];
-                        if (e16 & 0x8000u) {
-                            const int ld = (int)(e16 & 0x7FFFu);
-                            const uint32_t b0 = ltbase[ld];
-                            if (b0 == 0xFFFFu) {
-                                (void)__hip_atomic_fetch_min(&ltmin[ld], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                (void)__hip_atomic_fetch_max(&ltmax[ld], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ret[e] = 0xFFFFFFFFu;
+                    if (rel - 1u < hi) {
+                        const uint32_t b = (g << log2nb) + (rel >> shift);
+                        const uint32_t old = __hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        ret[e] = (old >> ((b << 4) & 31u)) & 0xFFFFu;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < NE; e++)
+                    if (ret[e] != 0xFFFFFFFFu) skeys[ret[e]] = key[e];
+            }
+            __syncthreads();
+            if (XS_SEL_STOP == 4) { if (skeys[tid] == 0x12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
+
+            // ---------------- E. one thread per (group, quantile): bin, selection inside it, interpolation, stores ----------
+            // The table now holds every bin's END position (shift != 0) or still its start (shift == 0).
+            for (int o = tid; o < G * Q; o += NT) {
+                const int g = o / Q, kq = o - g * Q;
+                const int gstart = (int)pre[g * tpg], gend = (int)pre[(g + 1) * tpg];
+                const int nlo = (int)gmass[2 * g], nhi = (int)gmass[2 * g + 1];
+                const int n = nlo + (gend - gstart) + nhi;
+                const uint16_t *tab = hist16 + ((size_t)g << log2nb);
+                // bin (index inside the group) whose keys hold absolute position pa
+                auto bin_of = [&](int pa) {
+                    int b = 0;
+                    if (shift != 0) {  // END positions: the first bin whose end exceeds pa
+                        for (int s = NB >> 1; s > 0; s >>= 1) b = (int)tab[b + s - 1] <= pa ? b + s : b;
+                    } else {           // start positions: the last bin that starts at or before pa
+                        for (int s = NB >> 1; s > 0; s >>= 1) b = (int)tab[b + s] <= pa ? b + s : b;
+                    }
+                    return b;
+                };
+                float res = __builtin_nanf("");
+                int o0 = 0;
+                bool two = false;
+                float gamma = 0.f;
+                if (n > 0) sel_ordinals(n, q[kq], o0, two, gamma);
+                // first the quantile's own neighbours; a second round only for the reference's NaN rule (inf - inf): a[n - 1]
+#pragma nounroll
+                for (int round = 0; round < 2 && n > 0; round++) {
+                    const int od = round == 0 ? o0 : n - 1;
+                    const bool tw = round == 0 && two;
+                    // ---- keys of ordinal od and, when tw, of od + 1
+                    uint32_t k0 = MAXK, k1 = MAXK;
+                    const int o1 = od + 1;
+                    if (od < nlo) k0 = kmin; else if (od >= n - nhi) k0 = kmax;
+                    if (tw) { if (o1 < nlo) k1 = kmin; else if (o1 >= n - nhi) k1 = kmax; }
+                    const bool need0 = od >= nlo && od < n - nhi, need1 = tw && o1 >= nlo && o1 < n - nhi;
+                    if (need0 || need1) {
+                        const int pa = gstart + ((need0 ? od : o1) - nlo);  // the first position that has to be read
+                        const int b = bin_of(pa);
+                        if (shift == 0) {
+                            const uint32_t kb = kmin + (uint32_t)b;
+                            if (need0) { k0 = kb; if (need1) k1 = kmin + (uint32_t)bin_of(pa + 1); }
+                            else k1 = kb;
+                        } else {
+                            const int s0 = b > 0 ? (int)tab[b - 1] : gstart, e0 = (int)tab[b];
+                            const int m = e0 - s0, r = pa - s0;
+                            uint32_t a0 = MAXK, a1 = MAXK;
+                            if (m <= SEL_CAPBIN) {
+                                const int sa = s0 & ~3, lead = s0 - sa, mm = m + lead, rr = r + lead;
+                                const uint32_t *sla = skeys + sa;
+                                if (mm <= 8) sel_sorted_pick2<8>(sla, lead, mm, rr, a0, a1);
+                                else if (mm <= 16) sel_sorted_pick2<16>(sla, lead, mm, rr, a0, a1);
+                                else if (mm <= 32) sel_sorted_pick2<32>(sla, lead, mm, rr, a0, a1);
+                                else sel_sorted_pick2<64>(sla, lead, mm, rr, a0, a1);
                             } else {
-                                const uint32_t s = b0 + __hip_atomic_fetch_add(&ltcur[ld], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                ckey[s] = k;
-                                cinfo[s] = (uint16_t)ld;
+                                // a long run: resolved only when it is one value
+                                uint32_t mn = MAXK, mx = 0u;
+                                for (int i = 0; i < m; i++) { const uint32_t kj = skeys[s0 + i]; mn = min(mn, kj); mx = max(mx, kj); }
+                                if (mn == mx) a0 = a1 = mn; else flag_cell = true;
                             }
+                            if (need0) {
+                                k0 = a0;
+                                if (need1) {
+                                    if (r + 1 < m) k1 = a1;
+                                    else {  // the minimum of the next bin that holds anything
+                                        int b1 = b + 1;
+                                        while (b1 < NB - 1 && (int)tab[b1] == e0) b1++;
+                                        const int e1 = (int)tab[b1];
+                                        uint32_t mn = MAXK;
+                                        for (int i = e0; i < e1; i++) mn = min(mn, skeys[i]);
+                                        k1 = mn;
+                                    }
+                                }
+                            } else k1 = a0;  // (od itself was an extreme value: position pa is od + 1)
                         }
                     }
-                }
-            }
-            __syncthreads();
-            // ---------------- F. candidates rank themselves inside their slice; targets pick theirs ----------------
-            if (shift != 0 && !overflow) {
-                for (int s = tid; s < ctot; s += NT) {
-                    const int ld = (int)cinfo[s];
-                    const int b0 = (int)ltbase[ld], m = (int)ltcur[ld];
-                    const uint32_t k = ckey[s];
-                    int rk = 0;
-                    for (int i = 0; i < m; i++) {
-                        const uint32_t ki = ckey[b0 + i];
-                        rk += (ki < k || (ki == k && b0 + i < s)) ? 1 : 0;
-                    }
-                    cinfo[s] = (uint16_t)rk;
-                }
-            }
-            __syncthreads();
-            if (shift != 0 && !overflow) {
-                for (int tt = tid; tt < NTGT; tt += NT) {
-                    if (tbin[tt] == 0xFFFFu) continue;
-                    const int ld = (int)tlead[tt];
-                    const int b0 = (int)ltbase[ld];
-                    uint32_t k = MAXK;
-                    if (b0 == 0xFFFF) {
-                        if (ltmin[ld] == ltmax[ld]) k = ltmin[ld];  // a long run of one value
-                        else flag_cell = true;
-                    } else {
-                        const int m = (int)ltcur[ld], r = (int)tr[tt];
-                        for (int i = 0; i < m; i++) k = (int)cinfo[b0 + i] == r ? ckey[b0 + i] : k;
-                        if (k == MAXK) flag_cell = true;  // (cannot happen: the slice holds the whole bin)
-                    }
-                    tkey[tt] = k;
-                }
-            }
-            __syncthreads();
-
-            // ---------------- G. interpolation, factors, stores ----------------
-            for (int o = tid; o < G * Q; o += NT) {
-                const int g = o / Q, k = o - g * Q;
-                const int nh = (int)pre[(g + 1) * tpg] - (int)pre[g * tpg];
-                const int n = nh + (int)gmass[2 * g] + (int)gmass[2 * g + 1];
-                float res = __builtin_nanf("");
-                if (n > 0) {
-                    int o0;
-                    bool two;
-                    float gamma;
-                    sel_ordinals(n, q[k], o0, two, gamma);
-                    const float v0 = from_key(tkey[g * NTG + 2 * k]), v1 = from_key(tkey[g * NTG + 2 * k + 1]);
-                    // device_math.hpp::quantile_sorted with a(o0) = v0, a(o0 + 1) = v1, a(n - 1) = the group's maximum
-                    if (!two) res = v0;
-                    else {
-                        const float diff = v1 - v0;
-                        if (gamma >= 0.5f) res = (float)((double)v1 - (double)diff * (1.0 - (double)gamma));
-                        else res = v0 + diff * gamma;
-                        if (res != res) res = from_key(tkey[g * NTG + 2 * Q]);
-                    }
+                    // ---- device_math.hpp::quantile_sorted with a(o0) = k0, a(o0 + 1) = k1
+                    const float v0 = from_key(k0), v1 = from_key(k1);
+                    if (round == 1) { res = v0; break; }
+                    if (!two) { res = v0; break; }
+                    const float diff = v1 - v0;
+                    if (gamma >= 0.5f) res = (float)((double)v1 - (double)diff * (1.0 - (double)gamma));
+                    else res = v0 + diff * gamma;
+                    if (res == res) break;
                 }
                 const size_t oo = (size_t)c * G * Q + o;
                 if (mode == 0) out_hq[oo] = res;
