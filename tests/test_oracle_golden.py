@@ -154,7 +154,7 @@ def test_pipeline_qdm_adjust(golden, name):
             assert_close(sim_q, d[f"qdm_simq_rw{rw}"], rtol=0.0, atol=0.0, what=f"sim_q rw{rw}")
             if G > 1:  # sim_q = k/(N-1) can sit exactly midway between two float32 nodes: cKDTree tie
                 assert_close_or_tie(scen, d[key], d["sim"], d["q"], d["eqm_af"], gidx, kind, 1e-6, what=key,
-                                    newx=sim_q)
+                                    newx=sim_q, max_frac=5e-3)
             else:
                 assert_close(scen, d[key], rtol=1e-6, what=key)
 

@@ -1,28 +1,49 @@
-"""Global / contextual options (xsdba.options, options.py:13-83): ``set_options(extra_output=bool)``."""
+"""Package-wide switches of the drop-in API: the same names and behaviour as ``xsdba.set_options`` (reference
+options.py:13-83) so that callers' code keeps working — ``with set_options(extra_output=True): ...`` or the plain call for a
+lasting change.
+
+Each switch is described by one ``_Switch`` record (default value + accepted type); ``OPTIONS`` is the live mapping the rest
+of the package reads (``OPTIONS[EXTRA_OUTPUT]``).
+"""
 from __future__ import annotations
 
-EXTRA_OUTPUT = "extra_output"
-AS_DATASET = "as_dataset"
+from dataclasses import dataclass
 
-OPTIONS = {EXTRA_OUTPUT: False, AS_DATASET: False}
-_VALIDATORS = {EXTRA_OUTPUT: lambda opt: isinstance(opt, bool), AS_DATASET: lambda opt: isinstance(opt, bool)}
+EXTRA_OUTPUT = "extra_output"  # adjust() returns a Dataset with the diagnostics next to scen
+AS_DATASET = "as_dataset"      # always wrap results in a Dataset
+
+
+@dataclass(frozen=True)
+class _Switch:
+    default: object
+    kind: type
+
+    def accepts(self, value) -> bool:
+        # bool is the only kind in use; a bool subclass check keeps 0 / 1 out, like the reference's isinstance test
+        return isinstance(value, self.kind)
+
+
+_SWITCHES = {EXTRA_OUTPUT: _Switch(False, bool), AS_DATASET: _Switch(False, bool)}
+
+OPTIONS = {name: sw.default for name, sw in _SWITCHES.items()}
 
 
 class set_options:
-    """Set options in a controlled context (or globally when not used as a context manager)."""
+    """Change switches now; used as a context manager, put the previous values back on exit."""
 
-    def __init__(self, **kwargs):
-        self.old = {}
-        for k, v in kwargs.items():
-            if k not in OPTIONS:
-                raise ValueError(f"Argument name {k!r} is not in the set of valid options {set(OPTIONS)!r}.")
-            if k in _VALIDATORS and not _VALIDATORS[k](v):
-                raise ValueError(f"option {k!r} given an invalid value: {v!r}")
-            self.old[k] = OPTIONS[k]
-        OPTIONS.update(kwargs)
+    def __init__(self, **changes):
+        unknown = [name for name in changes if name not in _SWITCHES]
+        if unknown:
+            raise ValueError(f"Argument name {unknown[0]!r} is not in the set of valid options {set(OPTIONS)!r}.")
+        for name, value in changes.items():
+            if not _SWITCHES[name].accepts(value):
+                raise ValueError(f"option {name!r} given an invalid value: {value!r}")
+        self.old = {name: OPTIONS[name] for name in changes}
+        OPTIONS.update(changes)
 
     def __enter__(self):
-        return
+        return None
 
-    def __exit__(self, option_type, value, traceback):
+    def __exit__(self, exc_type, exc, tb):
         OPTIONS.update(self.old)
+        return False
