@@ -79,7 +79,7 @@ def load_reference():
     nbu = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(nbu)
 
-    wanted = {"_interp_on_quantiles_1D", "_interp_on_quantiles_2d", "equally_spaced_nodes"}
+    wanted = {"_interp_on_quantiles_1D", "_interp_on_quantiles_2d", "equally_spaced_nodes", "_ecdf_1d", "map_cdf_1d"}
     tree = ast.parse((REF / "utils.py").read_text())
     ns = {
         "np": np,
@@ -565,6 +565,209 @@ def gen_known_answers(rng):
     return 1
 
 
+# --------------------------------------------------------------------------------------
+# round 2: the rows of the hot path's neighbourhood that had no reference-generated vector
+# --------------------------------------------------------------------------------------
+def month_fractional_index(T, start_doy0=0):
+    """Grouper.get_index(interp=True) for time.month on a noleap axis (base.py:308-309):
+    month - 0.5 + day / days_in_month."""
+    _, month, day, _ = noleap_fields(T, start_doy0)
+    return month - 0.5 + day / _DPM[month - 1]
+
+
+def broadcast_linear(tab, i):
+    """utils.broadcast(grouped, x, interp="linear") for a month table (utils.py:222-246): cyclic bounds without cyclic
+    coordinates (months 0 and 13, :284-314), then DataArray.interp(method="linear") = numpy.interp per cell in float64,
+    cast back to the table dtype (:243)."""
+    C, G = tab.shape
+    ext = np.concatenate([tab[:, -1:], tab, tab[:, :1]], axis=1)
+    xp = np.arange(0, G + 2, dtype=np.float64)
+    out = np.empty((C, i.size), tab.dtype)
+    for c in range(C):
+        out[c] = np.interp(i, xp, ext[c].astype(np.float64)).astype(tab.dtype)
+    return out
+
+
+def group_nanmean(x, gidx, G, W):
+    """Grouper.apply("mean", x, skipna=True) (base.py:347-457 with a string func): mean over (time, window) of every
+    group block, in the data dtype (xarray -> numpy nanmean)."""
+    rows = group_rows(x, gidx, G, W)
+    out = np.empty((x.shape[0], G), x.dtype)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        for g in range(G):
+            out[:, g] = np.nanmean(rows[g], axis=-1)
+    return out
+
+
+def scaling_train(ref, hist, gidx, G, W, kind):  # _adjustment.py:941-958
+    return get_correction(group_nanmean(hist, gidx, G, W), group_nanmean(ref, gidx, G, W), kind)
+
+
+def loci_train(ref, hist, gidx, G, W, thresh):  # _adjustment.py:889-914
+    C = ref.shape[0]
+    rr, hh = group_rows(ref, gidx, G, W), group_rows(hist, gidx, G, W)
+    s_thresh = np.empty((C, G), hist.dtype)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        for g in range(G):
+            for c in range(C):
+                # group.apply(u.map_cdf, {x: hist, y: ref}, y_value=thresh).isel(x=0); output_dtypes=[x.dtype] (utils.py:74-84)
+                s_thresh[c, g] = UT["map_cdf_1d"](hh[g][c], rr[g][c], np.atleast_1d(thresh))[0]
+        sth = s_thresh[:, gidx]                                   # u.broadcast(s_thresh, hist, group) — nearest
+        ws = np.where(hist >= sth, hist, np.nan).astype(hist.dtype)
+        wo = np.where(ref >= thresh, ref, np.nan).astype(ref.dtype)
+        ms, mo = group_nanmean(ws, gidx, G, W), group_nanmean(wo, gidx, G, W)
+        af = get_correction(ms - s_thresh, mo - thresh, "*")
+    return af.astype(ref.dtype), s_thresh
+
+
+def loci_adjust(sim, af_t, sth_t, thresh):  # _adjustment.py:917-938 with the tables already broadcast on time
+    with np.errstate(all="ignore"):
+        return np.clip(af_t * (sim - sth_t) + thresh, 0, None).astype(sim.dtype)
+
+
+def gen_families(rng):
+    """Scaling, LOCI and the max_tail_factor mask (_adjustment.py:889-974, 648-658, 672-673)."""
+    d = {}
+    T, C = 3650, 3
+    doy, month, _, _ = noleap_fields(T)
+    imon = month_fractional_index(T)
+    d["month_index_interp"] = imon
+    q20 = UT["equally_spaced_nodes"](20).astype(np.float32)
+    for gname, gidx, G, W in (("month", month - 1, 12, 1), ("doy31", doy - 1, 365, 31), ("time", np.zeros(T, np.int64), 1, 1)):
+        d[f"{gname}_gidx"] = gidx.astype(np.int32)
+        d[f"{gname}_GW"] = np.array([G, W])
+        for kind, tag in (("+", "add"), ("*", "mul")):
+            ref, hist, sim = synth_temperature(rng, C, T) if kind == "+" else synth_precip(rng, C, T)
+            for a in (ref, hist, sim):
+                a[1, rng.random(T) < 0.01] = np.nan
+            k = f"{gname}_{tag}"
+            d[f"{k}_ref"], d[f"{k}_hist"], d[f"{k}_sim"] = ref, hist, sim
+            # --- Scaling
+            af = scaling_train(ref, hist, gidx, G, W, kind)
+            d[f"{k}_scaling_af"] = af
+            with np.errstate(all="ignore"):
+                d[f"{k}_scaling_scen_nearest"] = apply_correction(sim, af[:, gidx], kind).astype(sim.dtype)
+                if gname == "month":
+                    d[f"{k}_scaling_scen_linear"] = apply_correction(sim, broadcast_linear(af, imon), kind).astype(sim.dtype)
+            # --- max_tail_factor mask on an EQM adjustment (hist_q_raw = hist_q without adapt_freq, _adjustment.py:262-270)
+            if gname != "time":
+                eaf, ehq = eqm_train(ref, hist, gidx, G, W, q20, kind)
+                newg = (gidx + 1).astype(np.int64)
+                with np.errstate(all="ignore"):
+                    scen = qm_adjust(sim, eaf, ehq, newg, G, "nearest", "constant", kind)
+                d[f"{k}_eqm_hist_q"], d[f"{k}_eqm_scen"] = ehq, scen
+                for f in (1.0, 1.02):
+                    last = ehq[:, :, -1][:, gidx]  # broadcast(last_quantile, sim, group, "nearest")
+                    with np.errstate(all="ignore"):
+                        mask = sim > np.float32(f) * last if sim.dtype == np.float32 else sim > f * last
+                    d[f"{k}_tailmask_{f}"] = np.where(mask, sim, scen).astype(sim.dtype)
+            # --- LOCI (multiplicative data only: a wet-day threshold)
+            if kind == "*":
+                thresh = 12.0
+                laf, lth = loci_train(ref, hist, gidx, G, W, thresh)
+                d[f"{k}_loci_af"], d[f"{k}_loci_hist_thresh"], d[f"{k}_loci_thresh"] = laf, lth, np.array(thresh)
+                d[f"{k}_loci_scen_nearest"] = loci_adjust(sim, laf[:, gidx], lth[:, gidx], thresh)
+                if gname == "month":
+                    d[f"{k}_loci_scen_linear"] = loci_adjust(sim, broadcast_linear(laf, imon), broadcast_linear(lth, imon), thresh)
+    np.savez_compressed(OUT / "families_scaling_loci_tail.npz", **d)
+    return len(d)
+
+
+def gen_vecquantiles(rng):
+    """nbutils._vecquantiles (nbutils.py:151-161), run through the stub guvectorize: res[0] = np.nanquantile(arr, rnk)."""
+    d = {}
+    i = 0
+    for dt in (np.float32, np.float64):
+        for L in (1, 2, 3, 30, 930):
+            a = (rng.standard_normal((12, L)) * 8 + 280).astype(dt)
+            a[rng.random(a.shape) < 0.1] = np.nan
+            a[3] = np.nan
+            rnk = rng.random(12).astype(dt)
+            rnk[0], rnk[1], rnk[2] = 0.0, 1.0, np.nan
+            out = np.empty(12, dt)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for r in range(12):
+                    res = np.empty(1, dt)
+                    NBU._vecquantiles(a[r], rnk[r], res)
+                    out[r] = res[0]
+            d[f"arr_{i}"], d[f"rnk_{i}"], d[f"out_{i}"] = a, rnk, out
+            i += 1
+    d["n"] = np.array(i)
+    np.savez_compressed(OUT / "vecquantiles.npz", **d)
+    return i
+
+
+def gen_interp_2d_fractional(rng):
+    """_interp_on_quantiles_2d (utils.py:380-400) with the FRACTIONAL group coordinate of Grouper.get_index(interp=True)
+    (base.py:308-309) on monthly tables — what interp="linear" / "cubic" hand to griddata (utils.py:476-513)."""
+    d = {}
+    i = 0
+    T = 730
+    _, month, _, _ = noleap_fields(T)
+    newg = month_fractional_index(T)
+    q = UT["equally_spaced_nodes"](20).astype(np.float32)
+    for name, data in (("tas", synth_temperature(rng, 2, 3650)), ("pr", synth_precip(rng, 2, 3650))):
+        ref, hist, sim = data
+        kind = "*" if name == "pr" else "+"
+        _, month_l, _, _ = noleap_fields(3650)
+        af, hq = eqm_train(ref, hist, month_l - 1, 12, 1, q, kind)
+        if name == "tas":  # holes in the table
+            hq, af = hq.copy(), af.copy()
+            hq[1, 3, 5] = np.nan
+            af[1, 7, 0] = np.nan
+        sim = sim[:, :T].copy()
+        sim[0, rng.random(T) < 0.02] = np.nan
+        for method in ("nearest", "linear", "cubic"):
+            for extrap in ("constant", "nan"):
+                o = interp_on_quantiles(sim, hq, af, newg, 12, method, extrap)
+                d[f"sim_{i}"], d[f"hq_{i}"], d[f"af_{i}"], d[f"newg_{i}"] = sim, hq, af, newg
+                d[f"method_{i}"], d[f"extrap_{i}"], d[f"out_{i}"] = np.array(method), np.array(extrap), o
+                i += 1
+    d["n"] = np.array(i)
+    np.savez_compressed(OUT / "interp_2d_fractional.npz", **d)
+    return i
+
+
+def gen_window_handcase():
+    """The reference's own Grouper.apply expectation (tests/test_base.py:76-120): x = arange(366) on 2000-01-01.. (a leap
+    year, standard calendar), group time.month, plain and with window=5: rolling(center=True).construct + groupby mean over
+    (time, window).  Written with explicit loops over real dates — independent of rolling_construct / group_rows above and
+    of the oracle's row gathering — so that the window / group bookkeeping itself has a hand-checkable vector:
+    January without a window is mean(0..30) = 15."""
+    import datetime
+
+    start = datetime.date(2000, 1, 1)
+    dates = [start + datetime.timedelta(days=k) for k in range(366)]
+    x = np.arange(366, dtype=np.float64)
+    month0 = np.array([dt.month - 1 for dt in dates], np.int32)
+    plain = np.zeros(12)
+    win5 = np.zeros(12)
+    for m in range(12):
+        ts = [k for k in range(366) if month0[k] == m]
+        plain[m] = sum(x[k] for k in ts) / len(ts)
+        vals = [x[k + o] for k in ts for o in (-2, -1, 0, 1, 2) if 0 <= k + o < 366]
+        win5[m] = sum(vals) / len(vals)
+    assert plain[0] == 15.0 and plain[1] == 45.0  # January: days 0..30, February 2000: days 31..59
+    d = dict(x=x, gidx=month0, plain=plain, win5=win5)
+    # the same series, day-of-year groups with window 5 (test_base.py:31-44: every group holds one centre x 5 slots)
+    doy0 = np.arange(366, dtype=np.int32)
+    d["doy_gidx"] = doy0
+    d["doy_win5"] = np.array([np.mean([x[k + o] for o in (-2, -1, 0, 1, 2) if 0 <= k + o < 366]) for k in range(366)])
+    np.savez_compressed(OUT / "window_groups_handcase.npz", **d)
+    return 1
+
+
+def main_round2():
+    rng = np.random.default_rng(20260202)
+    print("families:", gen_families(rng))
+    print("vecquantiles:", gen_vecquantiles(rng))
+    print("interp_2d fractional:", gen_interp_2d_fractional(rng))
+    print("window handcase:", gen_window_handcase())
+
+
 def main():
     rng = np.random.default_rng(20260101)
     print("quantile_1d cases:", gen_quantiles(rng))
@@ -576,4 +779,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # `make_golden.py` regenerates the round-1 files, `make_golden.py round2` the files added in round 2 (own seed, so that
+    # neither run disturbs the other's vectors)
+    if len(sys.argv) > 1 and sys.argv[1] == "round2":
+        main_round2()
+    else:
+        main()

@@ -256,3 +256,102 @@ def test_oracle_adapt_freq_reference_assertions():
     # adjust branch with the trained tables: same decisions on the same data and seed
     again = oracle.adapt_freq(prsim, None, month, 12, 1, 1.0, seed=7, P0_ref=P0_ref, P0_hist=P0_hist, pth=pth)
     np.testing.assert_array_equal(again[0], sim_ad)
+
+
+# ------------------------------------------------------------------------------------------------
+# round 2: rows that had no reference-generated vector (Scaling, LOCI, max_tail_factor, _vecquantiles, fractional group
+# coordinates, the window / group bookkeeping itself)
+# ------------------------------------------------------------------------------------------------
+def _lin_nodes(i, G):
+    """(g_lo, g_hi, frac) of utils.broadcast's linear interpolation between month centres, as xsdba_amd derives them"""
+    hi = np.ceil(i)
+    lo = hi - 1
+    return np.mod(lo - 1, G).astype(np.int32), np.mod(hi - 1, G).astype(np.int32), i - lo
+
+
+@pytest.mark.parametrize("gname", ["month", "doy31", "time"])
+@pytest.mark.parametrize("tag", ["add", "mul"])
+def test_scaling_against_reference_composition(golden, gname, tag):
+    d = golden("families_scaling_loci_tail")
+    kind = "+" if tag == "add" else "*"
+    k = f"{gname}_{tag}"
+    gidx, (G, W) = d[f"{gname}_gidx"], d[f"{gname}_GW"]
+    ref, hist, sim = d[f"{k}_ref"], d[f"{k}_hist"], d[f"{k}_sim"]
+    mh, mr = oracle.group_means(hist, gidx, int(G), int(W)), oracle.group_means(ref, gidx, int(G), int(W))
+    af = (mr - mh) if kind == "+" else (mr / mh)
+    scale = float(np.nanmax(np.abs(ref)))
+    # the reference sums float32 in numpy's pairwise order, the oracle in float64: 1e-5 relative (+ data-scale absolute for '+')
+    assert_close(af, d[f"{k}_scaling_af"], rtol=1e-5, atol=2e-6 * scale if kind == "+" else 0.0, what="scaling af")
+    got = oracle.scaling_adjust(sim, d[f"{k}_scaling_af"], gidx, kind)
+    assert_close(got, d[f"{k}_scaling_scen_nearest"], rtol=1e-6, what="scaling scen nearest")
+    if gname == "month":
+        g_lo, g_hi, frac = _lin_nodes(d["month_index_interp"], 12)
+        got = oracle.scaling_adjust(sim, d[f"{k}_scaling_af"], g_lo, kind, g_hi=g_hi, frac=frac)
+        assert_close(got, d[f"{k}_scaling_scen_linear"], rtol=1e-6, what="scaling scen linear")
+
+
+@pytest.mark.parametrize("gname", ["month", "doy31", "time"])
+def test_loci_against_reference_composition(golden, gname):
+    d = golden("families_scaling_loci_tail")
+    k = f"{gname}_mul"
+    gidx, (G, W) = d[f"{gname}_gidx"], d[f"{gname}_GW"]
+    ref, hist, sim, thresh = d[f"{k}_ref"], d[f"{k}_hist"], d[f"{k}_sim"], float(d[f"{k}_loci_thresh"])
+    af, sth = oracle.loci_train(ref, hist, gidx, int(G), int(W), thresh)
+    assert_close(sth, d[f"{k}_loci_hist_thresh"], rtol=2e-6, what="loci hist_thresh")
+    assert_close(af, d[f"{k}_loci_af"], rtol=2e-5, what="loci af")
+    got = oracle.loci_adjust(sim, d[f"{k}_loci_af"], d[f"{k}_loci_hist_thresh"], gidx, thresh)
+    assert_close(got, d[f"{k}_loci_scen_nearest"], rtol=1e-6, atol=1e-6, what="loci scen nearest")
+    if gname == "month":
+        g_lo, g_hi, frac = _lin_nodes(d["month_index_interp"], 12)
+        got = oracle.loci_adjust(sim, d[f"{k}_loci_af"], d[f"{k}_loci_hist_thresh"], g_lo, thresh, g_hi=g_hi, frac=frac)
+        assert_close(got, d[f"{k}_loci_scen_linear"], rtol=2e-6, atol=2e-6, what="loci scen linear")
+
+
+@pytest.mark.parametrize("gname", ["month", "doy31"])
+@pytest.mark.parametrize("tag", ["add", "mul"])
+def test_tail_mask_against_reference_composition(golden, gname, tag):
+    d = golden("families_scaling_loci_tail")
+    k = f"{gname}_{tag}"
+    gidx = d[f"{gname}_gidx"]
+    for f in (1.0, 1.02):
+        got = oracle.tail_mask(d[f"{k}_sim"], d[f"{k}_eqm_scen"], d[f"{k}_eqm_hist_q"], gidx, f)
+        exp = d[f"{k}_tailmask_{f}"]
+        assert_close(got, exp, rtol=0.0, what=f"tail mask {f}")
+        if f == 1.0:
+            assert (got != d[f"{k}_eqm_scen"])[~np.isnan(got)].any()  # the mask does bite
+
+
+def test_vecquantiles_against_reference_kernel(golden):
+    d = golden("vecquantiles")
+    for i in range(int(d["n"])):
+        arr, rnk, exp = d[f"arr_{i}"], d[f"rnk_{i}"], d[f"out_{i}"]
+        got = oracle.vecquantiles(arr, rnk)
+        # numpy's nanquantile lerps in the array dtype, numba's (what the reference runs, restated by the oracle) in float64
+        assert_close(got, exp, rtol=0.0 if arr.dtype == np.float64 else F32_ULP2, atol=1e-12, what=f"vecquantiles {i}")
+
+
+def test_interp_2d_fractional_group_coordinate(golden):
+    d = golden("interp_2d_fractional")
+    for i in range(int(d["n"])):
+        sim, hq, af, newg = d[f"sim_{i}"], d[f"hq_{i}"], d[f"af_{i}"], d[f"newg_{i}"]
+        method, extrap = str(d[f"method_{i}"]), str(d[f"extrap_{i}"])
+        G = hq.shape[1]
+        oldg = np.repeat(np.arange(0, G + 2, dtype=np.float64)[:, None], hq.shape[2], axis=1)
+        for c in range(sim.shape[0]):
+            ext = lambda t: np.concatenate([t[c, -1:], t[c], t[c, :1]])  # noqa: E731
+            got = oracle.interp_on_quantiles_2d(sim[c], newg, ext(hq), ext(af), oldg, method, extrap)
+            assert_close(got, d[f"out_{i}"][c], rtol=1e-6, atol=1e-7, what=f"case {i} {method}/{extrap} cell {c}")
+
+
+def test_window_group_bookkeeping_hand_case(golden):
+    """tests/test_base.py:76-120 (Grouper.apply("mean") with and without window=5 on arange(366)): expectations computed
+    with explicit loops over real dates in make_golden.py; January without a window is mean(0..30) = 15"""
+    d = golden("window_groups_handcase")
+    x = d["x"][None, :]
+    assert d["plain"][0] == 15.0
+    np.testing.assert_allclose(oracle.group_means(x, d["gidx"], 12, 1)[0], d["plain"], rtol=1e-14)
+    np.testing.assert_allclose(oracle.group_means(x, d["gidx"], 12, 5)[0], d["win5"], rtol=1e-14)
+    np.testing.assert_allclose(oracle.group_means(x, d["doy_gidx"], 366, 5)[0], d["doy_win5"], rtol=1e-14)
+    # the quantile path gathers the same rows: the median of a windowed day-of-year row of arange is its centre value
+    med = oracle.quantile_groups(x, d["doy_gidx"], 366, 5, np.array([0.5]))[0, :, 0]
+    np.testing.assert_allclose(med[2:-2], d["x"][2:-2], rtol=1e-14)
