@@ -97,7 +97,7 @@ def _unfold(y2, P, T):
 
 
 def _common_dtype(*arrays):
-    dt = max((np.asarray(a).dtype for a in arrays), key=lambda d: d.itemsize)  # base.py:681-685
+    dt = max((np.dtype(getattr(a, "dtype", None) or np.asarray(a).dtype) for a in arrays), key=lambda d: d.itemsize)  # base.py:681-685
     return np.result_type(dt, np.float32)
 
 
@@ -111,12 +111,33 @@ def _train_dataset(ref: DataArray, group: Grouper, quantiles, cell_dims, cell_sh
     coords["quantiles"] = Coordinate("quantiles", np.asarray(quantiles))
     out = {}
     for name, tab in tables.items():
+        if getattr(tab, "strides", None) is not None and tab.size and not any(tab.strides):  # a zero-stride placeholder stays one
+            tab = _Placeholder(tab)
+        if isinstance(tab, _Placeholder):
+            full = cell_shape + tuple(tab.shape[1:])
+            dims = cell_dims + ((prop, "quantiles") if len(tab.shape) == 3 else (prop,))
+            c2 = coords if len(tab.shape) == 3 else {k: c for k, c in coords.items() if k != "quantiles"}
+            out[name] = DataArray(np.broadcast_to(tab.value, full), dims, c2)
+            continue
         if tab.ndim == 3:
             out[name] = DataArray(tab.reshape(cell_shape + (G, Q)), cell_dims + (prop, "quantiles"), coords)
         else:
             c2 = {k: c for k, c in coords.items() if k != "quantiles"}
             out[name] = DataArray(tab.reshape(cell_shape + (G,)), cell_dims + (prop,), c2)
     return Dataset(out)
+
+
+class _Placeholder:
+    """a constant table of a given shape (no memory behind it)"""
+
+    def __init__(self, arr):
+        self.shape, self.value = tuple(arr.shape), np.asarray(arr.reshape(-1)[0] if arr.size else np.nan, arr.dtype)
+
+
+def _nan_like(tab):
+    """the all-NaN placeholder of hist_q_raw (:273-275) as a read-only zero-stride array: no memory behind it, and a device
+    table is not downloaded to build it"""
+    return np.broadcast_to(np.asarray(np.nan, tab.dtype), tuple(tab.shape))
 
 
 class _TrainBlock:
@@ -126,7 +147,7 @@ class _TrainBlock:
 def _prep_train(ds, group):
     _check_group(group, ds)
     ref, hist = as_dataarray(ds["ref"]), as_dataarray(ds["hist"])
-    dt = _common_dtype(ref.values, hist.values)
+    dt = _common_dtype(ref, hist)
     gidx, G = group.group_index(ref)
     tb = _TrainBlock()
     if not group.add_dims:
@@ -192,7 +213,7 @@ def _fused_eqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitt
         af = _corr(hq, hip.quantile_groups(tb.r2, tb.gidx_r, G, group.window, q), kind)
     # hist_q_raw = quantiles of hist BEFORE the pre-processing steps (:254-256); a NaN dummy unless max_tail_factor (:273-275)
     if max_tail_factor is None:
-        hq_raw = np.full_like(hq, np.nan)
+        hq_raw = _nan_like(hq)
     else:
         hq_raw = hq.copy() if h2 is h_raw else hip.quantile_groups(h_raw, gidx, G, group.window, q)
     out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, **(extra or {}))
@@ -216,7 +237,7 @@ def _fused_dqm_train(ds, *, group, kind, quantiles, adapt_freq_thresh=None, jitt
         sc = _corr(hip.group_means(h2, tb.gidx_h, G, group.window).astype(dt, copy=False),
                    hip.group_means(tb.r2, tb.gidx_r, G, group.window).astype(dt, copy=False), kind)
     # hist_q_raw: quantiles of the raw (not pre-processed, not normalised) hist (:151-153)
-    hq_raw = hip.quantile_groups(h_raw, gidx, G, group.window, q) if max_tail_factor is not None else np.full_like(hq, np.nan)
+    hq_raw = hip.quantile_groups(h_raw, gidx, G, group.window, q) if max_tail_factor is not None else _nan_like(hq)
     out = _train_dataset(ref, group, quantiles, cell_dims, cell_shape, af=af, hist_q=hq, hist_q_raw=hq_raw, scaling=sc,
                          **(extra or {}))
     out["af"].attrs["kind"] = kind
@@ -277,7 +298,7 @@ def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     if interp != "nearest" and group.prop != "group" and not grouped_linear:
         raise NotImplementedError(f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path")
     sim = as_dataarray(ds["sim"])
-    dt = _common_dtype(sim.values, as_dataarray(ds["af"]).values)
+    dt = _common_dtype(sim, as_dataarray(ds["af"]))
     pooled = [d for d in group.add_dims if d in sim.dims]
     if pooled:  # the pooled members become cells of their own, next to each other (the tables are broadcast over them)
         sim = sim.transpose(*[d for d in sim.dims if d != group.dim and d not in pooled], *pooled, group.dim)
@@ -483,10 +504,16 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
         scen, sim_q = hip.qdm_adjust(f2, np.ascontiguousarray(af[::P]), quantiles, gf, group.window, True, interp, extrapolation, kind)
         scen, sim_q = _unfold(scen, P, T), _unfold(sim_q, P, T)
     else:
-        scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind)
+        # sim_q (a float64 series as large as two copies of sim) is only produced when somebody will look at it
+        from .options import EXTRA_OUTPUT, OPTIONS
+
+        scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind,
+                                     want_sim_q=bool(OPTIONS[EXTRA_OUTPUT]))
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
-    return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
-                    "sim_q": _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")})
+    out = {"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen")}
+    if sim_q is not None:
+        out["sim_q"] = _series_like(sim, sim_q, cell_dims, cell_shape, group.dim, "sim_q")
+    return Dataset(out)
 
 
 def _fused_scaling_train(ds, *, group, kind):

@@ -9,6 +9,7 @@ import ctypes as C
 import os
 import subprocess
 import threading
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -99,8 +100,23 @@ def dtype_code(dt) -> int:
     raise TypeError(f"xsdba_amd supports float32/float64 data, got {dt}")
 
 
+def _release_device_buffer(ctx_ref, ptr: int) -> None:
+    """Finalizer of an owning DeviceArray: give the buffer back unless its context is already gone (destroying a context
+    frees everything it handed out).  Never raises: it may run during interpreter shutdown."""
+    try:
+        ctx = ctx_ref()
+        if ctx is not None and ctx.handle:
+            load().xsdba_hip_free(ctx.handle, C.c_void_p(ptr))
+    except Exception:  # pragma: no cover
+        pass
+
+
 class DeviceArray:
-    """A dense device buffer with numpy-like shape/dtype/strides metadata (element strides)."""
+    """A dense device buffer with numpy-like shape/dtype/strides metadata (element strides).
+
+    Ownership: an array made by the constructor (or returned by a ``hip.*`` call that was not given ``out=``) owns its
+    buffer and returns it to the context when it is garbage-collected or ``free()``d, whichever comes first; ``from_ptr``
+    views own nothing.  Buffers still alive when their ``Context`` is closed are released with it."""
 
     def __init__(self, ctx: "Context", shape, dtype):
         self.ctx = ctx
@@ -110,6 +126,7 @@ class DeviceArray:
         p = C.c_void_p()
         check(load().xsdba_hip_malloc(ctx.handle, C.c_size_t(max(self.nbytes, 1)), C.byref(p)), "malloc")
         self.ptr = p.value
+        self._finalizer = weakref.finalize(self, _release_device_buffer, weakref.ref(ctx), self.ptr)
 
     @classmethod
     def from_ptr(cls, ctx: "Context", ptr: int, shape, dtype) -> "DeviceArray":
@@ -123,26 +140,105 @@ class DeviceArray:
         self.foreign = True
         return self
 
+    # ---- numpy-like metadata (what the labelled layer needs to carry a device buffer around without touching it) ----
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def size(self) -> int:
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def reshape(self, *shape) -> "DeviceArray":
+        """A view of the same (dense, C-ordered) buffer under another shape; the view keeps its base alive."""
+        if len(shape) == 1 and not np.isscalar(shape[0]):
+            shape = tuple(shape[0])
+        if getattr(self, "cell_time_strides", None) is not None:
+            raise ValueError("a time-major device series cannot be reshaped")
+        known = int(np.prod([s for s in shape if s != -1], dtype=np.int64))
+        shape = tuple(int(self.size // max(known, 1)) if s == -1 else int(s) for s in shape)
+        if int(np.prod(shape, dtype=np.int64)) != self.size:
+            raise ValueError(f"cannot reshape device array of shape {self.shape} into {shape}")
+        v = DeviceArray.from_ptr(self.ctx, self.ptr, shape, self.dtype)
+        v._base = self
+        return v
+
+    def astype(self, dtype, copy: bool = True) -> "DeviceArray":
+        if np.dtype(dtype) != self.dtype:
+            raise TypeError(f"device arrays are not converted implicitly ({self.dtype} -> {np.dtype(dtype)}): convert on the host")
+        return self
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.download()
+        return host if dtype is None else host.astype(dtype)
+
+    # ---- transfers ------------------------------------------------------------------------------------------------
+    # Big pageable host arrays go through blocks that are page-locked just for their own copy (a few blocks in flight):
+    # DMA at the PCIe rate without pinning the whole array, so arrays larger than the lockable memory (memmaps) still work.
+    _PIN_BLOCK = 128 << 20
+    _PIN_MIN = 32 << 20
+    _PIN_GROUP = 4
+
+    def _blocked_copy(self, host: np.ndarray, to_device: bool) -> bool:
+        lib, h = load(), self.ctx.handle
+        base, n = host.ctypes.data, self.nbytes
+        blocks = [(o, min(self._PIN_BLOCK, n - o)) for o in range(0, n, self._PIN_BLOCK)]
+        pinned: list[int] = []     # offsets registered and not yet released
+        ok = True
+        try:
+            for gi in range(0, len(blocks), self._PIN_GROUP):
+                grp = blocks[gi:gi + self._PIN_GROUP]
+                new = []
+                for o, m in grp:   # page-lock the next group while the previous group's copies are still running
+                    if lib.xsdba_hip_host_register(h, C.c_void_p(base + o), C.c_size_t(m)) != 0:
+                        ok = False
+                        break
+                    new.append(o)
+                if gi:
+                    check(lib.xsdba_hip_synchronize(h), "synchronize")
+                    for o in pinned:
+                        lib.xsdba_hip_host_unregister(h, C.c_void_p(base + o))
+                    pinned = []
+                pinned = new
+                if not ok:
+                    break
+                for o, m in grp:
+                    d, s_ = C.c_void_p(self.ptr + o), C.c_void_p(base + o)
+                    check(lib.xsdba_hip_memcpy_async(h, d if to_device else s_, s_ if to_device else d, C.c_size_t(m)), "memcpy_async")
+        finally:
+            lib.xsdba_hip_synchronize(h)
+            for o in pinned:
+                lib.xsdba_hip_host_unregister(h, C.c_void_p(base + o))
+        return ok
+
     def upload(self, host: np.ndarray) -> "DeviceArray":
         host = np.ascontiguousarray(host, self.dtype)
         assert host.shape == self.shape
+        if self.nbytes >= self._PIN_MIN and self._blocked_copy(host, True):
+            return self
         check(load().xsdba_hip_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p),
                                           C.c_size_t(self.nbytes)), "memcpy_h2d")
         return self
 
     def download(self) -> np.ndarray:
+        shape = getattr(self, "logical_shape", None)
         out = np.empty(self.shape, self.dtype)
-        check(load().xsdba_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
-                                          C.c_size_t(self.nbytes)), "memcpy_d2h")
+        if not (self.nbytes >= self._PIN_MIN and self._blocked_copy(out, False)):
+            check(load().xsdba_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                              C.c_size_t(self.nbytes)), "memcpy_d2h")
         return out
 
     def free(self) -> None:
+        """Release the buffer now (idempotent; a no-op for views and once the context has been closed)."""
         if getattr(self, "foreign", False):
             self.ptr = None
             return
-        if self.ptr:
+        fin = getattr(self, "_finalizer", None)
+        if fin is not None:
+            fin.detach()
+        if self.ptr and self.ctx.handle:
             check(load().xsdba_hip_free(self.ctx.handle, C.c_void_p(self.ptr)), "free")
-            self.ptr = None
+        self.ptr = None
 
 
 class Context:

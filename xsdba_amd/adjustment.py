@@ -49,6 +49,26 @@ def update_history(hist_str: str, *inputs, new_name: str | None = None) -> str:
     return f"[{dt.datetime.now():%Y-%m-%d %H:%M:%S}] {new_name or ''}: {hist_str} - xsdba version: {__version__}\n" + merged
 
 
+def _device_resident(da):
+    """Large host series are moved to the GPU ONCE, before the adjustment code sees them (blocks page-locked on the fly,
+    DMA at the PCIe rate): everything downstream — trained tables included — then stays on the device, and a result is
+    downloaded only when its ``values`` are asked for.  Small inputs (< XSDBA_AMD_DEVICE_MIN_MB, default 64 MB) keep the
+    plain path: one library call per stage with host pointers.  Layouts the kernels read directly are (cells..., time) and
+    (time, cells...); anything else stays on the host (the library then copies it once)."""
+    import os
+
+    if getattr(da, "device_data", None) is not None or "time" not in da.dims:
+        return da
+    v = da.values
+    lim = float(os.environ.get("XSDBA_AMD_DEVICE_MIN_MB", "64")) * 2 ** 20
+    ax = da.dims.index("time")
+    if v.dtype not in (np.float32, np.float64) or v.nbytes < lim or not v.flags.c_contiguous or ax not in (0, v.ndim - 1):
+        return da
+    from ._lib import default_context
+
+    return DataArray(default_context().to_device(v), da.dims, da.coords, da.attrs, da.name)
+
+
 class BaseAdjustment(ParametrizableWithDataset):
     """Base class: input checks shared by every adjustment (adjustment.py:68-206)."""
 
@@ -123,7 +143,7 @@ class TrainAdjust(BaseAdjustment):
     def train(cls, ref, hist, **kwargs):
         """Train the adjustment object (adjustment.py:227-269)."""
         want_xr = is_xarray(ref)
-        ref, hist = as_dataarray(ref), as_dataarray(hist)
+        ref, hist = _device_resident(as_dataarray(ref)), _device_resident(as_dataarray(hist))
         kwargs = parse_group(cls._train, kwargs)
         skip_checks = kwargs.pop("skip_input_checks", False)
         if not skip_checks:
@@ -146,7 +166,7 @@ class TrainAdjust(BaseAdjustment):
     def adjust(self, sim, *args, **kwargs):
         """Return bias-adjusted data (adjustment.py:271-316)."""
         want_xr = is_xarray(sim)
-        sim = as_dataarray(sim)
+        sim = _device_resident(as_dataarray(sim))
         skip_checks = kwargs.pop("skip_input_checks", False)
         if not skip_checks:
             if "group" in self:

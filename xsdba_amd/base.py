@@ -393,8 +393,13 @@ def map_blocks(reduces=None, **out_vars):
             try:
                 out = func(ds, **kwargs)
                 out = as_dataset(out)
-                out = Dataset({k: v.transpose(*[d for d in all_dims if d in v.dims]) for k, v in out.data_vars.items()},
-                              attrs=out.attrs)
+                def _ordered(v):
+                    order = [d for d in all_dims if d in v.dims]
+                    if tuple(order) != tuple(v.dims) and getattr(v, "device_data", None) is not None and getattr(v, "_host", None) is None:
+                        return v  # device-resident result: kept as the kernels wrote it, (cells..., time) — labels tell the order
+                    return v.transpose(*order)
+
+                out = Dataset({k: _ordered(v) for k, v in out.data_vars.items()}, attrs=out.attrs)
             except Exception as err:
                 crds = list(ds.coords)
                 raise ValueError(f"{func.__name__} failed on block with coords : {crds}.") from err

@@ -1445,7 +1445,13 @@ API int xsdba_hip_host_register(xsdba_hip_ctx *ctx, void *host_ptr, size_t bytes
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!host_ptr || !bytes) return fail(XSDBA_E_ARG, "null/empty host buffer");
-    HIP_TRY(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    // read-write first; a read-only mapping (a numpy memmap opened with mode "r") can only be locked as read-only
+    hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipHostRegister(host_ptr, bytes, hipHostRegisterReadOnly);
+    }
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail((int)e, "hipHostRegister failed: %s", hipGetErrorString(e)); }
     return 0;
 }
 

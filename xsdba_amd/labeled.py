@@ -33,6 +33,10 @@ def _is_time_like(values) -> bool:
     return dt == object and getattr(arr, "size", 0) > 0 and hasattr(np.asarray(arr).flat[0], "year")
 
 
+def _is_device_array(obj) -> bool:
+    return type(obj).__name__ == "DeviceArray" and hasattr(obj, "ptr")
+
+
 class Coordinate:
     """1-D coordinate variable."""
 
@@ -68,15 +72,24 @@ class _DtAccessor:
 
 
 class DataArray:
+    """Labelled array.  The data live on the host (numpy) or on the GPU (a ``DeviceArray``: what ``train`` / ``adjust``
+    produce for device-resident or large inputs).  ``values`` always answers with a numpy array — a device buffer is
+    downloaded on first access and the copy kept — while the adjustment code itself passes the device buffer on
+    (``device_data``) so that tables and series never leave the GPU between ``train`` and ``adjust``."""
+
     def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
-        self.values = np.asarray(data)
+        if _is_device_array(data):
+            self._dev, self._host = data, None
+        else:
+            self._dev, self._host = None, np.asarray(data)
+        nd = len(self.shape)
         if dims is None:
-            dims = tuple(f"dim_{i}" for i in range(self.values.ndim))
+            dims = tuple(f"dim_{i}" for i in range(nd))
         if isinstance(dims, str):
             dims = (dims,)
         self.dims = tuple(dims)
-        if len(self.dims) != self.values.ndim:
-            raise ValueError(f"dims {self.dims} do not match data of shape {self.values.shape}")
+        if len(self.dims) != nd:
+            raise ValueError(f"dims {self.dims} do not match data of shape {self.shape}")
         self.coords = OrderedDict()
         if coords:
             items = coords.items() if isinstance(coords, dict) else coords
@@ -95,24 +108,39 @@ class DataArray:
 
     # ---- basic properties -----------------------------------------------------------------------
     @property
+    def values(self):
+        if self._host is None:
+            self._host = self._dev.download().reshape(self._dev.shape)
+        return self._host
+
+    @values.setter
+    def values(self, v):
+        self._host, self._dev = np.asarray(v), None
+
+    @property
+    def device_data(self):
+        """the DeviceArray behind this array, or None when the data live on the host only"""
+        return self._dev
+
+    @property
     def shape(self):
-        return self.values.shape
+        return tuple(self._dev.shape) if self._host is None else self._host.shape
 
     @property
     def dtype(self):
-        return self.values.dtype
+        return self._dev.dtype if self._host is None else self._host.dtype
 
     @property
     def ndim(self):
-        return self.values.ndim
+        return len(self.shape)
 
     @property
     def size(self):
-        return self.values.size
+        return int(np.prod(self.shape, dtype=np.int64))
 
     @property
     def sizes(self):
-        return OrderedDict(zip(self.dims, self.values.shape))
+        return OrderedDict(zip(self.dims, self.shape))
 
     @property
     def data(self):
@@ -194,6 +222,16 @@ class DataArray:
         return DataArray(data, dims, coords, self.attrs, self.name)
 
     # ---- structural -----------------------------------------------------------------------------
+    def _like(self, dims=None, coords=None, attrs=None, name=None):
+        """the same data (host copy and / or device buffer shared, nothing downloaded) under other labels"""
+        out = DataArray.__new__(DataArray)
+        out._dev, out._host = self._dev, self._host
+        out.dims = tuple(self.dims if dims is None else dims)
+        out.coords = OrderedDict(self.coords if coords is None else coords)
+        out.attrs = dict(self.attrs if attrs is None else attrs)
+        out.name = self.name if name is None else name
+        return out
+
     def transpose(self, *dims):
         if not dims:
             dims = self.dims[::-1]
@@ -203,6 +241,8 @@ class DataArray:
             dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
         if set(dims) != set(self.dims):
             raise ValueError(f"{dims} is not a permutation of {self.dims}")
+        if tuple(dims) == self.dims:
+            return self._like()
         return DataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords, self.attrs, self.name)
 
     @property
@@ -210,17 +250,23 @@ class DataArray:
         return self.transpose()
 
     def astype(self, dtype):
+        if np.dtype(dtype) == self.dtype:
+            return self._like()
         return DataArray(self.values.astype(dtype), self.dims, self.coords, self.attrs, self.name)
 
     def copy(self, data=None):
+        if data is None and self._host is None:
+            return self._like()  # (device buffers are never modified in place by this package)
         return DataArray(self.values.copy() if data is None else data, self.dims, self.coords, self.attrs, self.name)
 
     def rename(self, name=None):
         if isinstance(name, dict):
             dims = tuple(name.get(d, d) for d in self.dims)
             coords = OrderedDict((name.get(k, k), Coordinate(name.get(k, k), c.values, c.attrs)) for k, c in self.coords.items())
-            return DataArray(self.values, dims, coords, self.attrs, self.name)
-        return DataArray(self.values, self.dims, self.coords, self.attrs, name)
+            return self._like(dims=dims, coords=coords)
+        out = self._like()
+        out.name = name
+        return out
 
     def to_netcdf(self, path):
         """NetCDF-3 file readable by xarray (xsdba_amd/io.py)"""
@@ -238,18 +284,18 @@ class DataArray:
         c = OrderedDict(self.coords)
         for k, v in {**(coords or {}), **kw}.items():
             c[k] = v if isinstance(v, Coordinate) else Coordinate(k, v.values if isinstance(v, DataArray) and k not in v.coords else (v.coords[k].values if isinstance(v, DataArray) else v))
-        return DataArray(self.values, self.dims, c, self.attrs, self.name)
+        return self._like(coords=c)
 
     def assign_attrs(self, attrs=None, **kw):
         a = dict(self.attrs)
         a.update(attrs or {})
         a.update(kw)
-        return DataArray(self.values, self.dims, self.coords, a, self.name)
+        return self._like(attrs=a)
 
     def drop_vars(self, names, errors="raise"):
         names = [names] if isinstance(names, str) else list(names)
         c = OrderedDict((k, v) for k, v in self.coords.items() if k not in names)
-        return DataArray(self.values, self.dims, c, self.attrs, self.name)
+        return self._like(coords=c)
 
     def expand_dims(self, dim=None, **kw):
         spec = dict(dim or {}) if not isinstance(dim, str) else {dim: 1}

@@ -78,8 +78,23 @@ def cell_time_view(da: DataArray, dim: str = "time"):
     """Logical ``[cell, time]`` 2-D view of `da` (no copy for C-ordered (time, cells...) or (cells..., time)
     arrays: the library reads both layouts), with the cell dims and their shape to fold results back."""
     ax = da.dims.index(dim)
-    v = np.moveaxis(da.values, ax, -1)
     cell_dims = tuple(d for d in da.dims if d != dim)
+    dev = getattr(da, "device_data", None)
+    if dev is not None and getattr(da, "_host", None) is None:
+        # device-resident data: (cells..., time) is a reshape of the buffer, (time, cells...) the time-major view of it
+        shape = tuple(da.shape)
+        cell_shape = shape[:ax] + shape[ax + 1:]
+        n_cell, n_time = int(np.prod(cell_shape, dtype=np.int64)), shape[ax]
+        if ax == len(shape) - 1:
+            return dev.reshape(n_cell, n_time), cell_dims, cell_shape
+        if ax == 0 and getattr(dev, "cell_time_strides", None) is None:
+            from ._lib import DeviceArray
+
+            v = DeviceArray.from_ptr(dev.ctx, dev.ptr, (n_time, n_cell), dev.dtype)
+            v._base = dev
+            v.logical_shape, v.cell_time_strides = (n_cell, n_time), (1, n_cell)
+            return v, cell_dims, cell_shape
+    v = np.moveaxis(da.values, ax, -1)
     cell_shape = v.shape[:-1]
     return v.reshape(-1, v.shape[-1]), cell_dims, cell_shape
 
@@ -89,6 +104,11 @@ def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantil
     Cell dimensions the table does not have (the members pooled by ``Grouper(add_dims=...)`` at training) are broadcast,
     their sizes taken from `cell_shape`."""
     tail = [prop] + ([last] if last else [])
+    dev = getattr(tab, "device_data", None)
+    if dev is not None and tuple(tab.dims) == tuple(cell_dims) + tuple(tail):
+        # a device-resident table already laid out (cells..., group(, quantile)): a reshape of the buffer, nothing moves
+        n_cell = int(np.prod(tab.shape[:len(cell_dims)], dtype=np.int64))
+        return dev.reshape((n_cell,) + tuple(tab.shape[len(cell_dims):]))
     missing = [d for d in cell_dims if d not in tab.dims]
     if missing and cell_shape is None:
         raise ValueError(f"trained table lacks dimension(s) {missing} present on the data")
