@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--nquantiles", type=int, default=20)
     ap.add_argument("--time-major", action="store_true", help="store the cubes as (time, cell) instead of (cell, time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-level", action="store_true", help="skip the secondary figure through the drop-in API")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
     ap.add_argument("--gather", action="store_true", help="N>1: also time the final RCCL gather of scen to rank 0")
     args = ap.parse_args()
@@ -246,6 +247,8 @@ def main():
         }
         if gather_ms is not None:
             out["gather_ms"] = round(gather_ms, 3)
+        if not args.no_api_level and not args.time_major:
+            out["api_level"] = api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
                                                args.cpu_seconds, args.time_major, rank_window)
@@ -253,6 +256,56 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window):
+    """Secondary figure, never `value`: the same workload through the drop-in API — <Class>.train(ref, hist, group=...,
+    nquantiles=...) -> .adjust(sim) on labelled arrays (reference adjustment.py:227-316).
+      device_inputs: DataArrays wrapping the device cubes of the timed region (tables and scen stay on the device);
+      host_inputs:   numpy-backed DataArrays of a bounded sample of the same cells (uploaded through page-locked blocks,
+                     scen downloaded: the PCIe-inclusive rate)."""
+    import warnings
+
+    import xsdba_amd as xs
+    from xsdba_amd.labeled import DataArray
+
+    cls = {"eqm": xs.EmpiricalQuantileMapping, "dqm": xs.DetrendedQuantileMapping, "qdm": xs.QuantileDeltaMapping}[method]
+    grp = xs.Grouper("time" if group == "time" else f"time.{group}", window=W) if group != "time" else "time"
+    times = xs.date_range("2000-01-01", T, "noleap").values
+    units = "K" if kind == "+" else "mm/d"
+    adj_kw = {"rank_window": rank_window} if method == "qdm" else {}
+
+    def wrap(a, n):
+        return DataArray(a, ("cell", "time"), {"cell": np.arange(n), "time": times}, {"units": units})
+
+    def run(r, h, s_):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            obj = cls.train(r, h, group=grp, nquantiles=Q, kind=kind)
+            return obj.adjust(s_, **adj_kw)
+
+    res = {}
+    dev = [wrap(a, C) for a in (ref, hist, sim)]
+    run(*dev)  # warm-up (allocations)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        scen = run(*dev)
+    ctx.synchronize()
+    res["device_inputs_cells_per_s"] = round(C * reps / (time.perf_counter() - t0), 1)
+    del scen
+    n = min(C, 16384)
+    host = [wrap(np.ascontiguousarray(a.download()[:n]), n) for a in (ref, hist, sim)]
+    run(*host).values  # warm-up
+    t0 = time.perf_counter()
+    out = run(*host).values  # the download is part of it
+    dt_h = time.perf_counter() - t0
+    res["host_inputs_cells_per_s"] = round(n / dt_h, 1)
+    res["host_inputs_sample_cells"] = n
+    res["host_inputs_GBps"] = round(4 * n * T * 4 / dt_h / 1e9, 2)  # three series up, one down
+    assert out.shape == (n, T)
+    return res
 
 
 def pmc_traffic(workload, cells, days, kernel):

@@ -85,12 +85,16 @@ int xsdba_hip_memset(xsdba_hip_ctx *ctx, void *dst, int value, size_t bytes);
  *   memcpy_async                     hipMemcpyAsync(hipMemcpyDefault) on the context's stream, returns immediately;
  *   event_record(ctx, slot)          records event `slot` (0..15) of `ctx` on its stream;
  *   stream_wait_event(w, src, slot)  work queued on w's stream after this call starts only when event `slot` of `src`
- *                                    (as last recorded) has completed; a never-recorded event does not block. */
+ *                                    (as last recorded) has completed; a never-recorded event does not block;
+ *   event_synchronize(ctx, slot)     the HOST waits until event `slot` of `ctx` (as last recorded) has completed — what
+ *                                    lets a pipeline unpin the host block it read back two steps ago without draining the
+ *                                    streams (hipEventSynchronize); a never-recorded event returns at once. */
 int xsdba_hip_host_register(xsdba_hip_ctx *ctx, void *host_ptr, size_t bytes);
 int xsdba_hip_host_unregister(xsdba_hip_ctx *ctx, void *host_ptr);
 int xsdba_hip_memcpy_async(xsdba_hip_ctx *ctx, void *dst, const void *src, size_t bytes);
 int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot);
 int xsdba_hip_stream_wait_event(xsdba_hip_ctx *waiter, xsdba_hip_ctx *src, int slot);
+int xsdba_hip_event_synchronize(xsdba_hip_ctx *ctx, int slot);
 
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * enable != 0 brackets every kernel launch with an event pair; xsdba_hip_profile_read synchronises the

@@ -1482,6 +1482,16 @@ API int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot)
     return 0;
 }
 
+API int xsdba_hip_event_synchronize(xsdba_hip_ctx *ctx, int slot)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (slot < 0 || slot >= 16) return fail(XSDBA_E_ARG, "event slot %d out of range [0,16)", slot);
+    if (!ctx->user_ev[slot]) return 0;  // never recorded: nothing to wait for
+    HIP_TRY(hipEventSynchronize(ctx->user_ev[slot]));
+    return 0;
+}
+
 API int xsdba_hip_stream_wait_event(xsdba_hip_ctx *waiter, xsdba_hip_ctx *src, int slot)
 {
     int rc = check_ctx(waiter);

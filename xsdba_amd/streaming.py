@@ -1,8 +1,8 @@
 """Out-of-core driver: blocks of grid cells stream through the GPU.
 
 The reference leaves problems larger than memory to dask: every chunk of cells is an independent ``map_blocks`` call
-(base.py:640-702).  Here the host cubes (numpy arrays or memmaps, ``[cell, time]`` C-contiguous) are pinned in place and
-cut into blocks of cells; three HIP streams (three library contexts on one device) run as a pipeline ordered by events:
+(base.py:640-702).  Here the host cubes (numpy arrays or memmaps, ``[cell, time]`` C-contiguous) are cut into blocks of
+cells whose slices are page-locked only while their block is in flight; three HIP streams (three library contexts on one device) run as a pipeline ordered by events:
 
     stream "in"   host -> device copy of block i+1          (DMA at PCIe rate from the pinned cubes)
     stream "k"    train + adjust kernels of block i
@@ -27,22 +27,30 @@ def _ptr(a: np.ndarray, cell0: int = 0) -> C.c_void_p:
     return C.c_void_p(a.ctypes.data + cell0 * a.strides[0])
 
 
-class _Pinned:
-    """pins host arrays in place for the lifetime of the with-block"""
+class _BlockPins:
+    """Page-locks host slices block by block: a slice is pinned just before its block is queued and released once the
+    block's read-back has completed, so at most a few blocks are locked at any time — cubes larger than the lockable
+    memory (numpy memmaps of a dataset larger than RAM) stream through like dask chunks would.  Slices that cannot be
+    locked (exotic mappings) are simply copied unpinned."""
 
-    def __init__(self, ctx: Context, arrays):
-        self.ctx, self.arrays, self.done = ctx, arrays, []
+    def __init__(self, ctx: Context):
+        self.ctx, self.live = ctx, {}
 
-    def __enter__(self):
-        for a in self.arrays:
-            check(load().xsdba_hip_host_register(self.ctx.handle, _ptr(a), C.c_size_t(a.nbytes)), "host_register")
-            self.done.append(a)
-        return self
+    def pin(self, key, arrays, c0, n):
+        done = []
+        for a in arrays:
+            p = _ptr(a, c0)
+            if load().xsdba_hip_host_register(self.ctx.handle, p, C.c_size_t(n * a.strides[0])) == 0:
+                done.append(p)
+        self.live[key] = done
 
-    def __exit__(self, *exc):
-        for a in self.done:
-            load().xsdba_hip_host_unregister(self.ctx.handle, _ptr(a))
-        return False
+    def release(self, key):
+        for p in self.live.pop(key, []):
+            load().xsdba_hip_host_unregister(self.ctx.handle, p)
+
+    def release_all(self):
+        for key in list(self.live):
+            self.release(key)
 
 
 def _rec(ctx: Context, slot: int):
@@ -100,14 +108,21 @@ def train_adjust_streamed(method, ref, hist, sim, gidx, G, W, q, kind="+", *, bl
         time_num = c_k.to_device(np.ascontiguousarray(time_num, np.float64))
     # event slots (per context): s = buffer set; "in": s -> block uploaded; "k": s -> block computed; "out": s -> read back
     pinned = [ref, hist, sim, scen] + ([af_h, hq_h] if keep_tables else [])
-    t0 = time.perf_counter()
-    with _Pinned(c_k, pinned):
-        t_pin = time.perf_counter() - t0
-        t1 = time.perf_counter()
+    pins = _BlockPins(c_k)
+    t_pin = 0.0
+    t1 = time.perf_counter()
+    try:
         for i in range(nblocks):
             s = i % NS
             c0, n = i * B, min(B, Cn - i * B)
             rows = n * T * 4
+            # ---- host slices: block i - NS has been read back (the host waits on its event only), its slices are unpinned;
+            #      (the slices of block i were pinned while block i - 1 was being queued / computed)
+            if i >= NS:
+                check(load().xsdba_hip_event_synchronize(c_out.handle, C.c_int(s)), "event_synchronize")
+                pins.release(i - NS)
+            if i == 0:
+                pins.pin(0, pinned, c0, n)
             # ---- upload: the set's inputs were last read by the kernels of block i - NS
             _wait(c_in, c_k, s)
             for dst, src in ((d_ref[s], ref), (d_hist[s], hist), (d_sim[s], sim)):
@@ -137,16 +152,36 @@ def train_adjust_streamed(method, ref, hist, sim, gidx, G, W, q, kind="+", *, bl
                 _copy(c_out, _ptr(af_h, c0), C.c_void_p(d_af[s].ptr), n * G * Q * 4)
                 _copy(c_out, _ptr(hq_h, c0), C.c_void_p(d_hq[s].ptr), n * G * Q * 4)
             _rec(c_out, s)
+            # ---- the next block's slices are page-locked now, while the GPU works on this one
+            if i + 1 < nblocks:
+                tp = time.perf_counter()
+                pins.pin(i + 1, pinned, (i + 1) * B, min(B, Cn - (i + 1) * B))
+                t_pin += time.perf_counter() - tp
         c_in.synchronize(); c_k.synchronize(); c_out.synchronize()
         t_pipe = time.perf_counter() - t1
+    finally:
+        # whatever happened: nothing may still be copying from / into a slice when it is unpinned, and every context and
+        # device buffer of the pipeline is given back here, not when the garbage collector gets to them
+        for ctx in (c_in, c_k, c_out):
+            try:
+                ctx.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
+        pins.release_all()
+        for lst in (d_ref, d_hist, d_sim, d_scen, d_af, d_hq, d_sc or [], d_tr or []):
+            for d in lst:
+                try:
+                    d.free()
+                except Exception:  # noqa: BLE001
+                    pass
+            lst.clear()
+        if isinstance(time_num, DeviceArray):
+            time_num.free()
+        for ctx in (c_in, c_out, c_k):
+            ctx.close()
     if stats is not None:
         h2d = 3 * Cn * T * 4
         d2h = Cn * T * 4 + (2 * Cn * G * Q * 4 if keep_tables else 0)
         stats.update(cells=Cn, blocks=nblocks, block_cells=B, pin_s=t_pin, pipeline_s=t_pipe, h2d_bytes=h2d, d2h_bytes=d2h,
-                     h2d_GBps=h2d / t_pipe / 1e9, cells_per_s=Cn / t_pipe, cells_per_s_incl_pinning=Cn / (t_pipe + t_pin))
-    for ctx in (c_in, c_out):
-        ctx.close()
-    for lst in (d_ref, d_hist, d_sim, d_scen, d_af, d_hq, d_sc or [], d_tr or []):
-        lst.clear()
-    c_k.close()
+                     h2d_GBps=h2d / t_pipe / 1e9, cells_per_s=Cn / t_pipe, cells_per_s_incl_pinning=Cn / t_pipe)  # (pinning happens inside the pipeline now)
     return (scen, af_h, hq_h) if keep_tables else scen
