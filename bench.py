@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-level", action="store_true", help="skip the secondary figure through the drop-in API")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
-    ap.add_argument("--gather", action="store_true", help="N>1: also time the final RCCL gather of scen to rank 0")
+    ap.add_argument("--gather", action="store_true", help="also time (and verify) the final native RCCL gather of scen to rank 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,29 +184,39 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    gather_ms = None
-    if dist is not None and args.gather:
-        # the one collective of the path: the final gather of the per-rank scen blocks to rank 0 (RCCL over xGMI
-        # with backend nccl); timed separately, never part of `value`
-        import ctypes
-
-        import torch
-
-        from xsdba_amd._lib import check, load
-        from xsdba_amd.sharding import gather_cells
+    gather_info = None
+    if args.gather:
+        # the one collective of the path: the final gather of the per-rank scen blocks to rank 0 — native (xsdba_hip_gather:
+        # RCCL sends / receives straight from the device buffers on the library's stream); timed separately, never part of
+        # `value`.  Self-check: rank 0 compares rows of every rank's block in the gathered cube with what that rank holds.
+        from xsdba_amd.sharding import comm_info, gather_device, init_comm, shard_plan
 
         scen_dev = outs[-1] if method != "dqm" else outs[3]
-        scen_t = torch.empty((C, T), dtype=torch.float32, device=tdev)
-        check(load().xsdba_hip_memcpy_d2h(ctx.handle, ctypes.c_void_p(scen_t.data_ptr()), ctypes.c_void_p(scen_dev.ptr),
-                                          ctypes.c_size_t(scen_dev.nbytes)), "copy of scen into the collective's buffer")
+        init_comm(ctx, rank, world)
+        r_rccl, n_rccl = comm_info(ctx)
+        assert (r_rccl, n_rccl) == (rank, world), (r_rccl, n_rccl)
+        assert shard_plan(C * world, world, rank) == (rank * C, C)
+        full = gather_device(ctx, scen_dev, C * world, root=0)  # warm-up (connection set-up) + the buffer
         barrier()
         g0 = time.perf_counter()
-        full = gather_cells(scen_t, C * world, dst=0)
-        if tdev == "cuda":
-            torch.cuda.synchronize()
+        gather_device(ctx, scen_dev, C * world, root=0, out=full)
+        ctx.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
+        probe_rows = [0, C // 2, C - 1]
+        mine = scen_dev.download()[probe_rows]
+        ok = True
+        if dist is not None:
+            box = [None] * world if rank == 0 else None
+            dist.gather_object(mine, box, dst=0)
+        else:
+            box = [mine]
         if rank == 0:
-            assert tuple(full.shape) == (C * world, T)
+            got = full.download()
+            for r, rows in enumerate(box):
+                ok = ok and np.array_equal(got[[r * C + i for i in probe_rows]], rows, equal_nan=True)
+            gather_info = {"ms": round(gather_ms, 3), "ranks_seen_by_rccl": n_rccl, "bytes": int(C * world * T * 4),
+                           "GB/s": round(C * (world - 1) * T * 4 / (gather_ms * 1e-3) / 1e9, 1), "verified": bool(ok)}
+            assert ok, "the gathered cube differs from the per-rank results"
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -245,8 +255,8 @@ def main():
             },
             "roofline": roof,
         }
-        if gather_ms is not None:
-            out["gather_ms"] = round(gather_ms, 3)
+        if gather_info is not None:
+            out["gather"] = gather_info
         if not args.no_api_level and not args.time_major:
             out["api_level"] = api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
         if not args.no_cpu_baseline:

@@ -96,6 +96,31 @@ int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot);
 int xsdba_hip_stream_wait_event(xsdba_hip_ctx *waiter, xsdba_hip_ctx *src, int slot);
 int xsdba_hip_event_synchronize(xsdba_hip_ctx *ctx, int slot);
 
+/* ---- e: multi-GPU.  Cells shard embarrassingly: one process per GPU, rank r owns a contiguous block of
+ * the flattened cell index (the role dask's chunks over lat / lon play for the reference: map_blocks, base.py:640-650,
+ * 715), nothing is exchanged during train / adjust, and the ONE collective is the final gather of the per-rank results —
+ * RCCL point-to-point over xGMI, straight from / into the device buffers on the context's stream (no staging copy).
+ * librccl.so is dlopen'ed on first use: a single-GPU user never needs it.
+ *   shard_plan(n_cell, n_ranks, rank)  -> first cell and number of cells of `rank` (blocks differ by at most one cell and
+ *                                         tile [0, n_cell) exactly); pure arithmetic, no context, no GPU;
+ *   comm_unique_id(id)                 rank 0 fills the XSDBA_COMM_ID_BYTES-byte token; the CALLER hands the bytes to the
+ *                                         other ranks by whatever rendezvous it has (a file, MPI, torch.distributed ...);
+ *   comm_init(ctx, id, rank, n_ranks)  collective: every rank calls it with the same token (ncclCommInitRank);
+ *   comm_info(ctx, &rank, &n_ranks)    what RCCL itself reports for the communicator (-1, 0 before comm_init);
+ *   gather(ctx, send, n_local, row_elems, dtype, recv, n_cell, root)
+ *                                      every rank sends its [n_local, row_elems] device block (n_local as in shard_plan)
+ *                                      to `root`, which receives them at their places of the [n_cell, row_elems] device
+ *                                      buffer `recv` (ignored elsewhere); asynchronous on the context's stream;
+ *   comm_destroy(ctx)                  (also done by xsdba_hip_destroy). */
+#define XSDBA_COMM_ID_BYTES 128
+int xsdba_hip_shard_plan(int64_t n_cell, int n_ranks, int rank, int64_t *first_cell, int64_t *n_local);
+int xsdba_hip_comm_unique_id(void *id);
+int xsdba_hip_comm_init(xsdba_hip_ctx *ctx, const void *id, int rank, int n_ranks);
+int xsdba_hip_comm_info(xsdba_hip_ctx *ctx, int *rank, int *n_ranks);
+int xsdba_hip_gather(xsdba_hip_ctx *ctx, const void *send, int64_t n_local, int64_t row_elems, int dtype, void *recv,
+                     int64_t n_cell, int root);
+int xsdba_hip_comm_destroy(xsdba_hip_ctx *ctx);
+
 /* Per-kernel timing with HIP events on the context's stream (bench.py's roofline leg).
  * enable != 0 brackets every kernel launch with an event pair; xsdba_hip_profile_read synchronises the
  * stream and returns, for up to `cap` distinct kernels, name / launch count / total milliseconds

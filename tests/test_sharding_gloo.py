@@ -10,7 +10,7 @@ from pathlib import Path
 import numpy as np
 import pytest
 
-from xsdba_amd.sharding import shard_bounds, shard_cells
+from xsdba_amd.sharding import shard_bounds, shard_cells, shard_plan
 
 ROOT = Path(__file__).resolve().parent.parent
 
@@ -26,6 +26,8 @@ def test_shard_bounds_tile_the_cells(n, world):
     np.testing.assert_array_equal(np.concatenate([shard_cells(x, world, r) for r in range(world)]), x)
     with pytest.raises(ValueError):
         shard_bounds(n, world, world)
+    # the library's own plan (xsdba_hip_shard_plan: pure arithmetic, callable without a GPU) is the same tiling
+    assert [shard_plan(n, world, r) for r in range(world)] == [(a, b - a) for a, b in blocks]
 
 
 def test_two_rank_gloo_shard_and_gather(tmp_path):
@@ -34,7 +36,7 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
         import os, sys
         sys.path.insert(0, {str(ROOT)!r})
         import numpy as np, torch, torch.distributed as dist
-        from xsdba_amd.sharding import shard_bounds, shard_cells, gather_cells
+        from xsdba_amd.sharding import shard_bounds, shard_cells, shard_plan, gather_cells
         dist.init_process_group("gloo")
         rank, world = dist.get_rank(), dist.get_world_size()
         n_cell, T = 11, 5

@@ -27,7 +27,7 @@ SYMBOLS = [
     "xsdba_hip_abi_version", "xsdba_hip_device_count", "xsdba_hip_create", "xsdba_hip_destroy",
     "xsdba_hip_last_error", "xsdba_hip_synchronize", "xsdba_hip_get_stream", "xsdba_hip_malloc", "xsdba_hip_free",
     "xsdba_hip_memcpy_h2d", "xsdba_hip_memcpy_d2h", "xsdba_hip_memset", "xsdba_hip_host_register",
-    "xsdba_hip_host_unregister", "xsdba_hip_memcpy_async", "xsdba_hip_event_record", "xsdba_hip_stream_wait_event", "xsdba_hip_event_synchronize", "xsdba_hip_profile_enable",
+    "xsdba_hip_host_unregister", "xsdba_hip_memcpy_async", "xsdba_hip_event_record", "xsdba_hip_stream_wait_event", "xsdba_hip_event_synchronize", "xsdba_hip_shard_plan", "xsdba_hip_comm_unique_id", "xsdba_hip_comm_init", "xsdba_hip_comm_info", "xsdba_hip_gather", "xsdba_hip_comm_destroy", "xsdba_hip_profile_enable",
     "xsdba_hip_profile_read", "xsdba_hip_timer_start", "xsdba_hip_timer_stop", "xsdba_hip_quantile_groups",
     "xsdba_hip_eqm_train", "xsdba_hip_dqm_train", "xsdba_hip_qm_adjust", "xsdba_hip_qm_adjust_linear2d", "xsdba_hip_qm_adjust_cubic2d", "xsdba_hip_dqm_adjust",
     "xsdba_hip_qdm_adjust", "xsdba_hip_tail_mask", "xsdba_hip_jitter", "xsdba_hip_adapt_freq", "xsdba_hip_group_means", "xsdba_hip_scaling_adjust", "xsdba_hip_loci_train", "xsdba_hip_loci_adjust", "xsdba_hip_rank_groups", "xsdba_hip_polydetrend_trend", "xsdba_hip_polydetrend_fit", "xsdba_hip_series_correction", "xsdba_hip_rolling_mean", "xsdba_hip_synth_series", "xsdba_hip_vecquantiles",

@@ -1,5 +1,6 @@
 // api.hip — host side of libxsdba_hip.so: context, group plans, staging, launches, C ABI (include/xsdba_hip.h).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -89,6 +90,8 @@ struct xsdba_hip_ctx {
     hipEvent_t user_ev[16] = {};  // event_record / stream_wait_event slots, created on first use
     int lds_limit = 160 * 1024;
     int n_cu = 256;
+    void *comm = nullptr;  // ncclComm_t once xsdba_hip_comm_init has run
+    int comm_rank = -1, comm_size = 0;
 };
 
 namespace {
@@ -1371,6 +1374,7 @@ API int xsdba_hip_destroy(xsdba_hip_ctx *ctx)
     if (!ctx) return 0;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->comm) (void)xsdba_hip_comm_destroy(ctx);
     for (auto &p : ctx->plans) free_plan(p.get());
     for (auto &b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (void *p : ctx->user_allocs) (void)hipFree(p);
@@ -1479,6 +1483,148 @@ API int xsdba_hip_event_record(xsdba_hip_ctx *ctx, int slot)
     if (slot < 0 || slot >= 16) return fail(XSDBA_E_ARG, "event slot %d out of range [0,16)", slot);
     if (!ctx->user_ev[slot]) HIP_TRY(hipEventCreateWithFlags(&ctx->user_ev[slot], hipEventDisableTiming));
     HIP_TRY(hipEventRecord(ctx->user_ev[slot], ctx->stream));
+    return 0;
+}
+
+// ---- multi-GPU: RCCL through dlopen (no link-time dependency) ---------------------------------------------------------
+namespace {
+struct Id128 { char b[XSDBA_COMM_ID_BYTES]; };  // ncclUniqueId (passed by value)
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
+    int (*CommUserRank)(void *, int *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return 0;
+    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(XSDBA_E_ARG, "librccl.so not found (%s): the multi-GPU gather needs RCCL", dlerror());
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+    g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
+    g_rccl.GroupStart = (decltype(g_rccl.GroupStart))sym("ncclGroupStart");
+    g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd))sym("ncclGroupEnd");
+    g_rccl.Send = (decltype(g_rccl.Send))sym("ncclSend");
+    g_rccl.Recv = (decltype(g_rccl.Recv))sym("ncclRecv");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.CommCount || !g_rccl.CommUserRank ||
+        !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.Send || !g_rccl.Recv || !g_rccl.GetErrorString) {
+        dlclose(h);
+        return fail(XSDBA_E_ARG, "librccl.so lacks a required entry point");
+    }
+    g_rccl.lib = h;
+    return 0;
+}
+
+#define RCCL_TRY(expr)                                                                                          \
+    do {                                                                                                        \
+        int r_ = (expr);                                                                                        \
+        if (r_ != 0) return fail(XSDBA_E_ARG, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));               \
+    } while (0)
+
+void shard_block(int64_t n_cell, int n_ranks, int rank, int64_t *first, int64_t *count)
+{
+    const int64_t base = n_cell / n_ranks, rem = n_cell % n_ranks;
+    *first = rank * base + std::min<int64_t>(rank, rem);
+    *count = base + (rank < rem ? 1 : 0);
+}
+}  // namespace
+
+API int xsdba_hip_shard_plan(int64_t n_cell, int n_ranks, int rank, int64_t *first_cell, int64_t *n_local)
+{
+    if (n_cell < 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks || !first_cell || !n_local)
+        return fail(XSDBA_E_ARG, "bad shard_plan arguments (n_cell %lld, n_ranks %d, rank %d)", (long long)n_cell, n_ranks, rank);
+    shard_block(n_cell, n_ranks, rank, first_cell, n_local);
+    return 0;
+}
+
+API int xsdba_hip_comm_unique_id(void *id)
+{
+    if (!id) return fail(XSDBA_E_ARG, "null id buffer");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id));
+    return 0;
+}
+
+API int xsdba_hip_comm_destroy(xsdba_hip_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+        ctx->comm_rank = -1;
+        ctx->comm_size = 0;
+    }
+    return 0;
+}
+
+API int xsdba_hip_comm_init(xsdba_hip_ctx *ctx, const void *id, int rank, int n_ranks)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(XSDBA_E_ARG, "bad comm_init arguments");
+    if ((rc = rccl_load())) return rc;
+    if (ctx->comm && (rc = xsdba_hip_comm_destroy(ctx))) return rc;
+    Id128 tok;
+    memcpy(tok.b, id, XSDBA_COMM_ID_BYTES);
+    HIP_TRY(hipSetDevice(ctx->device));
+    RCCL_TRY(g_rccl.CommInitRank(&ctx->comm, n_ranks, tok, rank));
+    RCCL_TRY(g_rccl.CommUserRank(ctx->comm, &ctx->comm_rank));
+    RCCL_TRY(g_rccl.CommCount(ctx->comm, &ctx->comm_size));
+    return 0;
+}
+
+API int xsdba_hip_comm_info(xsdba_hip_ctx *ctx, int *rank, int *n_ranks)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (rank) *rank = ctx->comm_rank;
+    if (n_ranks) *n_ranks = ctx->comm_size;
+    return 0;
+}
+
+API int xsdba_hip_gather(xsdba_hip_ctx *ctx, const void *send, int64_t n_local, int64_t row_elems, int dtype, void *recv,
+                         int64_t n_cell, int root)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->comm) return fail(XSDBA_E_ARG, "xsdba_hip_comm_init has not been called on this context");
+    if (root < 0 || root >= ctx->comm_size || row_elems <= 0 || n_cell < 0) return fail(XSDBA_E_ARG, "bad gather arguments");
+    const size_t esz = dtype == XSDBA_F32 ? 4 : (dtype == XSDBA_F64 ? 8 : 0);
+    if (!esz) return fail(XSDBA_E_ARG, "dtype must be XSDBA_F32 or XSDBA_F64");
+    const int nccl_dt = dtype == XSDBA_F32 ? 7 : 8;  // ncclFloat32 / ncclFloat64
+    int64_t first, count;
+    shard_block(n_cell, ctx->comm_size, ctx->comm_rank, &first, &count);
+    if (count != n_local) return fail(XSDBA_E_ARG, "rank %d owns %lld cells of %lld, not %lld", ctx->comm_rank, (long long)count, (long long)n_cell, (long long)n_local);
+    if (n_local && (!send || !is_device_ptr(send))) return fail(XSDBA_E_ARG, "send must be a device buffer");
+    if (ctx->comm_rank == root && n_cell && (!recv || !is_device_ptr(recv))) return fail(XSDBA_E_ARG, "recv must be a device buffer on the root");
+    RCCL_TRY(g_rccl.GroupStart());
+    if (ctx->comm_rank == root)
+        for (int r = 0; r < ctx->comm_size; r++) {
+            int64_t f, c;
+            shard_block(n_cell, ctx->comm_size, r, &f, &c);
+            if (c) RCCL_TRY(g_rccl.Recv((char *)recv + (size_t)f * row_elems * esz, (size_t)c * row_elems, nccl_dt, r, ctx->comm, ctx->stream));
+        }
+    if (n_local) RCCL_TRY(g_rccl.Send(send, (size_t)n_local * row_elems, nccl_dt, root, ctx->comm, ctx->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
     return 0;
 }
 
