@@ -9,8 +9,9 @@ window=31), kind "+", 30 years of daily data (10950 noleap days), nquantiles 20,
 data-path collective).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time | dqm_doy31_nan
 (BASELINE configs[4]: use --days 21900).
 
-N > 1: launched by torch.distributed.run, one process per GPU; torch is used only for the rendezvous,
-the barrier and the MAX over ranks (and the optional final RCCL gather of scen, timed separately).
+N > 1: launched by torch.distributed.run, one process per GPU; torch is used only for the rendezvous, the barrier and the
+MAX over ranks (CPU tensors over gloo); the one collective of the path, the final gather of scen (--gather, timed
+separately and verified), is the library's own RCCL call over xGMI, straight from the device buffers.
 """
 from __future__ import annotations
 
@@ -89,7 +90,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     dist = None
-    backend = os.environ.get("XSDBA_BENCH_BACKEND", "nccl")  # "gloo": code-path check of N>1 on a 1-GPU box
+    # torch.distributed is rendezvous / barrier / MAX-over-ranks plumbing only, on CPU tensors ("gloo"): the process then
+    # runs ONE HIP runtime — the system one this library is built on — and the data-path collective (the final gather) is the
+    # library's own RCCL call (xsdba_hip_gather).  XSDBA_BENCH_BACKEND=nccl routes the plumbing through torch's bundled RCCL
+    # instead (a second HIP runtime in the process).
+    backend = os.environ.get("XSDBA_BENCH_BACKEND", "gloo")
     from xsdba_amd import _lib as xlib
 
     ndev = max(xlib.device_count(), 1)
@@ -192,7 +197,16 @@ def main():
         from xsdba_amd.sharding import comm_info, gather_device, init_comm, shard_plan
 
         scen_dev = outs[-1] if method != "dqm" else outs[3]
-        init_comm(ctx, rank, world)
+        # (RCCL prints a version banner on stdout when its first communicator comes up: stdout belongs to the JSON line)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            init_comm(ctx, rank, world)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         r_rccl, n_rccl = comm_info(ctx)
         assert (r_rccl, n_rccl) == (rank, world), (r_rccl, n_rccl)
         assert shard_plan(C * world, world, rank) == (rank * C, C)

@@ -1507,7 +1507,21 @@ Rccl g_rccl;
 int rccl_load()
 {
     if (g_rccl.lib) return 0;
-    void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    // RCCL must come from the SAME ROCm as the HIP runtime this library runs on: a bare dlopen("librccl.so") may find another
+    // copy first (a Python wheel's bundled one, built against its own libamdhip64 — its communicator then sees no device).
+    // So: the directory the loaded libamdhip64 lives in first, then the loader's search path.
+    void *h = nullptr;
+    Dl_info info;
+    if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+        std::string dir(info.dli_fname);
+        const size_t slash = dir.rfind('/');
+        if (slash != std::string::npos) {
+            dir.resize(slash + 1);
+            h = dlopen((dir + "librccl.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen((dir + "librccl.so.1").c_str(), RTLD_NOW | RTLD_GLOBAL);
+        }
+    }
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) return fail(XSDBA_E_ARG, "librccl.so not found (%s): the multi-GPU gather needs RCCL", dlerror());
@@ -1616,14 +1630,24 @@ API int xsdba_hip_gather(xsdba_hip_ctx *ctx, const void *send, int64_t n_local, 
     if (count != n_local) return fail(XSDBA_E_ARG, "rank %d owns %lld cells of %lld, not %lld", ctx->comm_rank, (long long)count, (long long)n_cell, (long long)n_local);
     if (n_local && (!send || !is_device_ptr(send))) return fail(XSDBA_E_ARG, "send must be a device buffer");
     if (ctx->comm_rank == root && n_cell && (!recv || !is_device_ptr(recv))) return fail(XSDBA_E_ARG, "recv must be a device buffer on the root");
+    // one group of point-to-point transfers; every block travels in pieces of at most 2^28 elements (1 GiB of float32):
+    // sender and receiver cut their block the same way, so the pieces pair up in order
+    const size_t PIECE = (size_t)1 << 28;
     RCCL_TRY(g_rccl.GroupStart());
     if (ctx->comm_rank == root)
         for (int r = 0; r < ctx->comm_size; r++) {
             int64_t f, c;
             shard_block(n_cell, ctx->comm_size, r, &f, &c);
-            if (c) RCCL_TRY(g_rccl.Recv((char *)recv + (size_t)f * row_elems * esz, (size_t)c * row_elems, nccl_dt, r, ctx->comm, ctx->stream));
+            const size_t total = (size_t)c * row_elems;
+            char *base = (char *)recv + (size_t)f * row_elems * esz;
+            for (size_t o = 0; o < total; o += PIECE)
+                RCCL_TRY(g_rccl.Recv(base + o * esz, std::min(PIECE, total - o), nccl_dt, r, ctx->comm, ctx->stream));
         }
-    if (n_local) RCCL_TRY(g_rccl.Send(send, (size_t)n_local * row_elems, nccl_dt, root, ctx->comm, ctx->stream));
+    {
+        const size_t total = (size_t)n_local * row_elems;
+        for (size_t o = 0; o < total; o += PIECE)
+            RCCL_TRY(g_rccl.Send((const char *)send + o * esz, std::min(PIECE, total - o), nccl_dt, root, ctx->comm, ctx->stream));
+    }
     RCCL_TRY(g_rccl.GroupEnd());
     return 0;
 }
