@@ -66,3 +66,41 @@ def test_trained_object_from_file(tmp_path):
         np.testing.assert_array_equal(dqm.ds[name].values, dqm2.ds[name].values)
     assert repr(dqm2) == repr(dqm)
     np.testing.assert_array_equal(dqm2.adjust(sim).values, p.values)
+
+
+def test_cf_time_decoding_general_epochs(tmp_path):
+    """xarray writes 'days since <first timestamp>' or hours: any '<unit> since <date>' epoch decodes, the time of day survives
+    a round trip, and the julian calendar is refused by name"""
+    from scipy.io import netcdf_file
+
+    from xsdba_amd.io import open_dataset, to_netcdf
+
+    def write(path, values, units, calendar):
+        with netcdf_file(str(path), "w", version=2) as f:
+            f.createDimension("time", len(values))
+            t = f.createVariable("time", "d", ("time",))
+            t[:] = values
+            t.units = units
+            t.calendar = calendar
+            v = f.createVariable("x", "f", ("time",))
+            v[:] = np.arange(len(values), dtype=np.float32)
+
+    p = tmp_path / "hours.nc"
+    write(p, [12.0, 36.0, 60.0], "hours since 2001-02-27 00:00:00", "noleap")  # daily data stamped at noon
+    ds = open_dataset(p)
+    idx = ds["x"].coords["time"].index
+    assert list(idx.month) == [2, 2, 3] and list(idx.day) == [27, 28, 1]  # noleap: no Feb 29
+    np.testing.assert_allclose(idx.frac, 0.5)
+    to_netcdf(ds, tmp_path / "again.nc")
+    idx2 = open_dataset(tmp_path / "again.nc")["x"].coords["time"].index
+    assert idx2.equals(idx) and np.allclose(idx2.numeric_ns, idx.numeric_ns)
+
+    p = tmp_path / "std.nc"
+    write(p, [0.5, 1.5], "days since 1999-12-31", "proleptic_gregorian")
+    t = open_dataset(p)["x"].coords["time"].values
+    assert t[0] == np.datetime64("1999-12-31T12:00:00") and t[1] == np.datetime64("2000-01-01T12:00:00")
+
+    p = tmp_path / "jul.nc"
+    write(p, [0.0], "days since 2000-01-01", "julian")
+    with pytest.raises(NotImplementedError, match="julian"):
+        open_dataset(p)

@@ -36,12 +36,16 @@ class TimeIndex:
     """Calendar fields of a 1-D time axis + a float64 numeric axis (ns since 1970-01-01 in its calendar,
     the abscissa xarray's polyfit uses, detrending.py:202-203)."""
 
-    def __init__(self, year, month, day, calendar: str = "standard", values=None):
+    def __init__(self, year, month, day, calendar: str = "standard", values=None, frac=None):
+        if _canon(calendar) == "julian":
+            raise NotImplementedError("the 'julian' calendar is not supported (standard / proleptic_gregorian, noleap, all_leap, 360_day are)")
         self.year = np.asarray(year, np.int64)
         self.month = np.asarray(month, np.int64)
         self.day = np.asarray(day, np.int64)
         self.calendar = calendar
         self._values = values
+        # time of day as a fraction of the day (non-standard calendars: datetime64 values carry it themselves); None = midnight
+        self.frac = None if frac is None or not np.any(frac) else np.asarray(frac, np.float64)
 
     def __len__(self):
         return self.year.size
@@ -94,7 +98,10 @@ class TimeIndex:
     def numeric_ns(self) -> np.ndarray:
         if self._values is not None and np.issubdtype(np.asarray(self._values).dtype, np.datetime64):
             return np.asarray(self._values).astype("datetime64[ns]").astype(np.int64).astype(np.float64)
-        return self.days_since_1970.astype(np.float64) * 86400e9
+        days = self.days_since_1970.astype(np.float64)
+        if self.frac is not None:
+            days = days + self.frac
+        return days * 86400e9
 
     def equals(self, other: "TimeIndex") -> bool:
         return (self.size == other.size and _canon(self.calendar) == _canon(other.calendar)
@@ -103,7 +110,7 @@ class TimeIndex:
 
     def __getitem__(self, key):
         v = None if self._values is None else np.asarray(self._values)[key]
-        return TimeIndex(self.year[key], self.month[key], self.day[key], self.calendar, v)
+        return TimeIndex(self.year[key], self.month[key], self.day[key], self.calendar, v, None if self.frac is None else self.frac[key])
 
     def __repr__(self):
         if self.size == 0:

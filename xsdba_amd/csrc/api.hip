@@ -61,6 +61,7 @@ struct Plan {
     int G = 0, W = 0;
     int max_row = 0, max_mem = 0;
     std::vector<int> row_ptr, row_idx, mem_ptr, mem_idx;
+    std::vector<int> g_host;  // the group of every time step (compared on a hash hit)
     int *d_gidx = nullptr, *d_row_ptr = nullptr, *d_row_idx = nullptr, *d_mem_ptr = nullptr, *d_mem_idx = nullptr;
     // fast train path (train_cell.hpp): rows as sorted sets, toggle lists between consecutive groups
     bool simple = false;  // no time index occurs twice in one group row
@@ -208,6 +209,14 @@ int upload_ints(xsdba_hip_ctx *ctx, const std::vector<int> &v, int **d)
     return 0;
 }
 
+void free_plan(Plan *p)
+{
+    (void)hipFree(p->d_gidx); (void)hipFree(p->d_row_ptr); (void)hipFree(p->d_row_idx);
+    (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
+    (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
+    if (p->d_tog64) (void)hipFree(p->d_tog64);
+}
+
 // base.py:232-272 — rolling(center=True, window).construct puts x[t' + j - window/2] in slot j of centre t';
 // groupby then collects the centres of each group.  row_idx keeps multiplicities (coarse group + window).
 int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G, int W, Plan **out)
@@ -223,10 +232,29 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
     uint64_t h = fnv(g.data(), (size_t)T * sizeof(int));
     int64_t meta[3] = {T, G, W};
     h = fnv(meta, sizeof meta, h);
-    for (auto &p : ctx->plans) if (p->hash == h && p->T == T && p->G == G && p->W == W) { *out = p.get(); return 0; }
+    for (size_t i = 0; i < ctx->plans.size(); i++) {
+        Plan *p = ctx->plans[i].get();
+        // (the hash only narrows the search: the group indexes themselves decide)
+        if (p->hash == h && p->T == T && p->G == G && p->W == W && !memcmp(p->g_host.data(), g.data(), (size_t)T * sizeof(int))) {
+            if (i + 1 != ctx->plans.size()) std::rotate(ctx->plans.begin() + i, ctx->plans.begin() + i + 1, ctx->plans.end());  // most recent last
+            *out = ctx->plans.back().get();
+            return 0;
+        }
+    }
+    // least recently used plans make room (a plan holds ~2 * T * W ints on the device); nothing is in flight on an evicted
+    // plan once the stream has drained
+    constexpr size_t MAX_PLANS = 16;
+    if (ctx->plans.size() >= MAX_PLANS) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        free_plan(ctx->plans.front().get());
+        ctx->plans.erase(ctx->plans.begin());
+    }
 
-    auto pl = std::make_unique<Plan>();
+    // (a plan that fails half-way gives its device arrays back)
+    struct PlanDeleter { void operator()(Plan *p) const { free_plan(p); delete p; } };
+    std::unique_ptr<Plan, PlanDeleter> pl(new Plan());
     pl->hash = h; pl->T = T; pl->G = G; pl->W = W;
+    pl->g_host = g;
     pl->row_ptr.assign((size_t)G + 1, 0);
     pl->mem_ptr.assign((size_t)G + 1, 0);
     const int hw = W / 2;
@@ -295,16 +323,8 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
     if ((rc = upload_ints(ctx, pl->mem_idx, &pl->d_mem_idx))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors must outlive the copies
     *out = pl.get();
-    ctx->plans.push_back(std::move(pl));
+    ctx->plans.push_back(std::unique_ptr<Plan>(pl.release()));
     return 0;
-}
-
-void free_plan(Plan *p)
-{
-    (void)hipFree(p->d_gidx); (void)hipFree(p->d_row_ptr); (void)hipFree(p->d_row_idx);
-    (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
-    (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
-    if (p->d_tog64) (void)hipFree(p->d_tog64);
 }
 
 // ---- series staging: any (host|device, strides) -> cell-major contiguous device view ---------------
@@ -330,6 +350,10 @@ int series_in(xsdba_hip_ctx *ctx, int slot_raw, int slot_cm, const void *x, int6
 {
     if (!x) return fail(XSDBA_E_ARG, "null series pointer");
     if (st <= 0 || sc <= 0) return fail(XSDBA_E_ARG, "strides must be positive");
+    // a HOST series is staged as exactly T * C dense elements: anything but the two dense layouts would be read past the copy
+    if (!is_device_ptr(x) && !((st == 1 && sc == T) || (sc == 1 && st == C) || C == 1 || T == 1))
+        return fail(XSDBA_E_ARG, "a host series must be dense: (stride_t, stride_c) = (1, n_time) or (n_cell, 1), got (%lld, %lld)",
+                    (long long)st, (long long)sc);
     const void *d;
     size_t nbytes = (size_t)T * (size_t)C * sizeof(R);
     int rc = stage_in(ctx, slot_raw, x, nbytes, &d);
@@ -487,7 +511,13 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
+            // timing aids that skip work (and so return wrong tables) exist in experiment builds only (-DXSDBA_DIAG): the release
+            // library never reads the variable
+#ifdef XSDBA_DIAG
             const int dbg = getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0;
+#else
+            const int dbg = 0;
+#endif
             auto go = [&](auto cfg, auto diag, auto dqm, auto t64) -> int {
                 constexpr int EPT = decltype(cfg)::value;
                 constexpr bool DIAG = decltype(diag)::value, DQM = decltype(dqm)::value, TOG64 = decltype(t64)::value;
@@ -566,7 +596,11 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
                                    flag_count, flag_list, C, pl->d_tog64, (unsigned char *)scratch,
+#ifdef XSDBA_DIAG
                                    getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
+#else
+                                   0);
+#endif
                 return check_launch("k_train_long");
             };
             using std::false_type;

@@ -3,8 +3,9 @@
 
 The image has no netCDF4 / h5netcdf / zarr; scipy ships a NetCDF-3 reader / writer (``scipy.io.netcdf_file``), the format
 xarray's own ``engine="scipy"`` reads and writes, so the files written here open with ``xarray.open_dataset`` and files
-written by xarray in NETCDF3 format open here.  CF conventions as xarray applies them: time as ``days since 1970-01-01``
-with a ``calendar`` attribute, strings as char arrays with a ``string<n>`` dimension, int64 stored as int32 (NetCDF-3 has no
+written by xarray in NETCDF3 format open here.  CF conventions as xarray applies them: time written as ``days since
+1970-01-01`` with a ``calendar`` attribute and read from any ``<days|hours|minutes|seconds> since <date>`` epoch (the time
+of day is kept), strings as char arrays with a ``string<n>`` dimension, int64 stored as int32 (NetCDF-3 has no
 64-bit integers), the ``_xsdba_adjustment`` JSON and the other attributes as text attributes.
 """
 from __future__ import annotations
@@ -90,19 +91,56 @@ def _cf_calendar(cal: str) -> str:
     return {"standard": "proleptic_gregorian"}.get(c, c)
 
 
-def _decode_time(days: np.ndarray, calendar: str):
+_UNIT_DAYS = {"days": 1.0, "day": 1.0, "d": 1.0, "hours": 1 / 24, "hour": 1 / 24, "hrs": 1 / 24, "hr": 1 / 24, "h": 1 / 24,
+              "minutes": 1 / 1440, "minute": 1 / 1440, "mins": 1 / 1440, "min": 1 / 1440,
+              "seconds": 1 / 86400, "second": 1 / 86400, "secs": 1 / 86400, "sec": 1 / 86400, "s": 1 / 86400}
+
+
+def _parse_cf_time_units(units: str):
+    """'<unit> since <YYYY-MM-DD[ HH:MM[:SS[.f]]]>' -> (length of the unit in days, (year, month, day), fraction of the
+    epoch's day)"""
+    unit, _, ref = units.partition(" since ")
+    unit = unit.strip().lower()
+    if unit not in _UNIT_DAYS:
+        raise NotImplementedError(f"time units {units!r}: the unit must be one of days / hours / minutes / seconds")
+    ref = ref.strip().replace("T", " ")
+    date, _, clock = ref.partition(" ")
+    try:
+        y, m, d = (int(p) for p in date.split("-"))
+        hh = mm = 0
+        ss = 0.0
+        if clock:
+            clock = clock.split()[0].rstrip("Z")  # (a trailing time zone field other than UTC is not honoured)
+            parts = clock.split(":")
+            hh, mm, ss = int(parts[0]), (int(parts[1]) if len(parts) > 1 else 0), (float(parts[2]) if len(parts) > 2 else 0.0)
+    except ValueError as err:
+        raise NotImplementedError(f"cannot parse the reference date of time units {units!r}") from err
+    return _UNIT_DAYS[unit], (y, m, d), (hh * 3600 + mm * 60 + ss) / 86400.0
+
+
+def _decode_time(values: np.ndarray, units: str, calendar: str):
+    """CF time decoding as xarray does it: any '<unit> since <date>' epoch, the time of day kept (datetime64[ns] for the
+    standard calendar, year / month / day fields + a day fraction for the others)."""
     cal = _canon(calendar)
-    d = np.floor(np.asarray(days, np.float64)).astype(np.int64)
+    if cal == "julian":
+        raise NotImplementedError("the 'julian' calendar is not supported")
+    scale, (y0, m0, d0), f0 = _parse_cf_time_units(units)
+    v = np.asarray(values, np.float64)
     if cal == "standard":
-        return np.datetime64("1970-01-01", "D") + d
+        epoch = np.datetime64(f"{y0:04d}-{m0:02d}-{d0:02d}", "ns") + np.timedelta64(int(round(f0 * 86400e9)), "ns")
+        return epoch + np.round(v * scale * 86400e9).astype("timedelta64[ns]")
     dpm = _DPM[cal]
     ylen = int(dpm.sum())
+    days = v * scale + f0 + ((y0 - 1970) * ylen + int(dpm[: m0 - 1].sum()) + d0 - 1)
+    d = np.floor(days + 1e-9).astype(np.int64)
+    frac = np.clip(days - d, 0.0, None)
+    frac[frac < 1e-9] = 0.0
     year = 1970 + d // ylen
     doy = d % ylen
     cum = np.concatenate([[0], np.cumsum(dpm)])
     month = np.searchsorted(cum, doy, side="right")
     day = doy - cum[month - 1] + 1
-    return TimeIndex(year, month, day, calendar)
+    return TimeIndex(year, month, day, calendar, frac=frac)
 
 
 def open_dataset(path) -> Dataset:
@@ -127,11 +165,9 @@ def open_dataset(path) -> Dataset:
         if dims == (name,):
             units = str(vattrs.get("units", ""))
             if " since " in units:
-                if not units.startswith("days since 1970-01-01"):
-                    raise NotImplementedError(f"time units {units!r}: only 'days since 1970-01-01' is decoded")
                 cal = vattrs.pop("calendar", "standard")
                 vattrs.pop("units")
-                coords[name] = Coordinate(name, _decode_time(a, {"proleptic_gregorian": "standard", "gregorian": "standard"}.get(cal, cal)), vattrs)
+                coords[name] = Coordinate(name, _decode_time(a, units, {"proleptic_gregorian": "standard", "gregorian": "standard"}.get(cal, cal)), vattrs)
             else:
                 coords[name] = Coordinate(name, a, vattrs)
     out = {}
