@@ -190,3 +190,29 @@ def test_select_many_cells_device_resident(hip):
     eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, 1, q, "*")
     assert_close(hq, ehq, rtol=0.0, what="hist_q")
     assert_close(af, eaf, rtol=0.0, what="af")
+
+
+@pytest.mark.parametrize("gname", ["time", "month", "season"])
+@pytest.mark.parametrize("dist,kind", [("normal", "+"), ("gamma", "*"), ("zero_inflated", "*"), ("rounded", "*"), ("small_int", "+"),
+                                       ("constant", "+"), ("inf", "+"), ("two_values", "*"), ("tiny_n", "+"), ("capped", "*")])
+def test_select_dqm_vs_oracle(hip, kernel, gname, dist, kind):
+    """dqm_train on un-windowed groups (_adjustment.py:150-190): group-mean normalisation + quantiles + scaling.  Within 2 ulp
+    of the oracle (float64 sums in another order); cells the shortcut cannot serve (negative multiplicative means, infinite
+    values) come back from the generic kernel."""
+    rng = np.random.default_rng(zlib.crc32(f"dqm{gname}{dist}".encode()))
+    C, T = 6, 3650
+    gidx, G = _groups(gname, T)
+    ref, hist = _draw(rng, dist, C, T)
+    if dist != "tiny_n":
+        ref[rng.random(ref.shape) < 0.02] = np.nan
+        hist[1, : T // 2] = np.nan
+        ref[2] = np.nan
+    q = _nodes(20)
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, 1, q, kind)
+    with np.errstate(all="ignore"):
+        eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, 1, q, kind)
+    scale = float(np.nanmax(np.abs(np.where(np.isfinite(ehq), ehq, np.nan)))) if np.isfinite(ehq).any() else 1.0
+    assert_close(sc, esc, rtol=3e-7, atol=1e-30, what="scaling")
+    assert_close(hq, ehq, rtol=3e-7, atol=3e-7 * scale, what="hist_q")
+    escale = float(np.nanmax(np.abs(np.where(np.isfinite(eaf), eaf, np.nan)))) if np.isfinite(eaf).any() else 1.0
+    assert_close(af, eaf, rtol=2e-6, atol=2e-6 * max(scale, escale), what="af")

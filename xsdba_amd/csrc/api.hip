@@ -465,7 +465,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         // un-windowed groups (group="time" / "time.month" / "time.season" ...): histogram multi-select, train_select.hpp.
         // XSDBA_HIP_TRAIN=rows pins the generic kernel, =sort the per-cell sort kernels (A/B runs, tests).
         const char *force = getenv("XSDBA_HIP_TRAIN");
-        const bool sel = (mode == 0 || mode == 1) && pl->W == 1 && pl->simple && G <= xs::SEL_MAXG &&
+        const bool sel = (mode == 0 || mode == 1 || mode == 2) && pl->W == 1 && pl->simple && G <= xs::SEL_MAXG &&
                          (int64_t)G * Q <= 4096 && T >= 64 && T <= 22 * 1024 &&
                          !(force && (!strcmp(force, "rows") || !strcmp(force, "sort")));
         if (sel) {
@@ -479,15 +479,18 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 constexpr int EPT2 = decltype(cfg)::value, LT = decltype(lt)::value;
                 constexpr int TP = 2 * EPT2 * xs::SEL_NT;
                 const size_t lds = xs::sel_layout(TP, G, Q, LT).bytes;
-                int rc2;
-                if ((rc2 = set_lds(xs::k_train_sel<EPT2, LT>, lds, ctx, "the multi-select tables"))) return rc2;
                 const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(EPT2 <= 11 ? 2 : 1, (size_t)ctx->lds_limit / lds));
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)per_cu * ctx->n_cu);  // blocks walk the cells grid-stride
-                LaunchScope ls(ctx, "k_train_sel");
-                hipLaunchKernelGGL((xs::k_train_sel<EPT2, LT>), dim3(nblk), dim3(xs::SEL_NT), lds, ctx->stream, (const float *)s0.dev,
-                                   (const float *)s1.dev, T, s0.sc, pl->d_gidx, G, (const float *)dq, Q, (int)kind, mode,
-                                   (float *)oaf.dev, (float *)ohq.dev, flag_count, flag_list, C);
-                return check_launch("k_train_sel");
+                auto launch = [&](auto kernel) -> int {
+                    int rc2;
+                    if ((rc2 = set_lds(kernel, lds, ctx, "the multi-select tables"))) return rc2;
+                    LaunchScope ls(ctx, "k_train_sel");
+                    hipLaunchKernelGGL(kernel, dim3(nblk), dim3(xs::SEL_NT), lds, ctx->stream, (const float *)s0.dev,
+                                       (const float *)s1.dev, T, s0.sc, pl->d_gidx, G, (const float *)dq, Q, (int)kind, mode,
+                                       (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C);
+                    return check_launch("k_train_sel");
+                };
+                return mode == 2 ? launch(xs::k_train_sel<EPT2, LT, true>) : launch(xs::k_train_sel<EPT2, LT, false>);
             };
             using std::integral_constant;
             auto pick = [&](auto cfg) -> int {

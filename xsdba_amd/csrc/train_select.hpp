@@ -31,7 +31,7 @@ namespace xs {
 
 struct SelLayout {
     int NT, TP, G, Q, NB, log2nb;
-    size_t off_hist, off_skeys, off_pre, off_hq, off_gmass, off_red, bytes;
+    size_t off_hist, off_skeys, off_pre, off_hq, off_gmass, off_gmu, off_red, bytes;
 };
 
 constexpr int SEL_NT = 512, SEL_CAPBIN = 61, SEL_MAXG = 32;
@@ -52,6 +52,7 @@ __host__ __device__ inline SelLayout sel_layout(int TP, int G, int Q, int log2to
     L.off_pre = take((size_t)(SEL_NT + 1) * 4);
     L.off_hq = take((size_t)G * Q * 4);
     L.off_gmass = take((size_t)2 * SEL_MAXG * 4);
+    L.off_gmu = take((size_t)2 * SEL_MAXG * 4);  // DQM: group means of hist, ref
     L.off_red = take(64 * 4);
     L.bytes = o;
     return L;
@@ -121,12 +122,16 @@ template <int N> __device__ __forceinline__ void sel_sorted_pick2(const uint32_t
 }
 
 // mode 0: quantiles of x0 -> out_hq.  mode 1 (eqm_train): x1 = hist -> out_hq, x0 = ref -> af = corr(hist_q, ref_q).
+// mode 2 (dqm_train, DQM = true; _adjustment.py:150-190): the same on the series normalised by their group means — order
+// statistics commute with the monotone normalisation, so they are selected on the raw values and normalised afterwards;
+// scaling = corr(mean(hist), mean(ref)).  Cells where that argument fails (non-finite mean, non-positive multiplicative
+// mean, inf - inf in the interpolation) are appended to flag_list like the sort-based kernels do.
 // LT: log2 of the number of histogram bins over all groups (14: 32 KB of LDS)
-template <int EPT2, int LT>
+template <int EPT2, int LT, bool DQM = false>
 __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ gidx, int G,
     const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af, float *__restrict__ out_hq,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C)
+    float *__restrict__ scaling, int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C)
 {
     constexpr int NT = SEL_NT, NE = 2 * EPT2, TP = NE * NT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -137,6 +142,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
     uint32_t *pre = reinterpret_cast<uint32_t *>(smem + L.off_pre);
     float *hqk = reinterpret_cast<float *>(smem + L.off_hq);
     uint32_t *gmass = reinterpret_cast<uint32_t *>(smem + L.off_gmass);  // [g][0: == kmin, 1: == kmax]
+    float *gmu = reinterpret_cast<float *>(smem + L.off_gmu);            // DQM: [0: hist, 1: ref][g] group means
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + L.off_red);
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -298,7 +304,9 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
             if (XS_SEL_STOP == 3) { if (hist[tid] == 0x12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
             // ---------------- D. scatter: every key to its bin's place (counting sort by bin) ----------------
-            if (shift != 0) {  // (shift == 0: a bin is one key, the table alone answers)
+            // (shift == 0: a bin is one key and the table alone answers — unless the group sums of DQM need the keys laid out)
+            const bool scattered = DQM || shift != 0;
+            if (scattered) {
                 uint32_t ret[NE];
 #pragma unroll
                 for (int i = 0; i < (NE + 3) / 4; i++) __asm__ volatile("" : "+v"(gpk[i]));
@@ -323,7 +331,24 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
             if (XS_SEL_STOP == 4) { if (skeys[tid] == 0x12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
             // ---------------- E. one thread per (group, quantile): bin, selection inside it, interpolation, stores ----------
-            // The table now holds every bin's END position (shift != 0) or still its start (shift == 0).
+            if (DQM) {
+                // group means: float64 sum of each group's contiguous slice of the bin-ordered keys (+ the extreme values that
+                // were counted apart), one wave per group, fixed reduction tree
+                for (int g = wid; g < G; g += NT / 64) {
+                    const int gs = (int)pre[g * tpg], ge = (int)pre[(g + 1) * tpg];
+                    double sum = 0.0;
+                    for (int i = gs + lane; i < ge; i += 64) sum += (double)from_key(skeys[i]);
+                    sum = wave_total_dpp(sum);
+                    if (lane == 0) {
+                        const int nlo = (int)gmass[2 * g], nhi = (int)gmass[2 * g + 1], n = nlo + (ge - gs) + nhi;
+                        if (nlo) sum += (double)nlo * (double)from_key(kmin);
+                        if (nhi) sum += (double)nhi * (double)from_key(kmax);
+                        gmu[arr * SEL_MAXG + g] = n ? (float)(sum / (double)n) : __builtin_nanf("");
+                    }
+                }
+                __syncthreads();
+            }
+            // The table now holds every bin's END position (scattered) or still its start (shift == 0, not scattered).
             for (int o = tid; o < G * Q; o += NT) {
                 const int g = o / Q, kq = o - g * Q;
                 const int gstart = (int)pre[g * tpg], gend = (int)pre[(g + 1) * tpg];
@@ -333,7 +358,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 // bin (index inside the group) whose keys hold absolute position pa
                 auto bin_of = [&](int pa) {
                     int b = 0;
-                    if (shift != 0) {  // END positions: the first bin whose end exceeds pa
+                    if (scattered) {  // END positions: the first bin whose end exceeds pa
                         for (int s = NB >> 1; s > 0; s >>= 1) b = (int)tab[b + s - 1] <= pa ? b + s : b;
                     } else {           // start positions: the last bin that starts at or before pa
                         for (int s = NB >> 1; s > 0; s >>= 1) b = (int)tab[b + s] <= pa ? b + s : b;
@@ -345,6 +370,13 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 bool two = false;
                 float gamma = 0.f;
                 if (n > 0) sel_ordinals(n, q[kq], o0, two, gamma);
+                float mu = 0.f, inv = 0.f;
+                if (DQM) {
+                    mu = gmu[arr * SEL_MAXG + g];
+                    inv = invert<float>(mu, kind);
+                    if (n > 0 && (!isfinite(mu) || (kind == '*' && !(inv > 0.f && isfinite(inv))))) flag_cell = true;
+                    if (kq == 0 && arr == 1) scaling[(size_t)c * G + g] = get_corr<float>(gmu[g], mu, kind);  // corr(mean(hist), mean(ref))
+                }
                 // first the quantile's own neighbours; a second round only for the reference's NaN rule (inf - inf): a[n - 1]
 #pragma nounroll
                 for (int round = 0; round < 2 && n > 0; round++) {
@@ -359,7 +391,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                     if (need0 || need1) {
                         const int pa = gstart + ((need0 ? od : o1) - nlo);  // the first position that has to be read
                         const int b = bin_of(pa);
-                        if (shift == 0) {
+                        if (!scattered) {
                             const uint32_t kb = kmin + (uint32_t)b;
                             if (need0) { k0 = kb; if (need1) k1 = kmin + (uint32_t)bin_of(pa + 1); }
                             else k1 = kb;
@@ -397,13 +429,15 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                         }
                     }
                     // ---- device_math.hpp::quantile_sorted with a(o0) = k0, a(o0 + 1) = k1
-                    const float v0 = from_key(k0), v1 = from_key(k1);
+                    float v0 = from_key(k0), v1 = from_key(k1);
+                    if (DQM) { v0 = apply_corr<float>(v0, inv, kind); v1 = apply_corr<float>(v1, inv, kind); }
                     if (round == 1) { res = v0; break; }
                     if (!two) { res = v0; break; }
                     const float diff = v1 - v0;
                     if (gamma >= 0.5f) res = (float)((double)v1 - (double)diff * (1.0 - (double)gamma));
                     else res = v0 + diff * gamma;
                     if (res == res) break;
+                    if (DQM) { flag_cell = true; break; }  // inf - inf: the generic kernel redoes the cell
                 }
                 const size_t oo = (size_t)c * G * Q + o;
                 if (mode == 0) out_hq[oo] = res;
