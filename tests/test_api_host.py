@@ -211,3 +211,22 @@ def test_broadcast_nearest_linear_cubic():
         c2 = u.broadcast(g2, x2, group=gr, interp="cubic")
     np.testing.assert_allclose(c2.values, u.broadcast(g2, x2, group=gr, interp="linear").values)
     np.testing.assert_allclose(c2.values[1], 2 * lin, rtol=1e-13)
+
+
+def test_grouper_week_like_reference():
+    """tests/test_base.py:76-120 with group="time.week": ISO weeks through get_index / Grouper.apply; year 2000 has 52 of them
+    (January 1st and 2nd belong to week 52 of 1999)"""
+    import datetime
+
+    T = 366
+    da = DataArray(np.arange(T, dtype=np.float64), ("time",), {"time": xs.date_range("2000-01-01", T).values})
+    grouper = xs.Grouper("time.week")
+    idx = grouper.get_index(da).values
+    exp = np.array([(datetime.date(2000, 1, 1) + datetime.timedelta(days=k)).isocalendar()[1] for k in range(T)])
+    np.testing.assert_array_equal(idx, exp)
+    out = grouper.apply("mean", da)
+    assert out.dims == ("week",) and out.sizes["week"] == 52
+    for w, v in zip(out.coords["week"].values, out.values):
+        np.testing.assert_allclose(v, np.arange(T)[exp == w].mean())
+    with pytest.raises(NotImplementedError):
+        xs.Grouper("time.week").get_index(DataArray(np.zeros(5), ("time",), {"time": xs.date_range("2000-01-01", 5, "noleap").values}))

@@ -190,6 +190,8 @@ class Grouper(Parametrizable):
         else:
             if self.prop == "season":
                 i = ind.month % 12 // 3
+            elif self.prop == "week":
+                i = ind.week
             elif self.prop in ("month", "dayofyear", "year", "day"):
                 i = getattr(ind, self.prop)
             else:
@@ -199,7 +201,7 @@ class Grouper(Parametrizable):
         return DataArray(np.asarray(i), dims=(self.dim,), coords={self.dim: da.coords[self.dim]}, name=self.prop)
 
     def n_groups(self, da=None) -> int:
-        return {"group": 1, "month": 12, "season": 4}.get(self.prop) or int(self.get_coordinate(da).size)
+        return {"group": 1, "month": 12, "season": 4, "week": 53}.get(self.prop) or int(self.get_coordinate(da).size)
 
     def group_index(self, da):
         """(0-based int32 group of every time step, number of groups): what the HIP kernels take as
@@ -276,6 +278,13 @@ class Grouper(Parametrizable):
                 coords = OrderedDict(parts[0].coords)
                 coords[self.dim] = ref.coords[self.dim]
                 return DataArray(out, parts[0].dims, coords, parts[0].attrs, parts[0].name)
+            if self.prop == "week":
+                # no fixed coordinate (the reference's get_coordinate knows none either): like its groupby, the weeks present
+                present = np.array([g for g, _ in pieces])
+                full = np.stack([p.values for p in parts]).astype(np.result_type(first.dtype, np.float32), copy=False)
+                coords = OrderedDict(first.coords)
+                coords["week"] = Coordinate("week", present + 1)
+                return DataArray(full, ("week",) + first.dims, coords, first.attrs, first.name)
             crd = self.get_coordinate(ref)
             full = np.full((crd.size,) + first.shape, np.nan, dtype=np.result_type(first.dtype, np.float32))
             for (g, _), p in zip(pieces, parts):

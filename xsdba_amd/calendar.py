@@ -79,6 +79,18 @@ class TimeIndex:
         return cum[np.arange(self.size), self.month - 1] + self.day
 
     @property
+    def week(self):
+        """ISO 8601 week number (1..53), what pandas' ``isocalendar().week`` gives (base.py:323-325); standard calendar only,
+        like the reference (xarray has no week accessor for cftime axes)"""
+        if _canon(self.calendar) != "standard":
+            raise NotImplementedError("week grouping needs the standard calendar (no ISO weeks on a cftime axis, as in the reference)")
+        d = np.array([np.datetime64(f"{y:04d}-{m:02d}-{dd:02d}") for y, m, dd in zip(self.year, self.month, self.day)]).astype("datetime64[D]")
+        dow = (d.astype(np.int64) + 3) % 7  # Monday = 0 (1970-01-01 was a Thursday)
+        thursday = d + (3 - dow).astype("timedelta64[D]")  # the Thursday of the same ISO week decides the ISO year
+        ystart = thursday.astype("datetime64[Y]").astype("datetime64[D]")
+        return ((thursday - ystart).astype(np.int64) // 7 + 1).astype(np.int64)
+
+    @property
     def is_leap_year(self):
         cal = _canon(self.calendar)
         if cal == "standard":
