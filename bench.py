@@ -273,6 +273,25 @@ def main():
             out["gather"] = gather_info
         if not args.no_api_level and not args.time_major:
             out["api_level"] = api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
+        if not args.no_api_level and not args.time_major and world == 1:
+            # secondary figure: the same step on (time, cell) cubes — what a (time, lat, lon) array is — through the same entry
+            # points (the library re-lays every series with a tiled transpose on the way in and out, charged to the step)
+            tm = [ctx.synth((C, T), np.float32, gen, i, seed, cell0, ncf, nif, time_major=True) for i in range(3)]
+            cm = (ref, hist, sim)
+            ref, hist, sim = tm
+            step()
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                step()
+            ctx.synchronize()
+            dt_tm = (time.perf_counter() - t1) / 3
+            out["time_major"] = {"value": round(C / dt_tm, 2), "unit": "grid-cells/s", "ms_per_step": round(dt_tm * 1e3, 3),
+                                 "vs_cell_major": round((C / dt_tm) / value, 4),
+                                 "note": "inputs (time, cell); results are written (cell, time); never the reported `value`"}
+            ref, hist, sim = cm
+            for a in tm:
+                a.free()
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
                                                args.cpu_seconds, args.time_major, rank_window)
@@ -338,8 +357,9 @@ def pmc_traffic(workload, cells, days, kernel):
     no PMC run matches the workload being benchmarked."""
     # the newest set first: "<round>_final_*", then the versioned sets in descending order (v10 before v9)
     def age(f):
-        m = re.search(r"r(\d+)_(final|v(\d+))", f.name)
-        return (int(m.group(1)), 10**6 if m.group(2) == "final" else int(m.group(3))) if m else (-1, -1)
+        m = re.search(r"r(\d+)_", f.name)
+        v = re.search(r"_v(\d+)", f.name)
+        return (int(m.group(1)), int(v.group(1)) if v else 10**6) if m else (-1, -1)  # "rNN_final_*" / "rNN_*" before "rNN_vK_*"
 
     for f in sorted((ROOT / "profiles").glob("*traffic*.json"), key=age, reverse=True):
         try:
