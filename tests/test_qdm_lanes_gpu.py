@@ -1,0 +1,112 @@
+"""k_qdm_lanes (qdm_adjust over exact groups of <= 32 members: a lane per group, members sorted in registers) against the
+oracle (reference _adjustment.py:783-886 / utils.py:573-638 restated) and against the generic kernel (XSDBA_HIP_QDM=count),
+bit for bit: ties anywhere and at the extremes (zero-inflated, capped, constant data), NaNs in sim, NaN factors (those
+cells fall back), -0.0, leap days (a 366th group with few members), time steps without a group, extrapolation "nan"."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _doy_index(T, leap=False):
+    if not leap:
+        return (np.arange(T) % 365).astype(np.int32), 365
+    g = np.empty(T, np.int32)
+    t, year = 0, 0
+    while t < T:
+        n = 366 if year % 4 == 0 else 365
+        m = min(n, T - t)
+        g[t:t + m] = np.arange(m)
+        t += m
+        year += 1
+    return g, 366
+
+
+def _case(name, C, T, seed):
+    rng = np.random.default_rng(seed)
+    gidx, G = _doy_index(T, leap=name == "leap")
+    doy = gidx.astype(np.float64)
+    sim = (5.0 + 3.0 * np.sin(2 * np.pi * doy / 365.0)[None, :] + rng.gamma(2.0, 2.0, (C, T))).astype(np.float32)
+    if name == "zero_inflated":
+        sim[rng.random((C, T)) < 0.45] = 0.0
+    elif name == "capped":
+        sim = np.minimum(sim, np.float32(9.0))
+    elif name == "rounded":
+        sim = np.round(sim)
+    elif name == "constant":
+        sim[:] = 3.0
+        sim[1] = 0.0
+    elif name == "nan_sim":
+        sim[rng.random((C, T)) < 0.08] = np.nan
+        sim[2] = np.nan
+        sim[3, 10:] = np.nan
+    elif name == "neg_zero":
+        sim[rng.random((C, T)) < 0.2] = -0.0
+        sim[rng.random((C, T)) < 0.2] = 0.0
+        sim -= np.float32(0.0)
+    elif name == "ungrouped":
+        gidx = gidx.copy()
+        gidx[rng.random(T) < 0.05] = -1
+    return sim, gidx, G
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_inflated", "capped", "rounded", "constant", "nan_sim", "neg_zero", "leap", "ungrouped"])
+@pytest.mark.parametrize("kind,extrap,Q", [("*", "constant", 20), ("+", "nan", 15), ("*", "constant", 50)])
+def test_lanes_vs_oracle_and_generic(name, kind, extrap, Q):
+    import zlib
+
+    from xsdba_amd import hip
+
+    C, T = 12, 10950 if name != "leap" else 10958
+    sim, gidx, G = _case(name, C, T, zlib.crc32(f"{name}{kind}{Q}".encode()))
+    rng = np.random.default_rng(7)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+    os.environ.pop("XSDBA_HIP_QDM", None)
+    scen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind, want_sim_q=False)
+    os.environ["XSDBA_HIP_QDM"] = "count"
+    try:
+        gen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind, want_sim_q=False)
+    finally:
+        os.environ.pop("XSDBA_HIP_QDM", None)
+    exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind)
+    np.testing.assert_array_equal(np.asarray(scen).view(np.uint32), np.asarray(gen).view(np.uint32))
+    np.testing.assert_array_equal(np.asarray(scen), exp)
+
+
+def test_lanes_nan_factors_fall_back():
+    from xsdba_amd import hip
+
+    C, T, Q = 9, 7300, 20
+    sim, gidx, G = _case("plain", C, T, 5)
+    rng = np.random.default_rng(3)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+    af[1, 17, 3] = np.nan          # one node
+    af[4, 100:140] = np.nan        # whole rows: the 2-D nearest node lies in another group
+    af[7] = np.nan                 # nothing valid
+    scen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", "constant", "*", want_sim_q=False)
+    exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", "constant", "*")
+    np.testing.assert_array_equal(np.asarray(scen), exp)
+
+
+@pytest.mark.parametrize("G,members", [(40, 20), (70, 32), (130, 7)])
+def test_lanes_other_group_shapes(G, members):
+    """groups need not be days of the year: G groups of `members` time steps each, interleaved"""
+    from xsdba_amd import hip
+
+    C, Q = 5, 12
+    T = G * members
+    rng = np.random.default_rng(G)
+    gidx = rng.permutation(np.repeat(np.arange(G), members)).astype(np.int32)
+    sim = rng.gamma(2.0, 2.0, (C, T)).astype(np.float32)
+    sim[rng.random((C, T)) < 0.3] = 0.0
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+    scen, _ = hip.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "*", want_sim_q=False)
+    exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "*")
+    np.testing.assert_array_equal(np.asarray(scen), exp)

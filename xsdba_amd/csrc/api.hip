@@ -21,6 +21,7 @@
 #include "train_cell3.hpp"
 #include "train_cell.hpp"
 #include "qdm_cell.hpp"
+#include "qdm_lanes.hpp"
 #include "train_long.hpp"
 #include "train_cell_f64.hpp"
 #include "train_select.hpp"
@@ -67,6 +68,8 @@ struct Plan {
     bool simple = false;  // no time index occurs twice in one group row
     int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
+    int *d_mem_t32 = nullptr;  // [32][G] member slot -> time index (-1: none) when every group has <= 32 members (k_qdm_lanes)
+    bool has_ungrouped = false;  // some time step belongs to no group
 };
 
 struct ProfEntry {
@@ -215,6 +218,7 @@ void free_plan(Plan *p)
     (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
     (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
     if (p->d_tog64) (void)hipFree(p->d_tog64);
+    if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
 }
 
 // base.py:232-272 — rolling(center=True, window).construct puts x[t' + j - window/2] in slot j of centre t';
@@ -260,7 +264,7 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
     const int hw = W / 2;
     for (int64_t t = 0; t < T; t++) {
         int gg = g[(size_t)t];
-        if (gg < 0) continue;
+        if (gg < 0) { pl->has_ungrouped = true; continue; }
         if (gg >= G) return fail(XSDBA_E_ARG, "group_of_time[%lld] = %d out of range [0,%d)", (long long)t, gg, G);
         int64_t lo = std::max<int64_t>(0, t - hw), hi = std::min<int64_t>(T - 1, t - hw + W - 1);
         if ((int64_t)pl->row_ptr[gg + 1] + (hi - lo + 1) > (1ll << 30)) return fail(XSDBA_E_ROW_TOO_LONG, "group row too long");
@@ -312,6 +316,12 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
                 std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t64.begin() + (size_t)(i + 1) * 64);
             if ((rc = upload_ints(ctx, t64, &pl->d_tog64))) return rc;
         }
+    }
+    if (G > 1 && pl->max_mem <= 32) {  // member slots of the short exact groups, slot-major: lane g of k_qdm_lanes reads [y][g]
+        std::vector<int> mt((size_t)32 * G, -1);
+        for (int i = 0; i < G; i++)
+            for (int y = 0; y < pl->mem_ptr[i + 1] - pl->mem_ptr[i]; y++) mt[(size_t)y * G + i] = pl->mem_idx[(size_t)pl->mem_ptr[i] + y];
+        if ((rc = upload_ints(ctx, mt, &pl->d_mem_t32))) return rc;
     }
     if ((rc = upload_ints(ctx, row_sorted, &pl->d_row_sorted))) return rc;
     if ((rc = upload_ints(ctx, tog_ptr, &pl->d_tog_ptr))) return rc;
@@ -998,6 +1008,34 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         return check_launch("k_qdm_adjust");
     };
     bool fast = false;
+    if constexpr (std::is_same<R, float>::value) {
+        // exact groups of at most 32 members (one per year of a day-of-year grouping): a lane per group, the members sorted in
+        // registers (qdm_lanes.hpp).  XSDBA_HIP_QDM=count pins the generic kernel, =cell the sort kernel.
+        const char *force = getenv("XSDBA_HIP_QDM");
+        const size_t lds = xs::qdm_lanes_lds_bytes(T, G, Q);
+        if (!ranks_only && !sim_q && !rw && G > 1 && interp == XSDBA_INTERP_NEAREST && pl->d_mem_t32 && s.st == 1 && Q < xs::QL_NAN &&
+            T < (1ll << 24) && lds <= (size_t)ctx->lds_limit && !force) {
+            void *flags;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            if ((rc = set_lds(xs::k_qdm_lanes, lds, ctx, "the factor table + the adjusted series"))) return rc;
+            const int nthr = 64 * std::max(1, std::min(6, (G + 63) / 64));  // (two blocks of <= 6 waves per CU: 3 waves per SIMD, 168 VGPRs each)
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_limit / lds));
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)2 * per_cu * ctx->n_cu);
+            {
+                LaunchScope ls(ctx, "k_qdm_lanes");
+                hipLaunchKernelGGL(xs::k_qdm_lanes, dim3(nblk), dim3(nthr), lds, ctx->stream, (const float *)s.dev, T, C, s.sc,
+                                   (const float *)daf, (const float *)dqn, G, Q, pl->d_mem_t32, extrap, (int)kind, (float *)o.kernel_dst, T,
+                                   pl->has_ungrouped ? 1 : 0, flag_count, flag_list);
+                if ((rc = check_launch("k_qdm_lanes"))) return rc;
+            }
+            // cells with NaN factors (the own-row shortcut does not hold): generic kernel, device-side count
+            if ((rc = launch_generic(flag_list, flag_count, std::min<int64_t>(C, 256)))) return rc;
+            if ((rc = series_out_end<R>(ctx, &o, T, C)) || (rc = series_out_end<double>(ctx, &oq, T, C))) return rc;
+            return sync_if(ctx, o.copy_back || oq.copy_back || !is_device_ptr(sim));
+        }
+    }
     {
         // sort-based kernel (qdm_cell.hpp): any grouping at O(T log T) per cell instead of O(T * row length)
         const char *force = getenv("XSDBA_HIP_QDM");  // "count" pins the generic kernel (A/B runs, tests)

@@ -1,0 +1,225 @@
+// qdm_lanes.hpp — qdm_adjust for SHORT ranking rows (exact day-of-year groups: one member per year, <= 32 members), float32.
+//
+// _adjustment.qdm_adjust (_adjustment.py:783-886) ranks every value of sim inside its group (utils.rank, utils.py:573-638:
+// average ranks, NaN -> NaN, percent ranks rescaled with the extreme ranks) and looks the percent rank up on the quantile
+// axis of the group's factor row.  k_qdm_adjust sorts those rows on the cross-lane path (one row per 32 lanes) and lets
+// every element bisect its row in LDS; that is latency-bound (11.3 ms per 64 800 cells x 10 950 days).
+//
+// Here a LANE owns a group: its <= 32 members sit in 32 registers (coalesced loads — consecutive lanes, consecutive days of
+// the year), Batcher's odd-even merge network sorts the (key, time index) pairs without leaving the registers (191
+// compare-exchanges, no LDS, no cross-lane traffic), one forward and one backward sweep over the sorted registers give the
+// tie runs, i.e. 2 * (average rank) = start + end + 1 of each element.  The map (N, 2r) -> table node is the same for every
+// cell when the group's extreme values are not tied (pmin, pmax of the rescaling depend on N only): it is tabulated once per
+// block with the very float64 expressions the generic kernel evaluates per element, so an element costs one table byte, one
+// factor read and one multiply.  Groups with tied extremes evaluate those expressions directly (same results by
+// construction).  The adjusted values are parked by time index in LDS and leave in one coalesced sweep.
+//
+// Cells whose factor table holds a NaN (the nearest node of the element's own row is then not the 2-D nearest neighbour)
+// are appended to flag_list and redone by k_qdm_adjust, like the cells k_qdm_cell cannot finish.
+#pragma once
+#include "kernels.hpp"
+
+namespace xs {
+
+constexpr int QL_M = 32;               // members per ranking row (registers per lane)
+constexpr int QL_TW = 2 * QL_M + 2;    // row pitch of the node table: 2r lies in [2, 2N]; NaN rows reach N + 33
+constexpr int QL_NAN = 255;            // node code: the factor is NaN (extrapolation = "nan", undefined percent rank)
+
+__host__ __device__ inline size_t qdm_lanes_lds_bytes(int64_t T, int G, int Q)
+{
+    return (((size_t)G * Q + (size_t)Q + 3) & ~(size_t)3) * 4 + (((size_t)T + 3) & ~(size_t)3) * 4 + (size_t)(QL_M + 1) * QL_TW + 16;
+}
+
+// the node of the group's own row nearest to the rescaled percent rank: utils.rank's formula and interp2d_nearest
+// (device_math.hpp) on a NaN-free row of the shared quantile axis, expression for expression
+__device__ __forceinline__ int ql_code(int twor, int N, double pmin, double pmax, const float *xq, int Q, int extrap)
+{
+    const double r = (double)twor / 2.0;  // = less + (equal + 1) / 2, exact
+    const double pr = r / (double)N;
+    const double sq = pmax * (pr - pmin) / (pmax - pmin);
+    if (sq != sq) return QL_NAN;
+    if (sq < (double)xq[0]) return extrap == 0 ? 0 : QL_NAN;
+    if (sq > (double)xq[Q - 1]) return extrap == 0 ? Q - 1 : QL_NAN;
+    int w;
+    (void)row_nearest<float, double>(sq, xq, Q, &w);
+    return w;
+}
+
+__global__ __launch_bounds__(384, 3) void k_qdm_lanes(const float *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
+                                                    const float *__restrict__ af, const float *__restrict__ quantiles, int G, int Q,
+                                                    const int *__restrict__ mem_t32, int extrap, int kind, float *__restrict__ scen,
+                                                    int64_t osc, int has_ungrouped, int *__restrict__ flag_count,
+                                                    int *__restrict__ flag_list)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float *ys = reinterpret_cast<float *>(smem);                                    // [G][Q] the cell's factors
+    float *xq = ys + (size_t)G * Q;                                                  // [Q] the quantile axis
+    float *stage = ys + ((((size_t)G * Q + (size_t)Q) + 3) & ~(size_t)3);            // [T] adjusted values by time index
+    unsigned char *codes = reinterpret_cast<unsigned char *>(stage + (((size_t)T + 3) & ~(size_t)3));  // [QL_M + 1][QL_TW]
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nwave = nt >> 6;
+    const int n = G * Q;
+
+    // ---- once per block: the quantile axis and the (N, 2r) -> node table of groups whose extremes are not tied
+    bool bad_axis = false;
+    for (int i = tid; i < Q; i += nt) { const float v = quantiles[i]; xq[i] = v; bad_axis |= v != v; }
+    __syncthreads();
+    // (the own row holds the 2-D nearest node only while no node of it is farther than one group step)
+    if (tid == 0 && !((double)xq[Q - 1] - (double)xq[0] <= 1.0)) bad_axis = true;
+    bad_axis = __syncthreads_or(bad_axis ? 1 : 0) != 0;
+    for (int i = tid; i < (QL_M + 1) * QL_TW; i += nt) {
+        const int N = i / QL_TW, tw = i - N * QL_TW;
+        int code = QL_NAN;
+        if (!bad_axis && N >= 1 && tw >= 2 && tw <= 2 * N) {
+            const double Nd = (double)N;
+            const double pmin = ((1.0 + 1.0) / 2.0) / Nd, pmax = ((Nd - 1.0) + (1.0 + 1.0) / 2.0) / Nd;
+            code = ql_code(tw, N, pmin, pmax, xq, Q, extrap);
+        }
+        codes[i] = (unsigned char)code;
+    }
+    __syncthreads();
+
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        // ---- the cell's factors (coalesced, NB loads in flight per thread)
+        bool has_nan = bad_axis;
+        {
+            const float *yq = af + (size_t)c * n;
+            constexpr int NB = 8;
+            for (int i0 = tid; i0 < n; i0 += NB * nt) {
+                float yv[NB];
+#pragma unroll
+                for (int k = 0; k < NB; k++) yv[k] = yq[min(i0 + k * nt, n - 1)];
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int i = i0 + k * nt;
+                    if (i < n) { ys[i] = yv[k]; has_nan |= yv[k] != yv[k]; }
+                }
+            }
+        }
+        if (has_ungrouped)
+            for (int64_t t = tid; t < T; t += nt) stage[t] = nan_of<float>();
+        if (__syncthreads_or(has_nan ? 1 : 0)) {  // (the barrier also orders the table / NaN fill before the group pass)
+            if (tid == 0) { const int slot = atomicAdd(flag_count, 1); flag_list[slot] = (int)c; }
+            continue;
+        }
+        const char *xrow = reinterpret_cast<const char *>(sim + c * sc);
+        for (int g0 = wid * 64; g0 < G; g0 += nwave * 64) {
+            const int g = g0 + lane;
+            const bool gv = g < G;
+            uint32_t k[QL_M], p[QL_M];
+            {
+                int tt[QL_M];
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) tt[y] = gv ? mem_t32[(size_t)y * G + g] : -1;
+                float x[QL_M];
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) x[y] = *reinterpret_cast<const float *>(xrow + (uint32_t)(max(tt[y], 0) * 4));
+                // (every load is issued before the first value is looked at: pinned, or each one sinks into its `present` branch)
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) __asm__ volatile("" : "+v"(x[y]));
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) {
+                    const bool present = tt[y] >= 0;
+                    const uint32_t bits = __float_as_uint(x[y]);
+                    // -0.0 ranks as +0.0 (scipy compares values); its sign rides in bit 31 of the payload and returns at the end
+                    k[y] = present ? to_key(x[y] + 0.0f) : 0xFFFFFFFFu;
+                    p[y] = present ? ((uint32_t)tt[y] | (bits == 0x80000000u ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
+                }
+            }
+            // ---- Batcher's odd-even merge sort of the (key, payload) pairs, in registers.  A pair travels as ONE 64-bit word,
+            // key on top (equal keys are then ordered by payload, which no result depends on): a compare-exchange is one
+            // 64-bit compare and four selects, and the key and payload networks cannot drift apart in the schedule (as two
+            // 32-bit networks the compiler ran all the key min / max first and kept every intermediate key alive for the
+            // payload selects: 500 live registers)
+            {
+                uint64_t kp[QL_M];
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) kp[y] = ((uint64_t)k[y] << 32) | p[y];
+#pragma unroll
+                for (int pp = 1; pp < QL_M; pp *= 2)
+#pragma unroll
+                    for (int kk = pp; kk >= 1; kk /= 2)
+#pragma unroll
+                        for (int j = kk % pp; j <= QL_M - 1 - kk; j += 2 * kk)
+#pragma unroll
+                            for (int i = 0; i <= (kk - 1 < QL_M - j - kk - 1 ? kk - 1 : QL_M - j - kk - 1); i++)
+                                if ((i + j) / (2 * pp) == (i + j + kk) / (2 * pp)) {
+                                    const uint64_t va = kp[i + j], vb = kp[i + j + kk];
+                                    const bool sw = vb < va;
+                                    kp[i + j] = sw ? vb : va;
+                                    kp[i + j + kk] = sw ? va : vb;
+                                }
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) { k[y] = (uint32_t)(kp[y] >> 32); p[y] = (uint32_t)kp[y]; }
+            }
+            // ---- forward sweep: start of every tie run (bits 24-28 of the payload), valid count, start of the last valid run
+            int N = 0, st = 0, last_start = 0;
+#pragma unroll
+            for (int j = 0; j < QL_M; j++) {
+                if (j > 0) st = (k[j] == k[j - 1]) ? st : j;
+                p[j] |= (uint32_t)st << 24;
+                const bool valid = k[j] != 0xFFFFFFFFu;
+                N += valid ? 1 : 0;
+                last_start = valid ? st : last_start;
+            }
+            const bool untied = (N < 2 || k[1] != k[0]) && (N < 1 || last_start == N - 1);
+            const int gq = (gv ? g : 0) * Q;
+            // ---- backward sweep: end of every tie run; 2r = start + end + 1 replaces the start in bits 24-30 of the payload
+            {
+                int e = QL_M;
+#pragma unroll
+                for (int j = QL_M - 1; j >= 0; j--) {
+                    if (j < QL_M - 1) e = (k[j] == k[j + 1]) ? e : j + 1;
+                    const uint32_t twor = ((p[j] >> 24) & 31u) + (uint32_t)e + 1u;
+                    p[j] = (p[j] & 0x80FFFFFFu) | (twor << 24);  // (an absent slot keeps its 24 low bits set: t = 2^24 - 1 is never a time index)
+                }
+            }
+            auto park = [&](uint32_t kj, uint32_t pj, int code) __attribute__((always_inline)) {
+                const float a = code == QL_NAN ? nan_of<float>() : ys[gq + (code == QL_NAN ? 0 : code)];
+                const float v = __uint_as_float(__float_as_uint(from_key(kj)) | (pj & 0x80000000u));
+                const float out = apply_corr<float>(v, a, kind);
+                if ((pj & 0xFFFFFFu) != 0xFFFFFFu) stage[pj & 0xFFFFFFu] = out;
+            };
+            if (!__any(!untied)) {
+                // 2r -> node from the block's table -> factor -> adjusted value, parked by time index
+                const unsigned char *crow = codes + N * QL_TW;
+#pragma unroll
+                for (int j = 0; j < QL_M; j++) park(k[j], p[j], (int)crow[(p[j] >> 24) & 127u]);
+            } else {
+                // some group of this wave has tied extremes: its rescaling differs, the float64 expressions are evaluated per
+                // element (a rolled loop over the places; the place is wave-uniform, the registers are picked by a select chain)
+                int nmin = 1;
+                bool eq = true;
+#pragma unroll
+                for (int j = 1; j < QL_M; j++) { eq = eq && k[j] == k[0]; nmin += eq ? 1 : 0; }
+                const int nmax = N - last_start;
+                const double Nd = (double)N;
+                const double pmin = (((double)nmin + 1.0) / 2.0) / Nd;
+                const double pmax = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
+#pragma unroll 1
+                for (int j = 0; j < QL_M; j++) {
+                    uint32_t kj = 0u, pj = 0u;
+#pragma unroll
+                    for (int u = 0; u < QL_M; u++) { kj = u == j ? k[u] : kj; pj = u == j ? p[u] : pj; }
+                    const int twor = (int)((pj >> 24) & 127u);
+                    const int code = (kj != 0xFFFFFFFFu && twor <= 2 * N) ? ql_code(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN;
+                    park(kj, pj, code);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            float *orow = scen + c * osc;
+            constexpr int NB = 8;
+            for (int64_t t0 = tid; t0 < T; t0 += (int64_t)NB * nt) {
+                float v[NB];
+#pragma unroll
+                for (int kq = 0; kq < NB; kq++) { const int64_t t = t0 + (int64_t)kq * nt; v[kq] = stage[t < T ? t : T - 1]; }
+#pragma unroll
+                for (int kq = 0; kq < NB; kq++) { const int64_t t = t0 + (int64_t)kq * nt; if (t < T) orow[t] = v[kq]; }
+            }
+        }
+        __syncthreads();  // the next cell refills ys / stage
+    }
+}
+
+}  // namespace xs
