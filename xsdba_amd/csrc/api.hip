@@ -68,7 +68,7 @@ struct Plan {
     bool simple = false;  // no time index occurs twice in one group row
     int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
-    int *d_mem_t32 = nullptr;  // [32][G] member slot -> time index (-1: none) when every group has <= 32 members (k_qdm_lanes)
+    int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     bool has_ungrouped = false;  // some time step belongs to no group
 };
 
@@ -317,10 +317,17 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
             if ((rc = upload_ints(ctx, t64, &pl->d_tog64))) return rc;
         }
     }
-    if (G > 1 && pl->max_mem <= 32) {  // member slots of the short exact groups, slot-major: lane g of k_qdm_lanes reads [y][g]
-        std::vector<int> mt((size_t)32 * G, -1);
+    if (G > 1 && pl->max_mem <= 32 && T < 65535) {
+        // member slots of the short exact groups for k_qdm_lanes, slot-pair-major: word [y / 2][g] holds the time indexes of
+        // members y and y + 1 of group g, 16 bits each (0xFFFF: no such member)
+        std::vector<int> mt((size_t)16 * G, -1);
         for (int i = 0; i < G; i++)
-            for (int y = 0; y < pl->mem_ptr[i + 1] - pl->mem_ptr[i]; y++) mt[(size_t)y * G + i] = pl->mem_idx[(size_t)pl->mem_ptr[i] + y];
+            for (int y = 0; y < pl->mem_ptr[i + 1] - pl->mem_ptr[i]; y++) {
+                const uint32_t t = (uint32_t)pl->mem_idx[(size_t)pl->mem_ptr[i] + y];
+                uint32_t w = (uint32_t)mt[(size_t)(y / 2) * G + i];
+                w = (y & 1) ? ((w & 0x0000FFFFu) | (t << 16)) : ((w & 0xFFFF0000u) | t);
+                mt[(size_t)(y / 2) * G + i] = (int)w;
+            }
         if ((rc = upload_ints(ctx, mt, &pl->d_mem_t32))) return rc;
     }
     if ((rc = upload_ints(ctx, row_sorted, &pl->d_row_sorted))) return rc;
@@ -1012,22 +1019,26 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         // exact groups of at most 32 members (one per year of a day-of-year grouping): a lane per group, the members sorted in
         // registers (qdm_lanes.hpp).  XSDBA_HIP_QDM=count pins the generic kernel, =cell the sort kernel.
         const char *force = getenv("XSDBA_HIP_QDM");
-        const size_t lds = xs::qdm_lanes_lds_bytes(T, G, Q);
+        const int nchunk = (G + 63) / 64;
+        const int nw = 4;  // waves per block; any wave takes any (cell, chunk) item
+        const size_t lds = xs::qdm_lanes_lds_bytes(nw, Q, pl->max_mem);
         if (!ranks_only && !sim_q && !rw && G > 1 && interp == XSDBA_INTERP_NEAREST && pl->d_mem_t32 && s.st == 1 && Q < xs::QL_NAN &&
-            T < (1ll << 24) && lds <= (size_t)ctx->lds_limit && !force) {
+            T < 65535 && (int64_t)C * nchunk < (1ll << 31) - 1 && lds <= (size_t)ctx->lds_limit && !force) {
             void *flags;
-            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C * nchunk + 1), &flags))) return rc;
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
-            if ((rc = set_lds(xs::k_qdm_lanes, lds, ctx, "the factor table + the adjusted series"))) return rc;
-            const int nthr = 64 * std::max(1, std::min(6, (G + 63) / 64));  // (two blocks of <= 6 waves per CU: 3 waves per SIMD, 168 VGPRs each)
-            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)ctx->lds_limit / lds));
-            const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)2 * per_cu * ctx->n_cu);
+            // time steps in no group stay NaN (no lane owns them)
+            if (pl->has_ungrouped) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)o.kernel_dst, 0x7FC00000, (size_t)T * C, ctx->stream));
+            if ((rc = set_lds(xs::k_qdm_lanes, lds, ctx, "the factor rows + the member-order buffer"))) return rc;
+            // up to 256 VGPRs: two waves per SIMD, eight per CU
+            const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(8 / nw), (size_t)ctx->lds_limit / lds));
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)per_cu * ctx->n_cu);
             {
                 LaunchScope ls(ctx, "k_qdm_lanes");
-                hipLaunchKernelGGL(xs::k_qdm_lanes, dim3(nblk), dim3(nthr), lds, ctx->stream, (const float *)s.dev, T, C, s.sc,
-                                   (const float *)daf, (const float *)dqn, G, Q, pl->d_mem_t32, extrap, (int)kind, (float *)o.kernel_dst, T,
-                                   pl->has_ungrouped ? 1 : 0, flag_count, flag_list);
+                hipLaunchKernelGGL(xs::k_qdm_lanes, dim3(nblk), dim3(64 * nw), lds, ctx->stream, (const float *)s.dev, T, C, s.sc,
+                                   (const float *)daf, (const float *)dqn, G, Q, pl->d_mem_t32, pl->max_mem, extrap, (int)kind,
+                                   (float *)o.kernel_dst, T, flag_count, flag_list);
                 if ((rc = check_launch("k_qdm_lanes"))) return rc;
             }
             // cells with NaN factors (the own-row shortcut does not hold): generic kernel, device-side count

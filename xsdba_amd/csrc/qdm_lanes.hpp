@@ -12,10 +12,12 @@
 // cell when the group's extreme values are not tied (pmin, pmax of the rescaling depend on N only): it is tabulated once per
 // block with the very float64 expressions the generic kernel evaluates per element, so an element costs one table byte, one
 // factor read and one multiply.  Groups with tied extremes evaluate those expressions directly (same results by
-// construction).  The adjusted values are parked by time index in LDS and leave in one coalesced sweep.
+// construction).  The adjusted values go through a per-wave [member][lane] LDS buffer back to member order and every lane
+// stores where it loaded from.  A wave works alone on (cell, 64 groups) items: no block barrier after the prologue.
 //
-// Cells whose factor table holds a NaN (the nearest node of the element's own row is then not the 2-D nearest neighbour)
-// are appended to flag_list and redone by k_qdm_adjust, like the cells k_qdm_cell cannot finish.
+// A wave whose factor rows hold a NaN (the nearest node of the element's own row is then not the 2-D nearest neighbour)
+// appends the cell to flag_list; k_qdm_adjust redoes those cells, like the cells k_qdm_cell cannot finish.  Time steps in
+// no group are not touched here: the host pre-fills the output with NaN when the grouping has any.
 #pragma once
 #include "kernels.hpp"
 
@@ -24,10 +26,14 @@ namespace xs {
 constexpr int QL_M = 32;               // members per ranking row (registers per lane)
 constexpr int QL_TW = 2 * QL_M + 2;    // row pitch of the node table: 2r lies in [2, 2N]; NaN rows reach N + 33
 constexpr int QL_NAN = 255;            // node code: the factor is NaN (extrapolation = "nan", undefined percent rank)
+constexpr int QL_CODES = ((QL_M + 1) * QL_TW + 15) & ~15;
 
-__host__ __device__ inline size_t qdm_lanes_lds_bytes(int64_t T, int G, int Q)
+// dynamic LDS of a block of `nwave` waves: the quantile axis and the node table (shared), then per wave the factor rows of its
+// 64 groups and a [max_mem][64] buffer that takes the adjusted values back from sorted order to member order
+__host__ __device__ inline size_t qdm_lanes_wave_bytes(int Q, int max_mem) { return ((size_t)64 * Q + (size_t)max_mem * 64) * 4; }
+__host__ __device__ inline size_t qdm_lanes_lds_bytes(int nwave, int Q, int max_mem)
 {
-    return (((size_t)G * Q + (size_t)Q + 3) & ~(size_t)3) * 4 + (((size_t)T + 3) & ~(size_t)3) * 4 + (size_t)(QL_M + 1) * QL_TW + 16;
+    return (((size_t)Q + 3) & ~(size_t)3) * 4 + QL_CODES + (size_t)nwave * qdm_lanes_wave_bytes(Q, max_mem);
 }
 
 // the node of the group's own row nearest to the rescaled percent rank: utils.rank's formula and interp2d_nearest
@@ -45,19 +51,22 @@ __device__ __forceinline__ int ql_code(int twor, int N, double pmin, double pmax
     return w;
 }
 
-__global__ __launch_bounds__(384, 3) void k_qdm_lanes(const float *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
-                                                    const float *__restrict__ af, const float *__restrict__ quantiles, int G, int Q,
-                                                    const int *__restrict__ mem_t32, int extrap, int kind, float *__restrict__ scen,
-                                                    int64_t osc, int has_ungrouped, int *__restrict__ flag_count,
-                                                    int *__restrict__ flag_list)
+__device__ __forceinline__ void lds_wave_fence_ql() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// Work item = (cell, chunk of 64 groups); a wave owns the items of ONE chunk (its member -> time table stays in registers,
+// two 16-bit indexes per register) and walks the cells; waves never wait for each other after the prologue.
+__global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
+                                                       const float *__restrict__ af, const float *__restrict__ quantiles, int G, int Q,
+                                                       const int *__restrict__ mem_t32, int max_mem, int extrap, int kind,
+                                                       float *__restrict__ scen, int64_t osc, int *__restrict__ flag_count,
+                                                       int *__restrict__ flag_list)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *ys = reinterpret_cast<float *>(smem);                                    // [G][Q] the cell's factors
-    float *xq = ys + (size_t)G * Q;                                                  // [Q] the quantile axis
-    float *stage = ys + ((((size_t)G * Q + (size_t)Q) + 3) & ~(size_t)3);            // [T] adjusted values by time index
-    unsigned char *codes = reinterpret_cast<unsigned char *>(stage + (((size_t)T + 3) & ~(size_t)3));  // [QL_M + 1][QL_TW]
+    float *xq = reinterpret_cast<float *>(smem);                                          // [Q] the quantile axis
+    unsigned char *codes = smem + (((size_t)Q + 3) & ~(size_t)3) * 4;                     // [QL_M + 1][QL_TW]
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nwave = nt >> 6;
-    const int n = G * Q;
+    float *ysw = reinterpret_cast<float *>(codes + QL_CODES + (size_t)wid * qdm_lanes_wave_bytes(Q, max_mem));  // [64][Q] factor rows
+    float *trw = ysw + (size_t)64 * Q;                                                    // [max_mem][64]
 
     // ---- once per block: the quantile axis and the (N, 2r) -> node table of groups whose extremes are not tied
     bool bad_axis = false;
@@ -78,147 +87,173 @@ __global__ __launch_bounds__(384, 3) void k_qdm_lanes(const float *__restrict__ 
     }
     __syncthreads();
 
-    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
-        // ---- the cell's factors (coalesced, NB loads in flight per thread)
+    const int nchunk = (G + 63) / 64;
+    const int n_items = (int)C * nchunk, n_waves = (int)gridDim.x * nwave;  // (n_cell * n_chunk < 2^31: host-checked)
+    uint32_t tt16[QL_M / 2];  // member slots -> time indexes of this lane's group, two 16-bit indexes per word, 0xFFFF: no such member
+    // The words are needed when an item's loads are issued and again when its results are stored, not in between: they are
+    // fetched anew (16 coalesced L2 hits) after the sort instead of occupying 16 registers through it — the pointer is made
+    // opaque so that the second fetch is not folded into the first and spilled.
+    auto fetch_slots = [&](int g) __attribute__((always_inline)) {
+        const int *mp = mem_t32;
+        __asm__ volatile("" : "+s"(mp));
+#pragma unroll
+        for (int y = 0; y < QL_M / 2; y++) tt16[y] = g < G ? (uint32_t)mp[(size_t)y * G + g] : 0xFFFFFFFFu;
+    };
+    int cur_chunk = -1;
+    for (int item = (int)blockIdx.x * nwave + wid; item < n_items; item += n_waves) {
+        const int ci = item / nchunk;
+        const int chunk = item - ci * nchunk;
+        const int64_t c = ci;
+        // (the lane index is made opaque per item: what derives from it — table and row addresses — is recomputed here instead
+        //  of being hoisted out of the item loop and spilled across the sort)
+        int ln = lane;
+        __asm__ volatile("" : "+v"(ln));
+        const int g0 = chunk * 64, g = g0 + ln;
+        if (chunk != cur_chunk) { cur_chunk = chunk; fetch_slots(g); }  // (else: still there from the previous item's stores)
+        auto slot_time = [&](int y) { return (tt16[y / 2] >> (16 * (y & 1))) & 0xFFFFu; };
+        // ---- loads: the members of the lane's group (consecutive lanes, consecutive days: coalesced) and the factor rows of
+        // the wave's groups (one contiguous piece of the cell's table), all issued before anything is looked at
+        const char *xrow = reinterpret_cast<const char *>(sim + c * sc);
+        float x[QL_M];
+#pragma unroll
+        for (int y = 0; y < QL_M; y++) {
+            const uint32_t t = slot_time(y);
+            x[y] = *reinterpret_cast<const float *>(xrow + (t == 0xFFFFu ? 0u : t * 4u));
+        }
+        const int nrow = min(64, G - g0), nfac = nrow * Q;
         bool has_nan = bad_axis;
         {
-            const float *yq = af + (size_t)c * n;
-            constexpr int NB = 8;
-            for (int i0 = tid; i0 < n; i0 += NB * nt) {
+            const float *yq = af + ((size_t)c * G + g0) * Q;
+            constexpr int NB = 20;  // (20 nodes: the wave's rows in one batch)
+            for (int i0 = ln; i0 < nfac; i0 += NB * 64) {
                 float yv[NB];
 #pragma unroll
-                for (int k = 0; k < NB; k++) yv[k] = yq[min(i0 + k * nt, n - 1)];
+                for (int kq = 0; kq < NB; kq++) yv[kq] = yq[min(i0 + kq * 64, nfac - 1)];
 #pragma unroll
-                for (int k = 0; k < NB; k++) {
-                    const int i = i0 + k * nt;
-                    if (i < n) { ys[i] = yv[k]; has_nan |= yv[k] != yv[k]; }
+                for (int kq = 0; kq < NB; kq++) {
+                    const int i = i0 + kq * 64;
+                    if (i < nfac) { ysw[i] = yv[kq]; has_nan |= yv[kq] != yv[kq]; }
                 }
             }
         }
-        if (has_ungrouped)
-            for (int64_t t = tid; t < T; t += nt) stage[t] = nan_of<float>();
-        if (__syncthreads_or(has_nan ? 1 : 0)) {  // (the barrier also orders the table / NaN fill before the group pass)
-            if (tid == 0) { const int slot = atomicAdd(flag_count, 1); flag_list[slot] = (int)c; }
+        // (every load is issued before the first value is looked at: pinned, or each one sinks into its `present` branch)
+#pragma unroll
+        for (int y = 0; y < QL_M; y++) __asm__ volatile("" : "+v"(x[y]));
+        lds_wave_fence_ql();  // the rows were written across lanes
+        if (__any(has_nan)) {
+            // a NaN factor among the wave's rows: the own-row node need not be the 2-D nearest one — the generic kernel redoes
+            // the cell (other waves of the cell may list it again: the list holds n_cell * n_chunk entries, the redo is idempotent)
+            if (lane == 0) { const int slot = atomicAdd(flag_count, 1); flag_list[slot] = (int)c; }
             continue;
         }
-        const char *xrow = reinterpret_cast<const char *>(sim + c * sc);
-        for (int g0 = wid * 64; g0 < G; g0 += nwave * 64) {
-            const int g = g0 + lane;
-            const bool gv = g < G;
-            uint32_t k[QL_M], p[QL_M];
-            {
-                int tt[QL_M];
+        uint32_t k[QL_M], p[QL_M];
 #pragma unroll
-                for (int y = 0; y < QL_M; y++) tt[y] = gv ? mem_t32[(size_t)y * G + g] : -1;
-                float x[QL_M];
-#pragma unroll
-                for (int y = 0; y < QL_M; y++) x[y] = *reinterpret_cast<const float *>(xrow + (uint32_t)(max(tt[y], 0) * 4));
-                // (every load is issued before the first value is looked at: pinned, or each one sinks into its `present` branch)
-#pragma unroll
-                for (int y = 0; y < QL_M; y++) __asm__ volatile("" : "+v"(x[y]));
-#pragma unroll
-                for (int y = 0; y < QL_M; y++) {
-                    const bool present = tt[y] >= 0;
-                    const uint32_t bits = __float_as_uint(x[y]);
-                    // -0.0 ranks as +0.0 (scipy compares values); its sign rides in bit 31 of the payload and returns at the end
-                    k[y] = present ? to_key(x[y] + 0.0f) : 0xFFFFFFFFu;
-                    p[y] = present ? ((uint32_t)tt[y] | (bits == 0x80000000u ? 0x80000000u : 0u)) : 0xFFFFFFFFu;
-                }
-            }
-            // ---- Batcher's odd-even merge sort of the (key, payload) pairs, in registers.  A pair travels as ONE 64-bit word,
-            // key on top (equal keys are then ordered by payload, which no result depends on): a compare-exchange is one
-            // 64-bit compare and four selects, and the key and payload networks cannot drift apart in the schedule (as two
-            // 32-bit networks the compiler ran all the key min / max first and kept every intermediate key alive for the
-            // payload selects: 500 live registers)
-            {
-                uint64_t kp[QL_M];
-#pragma unroll
-                for (int y = 0; y < QL_M; y++) kp[y] = ((uint64_t)k[y] << 32) | p[y];
-#pragma unroll
-                for (int pp = 1; pp < QL_M; pp *= 2)
-#pragma unroll
-                    for (int kk = pp; kk >= 1; kk /= 2)
-#pragma unroll
-                        for (int j = kk % pp; j <= QL_M - 1 - kk; j += 2 * kk)
-#pragma unroll
-                            for (int i = 0; i <= (kk - 1 < QL_M - j - kk - 1 ? kk - 1 : QL_M - j - kk - 1); i++)
-                                if ((i + j) / (2 * pp) == (i + j + kk) / (2 * pp)) {
-                                    const uint64_t va = kp[i + j], vb = kp[i + j + kk];
-                                    const bool sw = vb < va;
-                                    kp[i + j] = sw ? vb : va;
-                                    kp[i + j + kk] = sw ? va : vb;
-                                }
-#pragma unroll
-                for (int y = 0; y < QL_M; y++) { k[y] = (uint32_t)(kp[y] >> 32); p[y] = (uint32_t)kp[y]; }
-            }
-            // ---- forward sweep: start of every tie run (bits 24-28 of the payload), valid count, start of the last valid run
-            int N = 0, st = 0, last_start = 0;
-#pragma unroll
-            for (int j = 0; j < QL_M; j++) {
-                if (j > 0) st = (k[j] == k[j - 1]) ? st : j;
-                p[j] |= (uint32_t)st << 24;
-                const bool valid = k[j] != 0xFFFFFFFFu;
-                N += valid ? 1 : 0;
-                last_start = valid ? st : last_start;
-            }
-            const bool untied = (N < 2 || k[1] != k[0]) && (N < 1 || last_start == N - 1);
-            const int gq = (gv ? g : 0) * Q;
-            // ---- backward sweep: end of every tie run; 2r = start + end + 1 replaces the start in bits 24-30 of the payload
-            {
-                int e = QL_M;
-#pragma unroll
-                for (int j = QL_M - 1; j >= 0; j--) {
-                    if (j < QL_M - 1) e = (k[j] == k[j + 1]) ? e : j + 1;
-                    const uint32_t twor = ((p[j] >> 24) & 31u) + (uint32_t)e + 1u;
-                    p[j] = (p[j] & 0x80FFFFFFu) | (twor << 24);  // (an absent slot keeps its 24 low bits set: t = 2^24 - 1 is never a time index)
-                }
-            }
-            auto park = [&](uint32_t kj, uint32_t pj, int code) __attribute__((always_inline)) {
-                const float a = code == QL_NAN ? nan_of<float>() : ys[gq + (code == QL_NAN ? 0 : code)];
-                const float v = __uint_as_float(__float_as_uint(from_key(kj)) | (pj & 0x80000000u));
-                const float out = apply_corr<float>(v, a, kind);
-                if ((pj & 0xFFFFFFu) != 0xFFFFFFu) stage[pj & 0xFFFFFFu] = out;
-            };
-            if (!__any(!untied)) {
-                // 2r -> node from the block's table -> factor -> adjusted value, parked by time index
-                const unsigned char *crow = codes + N * QL_TW;
-#pragma unroll
-                for (int j = 0; j < QL_M; j++) park(k[j], p[j], (int)crow[(p[j] >> 24) & 127u]);
-            } else {
-                // some group of this wave has tied extremes: its rescaling differs, the float64 expressions are evaluated per
-                // element (a rolled loop over the places; the place is wave-uniform, the registers are picked by a select chain)
-                int nmin = 1;
-                bool eq = true;
-#pragma unroll
-                for (int j = 1; j < QL_M; j++) { eq = eq && k[j] == k[0]; nmin += eq ? 1 : 0; }
-                const int nmax = N - last_start;
-                const double Nd = (double)N;
-                const double pmin = (((double)nmin + 1.0) / 2.0) / Nd;
-                const double pmax = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
-#pragma unroll 1
-                for (int j = 0; j < QL_M; j++) {
-                    uint32_t kj = 0u, pj = 0u;
-#pragma unroll
-                    for (int u = 0; u < QL_M; u++) { kj = u == j ? k[u] : kj; pj = u == j ? p[u] : pj; }
-                    const int twor = (int)((pj >> 24) & 127u);
-                    const int code = (kj != 0xFFFFFFFFu && twor <= 2 * N) ? ql_code(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN;
-                    park(kj, pj, code);
-                }
-            }
+        for (int y = 0; y < QL_M; y++) {
+            const bool present = slot_time(y) != 0xFFFFu;
+            const uint32_t bits = __float_as_uint(x[y]);
+            // -0.0 ranks as +0.0 (scipy compares values); its sign rides in bit 31 of the payload and returns at the end
+            k[y] = present ? to_key(x[y] + 0.0f) : 0xFFFFFFFFu;
+            p[y] = present ? ((uint32_t)y | (bits == 0x80000000u ? 0x80000000u : 0u)) : 0xFFFFFFu;  // payload: the member slot
         }
-        __syncthreads();
+        // ---- Batcher's odd-even merge sort of the (key, payload) pairs, in registers.  A pair travels as ONE 64-bit word,
+        // key on top (equal keys are then ordered by payload, which no result depends on): a compare-exchange is one
+        // 64-bit compare and four selects, and the key and payload networks cannot drift apart in the schedule (as two
+        // 32-bit networks the compiler ran all the key min / max first and kept every intermediate key alive for the
+        // payload selects: 500 live registers)
         {
-            float *orow = scen + c * osc;
-            constexpr int NB = 8;
-            for (int64_t t0 = tid; t0 < T; t0 += (int64_t)NB * nt) {
-                float v[NB];
+            uint64_t kp[QL_M];
 #pragma unroll
-                for (int kq = 0; kq < NB; kq++) { const int64_t t = t0 + (int64_t)kq * nt; v[kq] = stage[t < T ? t : T - 1]; }
+            for (int y = 0; y < QL_M; y++) kp[y] = ((uint64_t)k[y] << 32) | p[y];
 #pragma unroll
-                for (int kq = 0; kq < NB; kq++) { const int64_t t = t0 + (int64_t)kq * nt; if (t < T) orow[t] = v[kq]; }
+            for (int pp = 1; pp < QL_M; pp *= 2)
+#pragma unroll
+                for (int kk = pp; kk >= 1; kk /= 2)
+#pragma unroll
+                    for (int j = kk % pp; j <= QL_M - 1 - kk; j += 2 * kk)
+#pragma unroll
+                        for (int i = 0; i <= (kk - 1 < QL_M - j - kk - 1 ? kk - 1 : QL_M - j - kk - 1); i++)
+                            if ((i + j) / (2 * pp) == (i + j + kk) / (2 * pp)) {
+                                const uint64_t va = kp[i + j], vb = kp[i + j + kk];
+                                const bool sw = vb < va;
+                                kp[i + j] = sw ? vb : va;
+                                kp[i + j + kk] = sw ? va : vb;
+                                // (two exchanges in flight at most: unbounded, the sixteen of a layer keep ~64 more registers busy)
+                                if (((i + j) & 1) == 1 || kk == 1) __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) { k[y] = (uint32_t)(kp[y] >> 32); p[y] = (uint32_t)kp[y]; }
+        }
+        int ln2 = lane;
+        __asm__ volatile("" : "+v"(ln2));
+        fetch_slots(g0 + ln2);  // (in flight under the sweeps)
+        // ---- forward sweep: start of every tie run (bits 24-28 of the payload), valid count, start of the last valid run
+        int N = 0, st = 0, last_start = 0;
+#pragma unroll
+        for (int j = 0; j < QL_M; j++) {
+            if (j > 0) st = (k[j] == k[j - 1]) ? st : j;
+            p[j] |= (uint32_t)st << 24;
+            const bool valid = k[j] != 0xFFFFFFFFu;
+            N += valid ? 1 : 0;
+            last_start = valid ? st : last_start;
+        }
+        const bool untied = (N < 2 || k[1] != k[0]) && (N < 1 || last_start == N - 1);
+        const int gq = ln2 * Q;  // the lane's row in the wave's factor rows
+        // ---- backward sweep: end of every tie run; 2r = start + end + 1 replaces the start in bits 24-30 of the payload
+        {
+            int e = QL_M;
+#pragma unroll
+            for (int j = QL_M - 1; j >= 0; j--) {
+                if (j < QL_M - 1) e = (k[j] == k[j + 1]) ? e : j + 1;
+                const uint32_t twor = ((p[j] >> 24) & 31u) + (uint32_t)e + 1u;
+                p[j] = (p[j] & 0x80FFFFFFu) | (twor << 24);  // (an absent slot keeps its 24 low bits set)
             }
         }
-        __syncthreads();  // the next cell refills ys / stage
+        auto park = [&](uint32_t kj, uint32_t pj, int code) __attribute__((always_inline)) {
+            const float a = code == QL_NAN ? nan_of<float>() : ysw[gq + (code == QL_NAN ? 0 : code)];
+            const float v = __uint_as_float(__float_as_uint(from_key(kj)) | (pj & 0x80000000u));
+            const float out = apply_corr<float>(v, a, kind);
+            if ((pj & 0xFFFFFFu) != 0xFFFFFFu) trw[(pj & 31u) * 64u + (uint32_t)ln2] = out;
+        };
+        if (!__any(!untied)) {
+            // 2r -> node from the block's table -> factor -> adjusted value, parked by member slot
+            const unsigned char *crow = codes + N * QL_TW;
+#pragma unroll
+            for (int j = 0; j < QL_M; j++) park(k[j], p[j], (int)crow[(p[j] >> 24) & 127u]);
+        } else {
+            // some group of this wave has tied extremes: its rescaling differs, the float64 expressions are evaluated per
+            // element (a rolled loop over the places; the place is wave-uniform, the registers are picked by a select chain)
+            int nmin = 1;
+            bool eq = true;
+#pragma unroll
+            for (int j = 1; j < QL_M; j++) { eq = eq && k[j] == k[0]; nmin += eq ? 1 : 0; }
+            const int nmax = N - last_start;
+            const double Nd = (double)N;
+            const double pmin = (((double)nmin + 1.0) / 2.0) / Nd;
+            const double pmax = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
+#pragma unroll 1
+            for (int j = 0; j < QL_M; j++) {
+                uint32_t kj = 0u, pj = 0u;
+#pragma unroll
+                for (int u = 0; u < QL_M; u++) { kj = u == j ? k[u] : kj; pj = u == j ? p[u] : pj; }
+                const int twor = (int)((pj >> 24) & 127u);
+                const int code = (kj != 0xFFFFFFFFu && twor <= 2 * N) ? ql_code(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN;
+                park(kj, pj, code);
+            }
+        }
+        // ---- back in member order: every lane stores where it loaded from (coalesced the same way)
+        lds_wave_fence_ql();
+        {
+            char *orow = reinterpret_cast<char *>(scen + c * osc);
+            float o[QL_M];
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) o[y] = trw[(y < max_mem ? y : 0) * 64 + ln2];
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) {
+                const uint32_t t = slot_time(y);
+                if (t != 0xFFFFu) *reinterpret_cast<float *>(orow + t * 4u) = o[y];
+            }
+        }
+        lds_wave_fence_ql();  // (the next item refills the wave's rows)
     }
 }
 
