@@ -566,7 +566,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             auto go3 = [&](auto cfg, auto p10, auto dqm) -> int {
                 constexpr int EPT = decltype(cfg)::value;
                 constexpr bool P10 = decltype(p10)::value, DQM = decltype(dqm)::value;
-                const size_t lds = xs::CellCfg3<EPT>::lds_bytes;
+                const size_t lds = xs::CellCfg3<EPT>::lds_bytes + (DQM ? ((size_t)G + 1) * sizeof(double) : 0);  // + the group sums of dqm_train
                 int rc2;
                 if ((rc2 = set_lds(xs::k_train_cell3<EPT, P10, DQM>, lds, ctx, "the per-cell sort"))) return rc2;
                 const int gm = getenv("XSDBA_HIP_GRID_MULT") ? atoi(getenv("XSDBA_HIP_GRID_MULT")) : 4;
@@ -574,11 +574,14 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 LaunchScope ls(ctx, "k_train_cell3");
                 hipLaunchKernelGGL((xs::k_train_cell3<EPT, P10, DQM>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, G, (const float *)dq, Q, (int)kind, mode,
-                                   (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C, pl->d_tog64);
+                                   (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C, pl->d_tog64,
+                                   pl->d_mem_ptr, pl->d_mem_idx, (8 * (int64_t)G <= T) ? pl->d_mem_t32 : (const int *)nullptr, pl->W);
                 return check_launch("k_train_cell3");
             };
             const char *t3 = getenv("XSDBA_HIP_TRAIN3");
-            const bool three = !dbg && pl->d_tog64 && Q <= 21 && G >= 48 && !(t3 && !strcmp(t3, "0"));
+            const size_t lds3 = (ept == 4 ? xs::CellCfg3<4>::lds_bytes : ept == 8 ? xs::CellCfg3<8>::lds_bytes : xs::CellCfg3<11>::lds_bytes) +
+                                (mode == 2 ? ((size_t)G + 1) * sizeof(double) : 0);
+            const bool three = !dbg && pl->d_tog64 && Q <= 21 && G >= 48 && lds3 <= (size_t)ctx->lds_limit && !(t3 && !strcmp(t3, "0"));
             auto pick3d = [&](auto cfg, auto p10) -> int { return mode == 2 ? go3(cfg, p10, true_type{}) : go3(cfg, p10, false_type{}); };
             auto pick3 = [&](auto cfg) -> int { return pl->max_row <= 1023 ? pick3d(cfg, true_type{}) : pick3d(cfg, false_type{}); };
             if (three)

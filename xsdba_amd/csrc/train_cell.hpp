@@ -225,9 +225,13 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
 // indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
 // (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
 // stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
-template <int EPT>
+struct NoLoadHook { __device__ __forceinline__ void operator()(const uint32_t *, int, int) const {} };
+
+// `hook(keys, T, tid)` runs between the load and the sort: the keys of the series are in LDS, everything from off_idx0 up
+// to off_misc is still free (the DQM group sums use it, train_cell3.hpp); it must end on a block barrier if it touches LDS
+template <int EPT, typename Hook = NoLoadHook>
 __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
-                                                          uint32_t *red, int stop_after, int &nvalid_out)
+                                                          uint32_t *red, int stop_after, int &nvalid_out, const Hook &hook = Hook())
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
@@ -289,6 +293,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         __syncthreads();
 
         if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
+        hook(keys, Ti, tid);
         return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after);
 }
 

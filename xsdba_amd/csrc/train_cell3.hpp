@@ -25,19 +25,150 @@ template <int EPT> struct CellCfg3 {
     static constexpr size_t lds_bytes = off_misc + 64 * 8;
 };
 
+// inclusive wave64 prefix sum of a double on the DPP cross-lane path (the steps of wave_incl_scan on both halves of the value)
+__device__ __forceinline__ double wave_incl_scan_f64(double v)
+{
+    auto step = [&](auto ctrl, auto rmask) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false);
+        v += __hiloint2double(hi, lo);
+    };
+    using std::integral_constant;
+    step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+    step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+    step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+    return v;
+}
+
+// dqm_train's group means (_adjustment.py:150-163: the mean over the windowed block of every group) without walking the rows:
+// the row of group g is the union of the windows of its members (base.py:261-272), so
+//     sum(row g) = sum over the members t of g of  S(t),   S(t) = sum of x over the window of t = P[hi(t)] - P[lo(t) - 1]
+// with P the float64 running sum of the series over time (NaN counts as 0; window clipped at both ends exactly like the
+// plan's rows, multiplicities included).  Runs as the load hook of cell_load_sort: P lives in the LDS the sort has not
+// claimed yet (10 bytes per time step would not fit any later), the G sums go to `gsum` behind the kernel's other LDS.
+// A lane per group adds its members in member order: a fixed summation order, unlike running sums updated by toggles.
+// Also leaves max |x| over the finite values in guard[0] (the guard of the multiplicative kind, see cell_group_quantiles3).
+template <int EPT> struct GroupSumHook {
+    unsigned char *smem;
+    double *gsum;          // [G] (LDS)
+    double *guard;         // [1] (LDS): max |x|
+    const int *mem_ptr, *mem_idx, *mem_t16;  // mem_t16: the plan's packed member table (groups of <= 32 members) or null
+    int G, W;
+    __device__ __forceinline__ void operator()(const uint32_t *keys, int Ti, int tid) const
+    {
+        using Cfg = CellCfg<EPT>;
+        constexpr int NT = Cfg::NT, NW = Cfg::NWAVE;
+        double *P = reinterpret_cast<double *>(smem + Cfg::off_idx0);  // [T] inclusive running sums (8 T bytes of the 10 T free ones)
+        double *part = reinterpret_cast<double *>(smem + CellCfg3<EPT>::off_misc);  // [NW] wave totals, [NW] wave maxima
+        const int lane = tid & 63, wid = tid >> 6;
+        // every thread owns EPT consecutive time steps: their sum first (nothing else is kept: the kernel has no registers to
+        // spare here, and a spilled partial costs a memory round trip in a phase every wave waits on), ...
+        auto value = [&](int j, bool &ok) {
+            const int i = tid * EPT + j;
+            const float v = from_key(keys[min(i, Cfg::TPAD - 1)]);
+            ok = i < Ti && v == v;
+            return v;
+        };
+        double run = 0.0;
+        float amaxf = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EPT; j++) {
+            bool ok;
+            const float v = value(j, ok);
+            run += ok ? (double)v : 0.0;
+            amaxf = fmaxf(amaxf, (ok && fabsf(v) <= 3.4028234663852886e38f) ? fabsf(v) : 0.0f);
+        }
+        const double incl = wave_incl_scan_f64(run);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amaxf = fmaxf(amaxf, __shfl_xor(amaxf, o, 64));
+        if (lane == 63) part[wid] = incl;
+        if (lane == 0) part[NW + wid] = (double)amaxf;
+        __syncthreads();
+        // ... the NW wave totals scanned by the first lanes of wave 0, ...
+        if (wid == 0) {
+            const double tot = lane < NW ? part[lane] : 0.0, mx = lane < NW ? part[NW + lane] : 0.0;
+            const double ex = wave_incl_scan_f64(tot) - tot;
+            double m = mx;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+            if (lane < NW) part[lane] = ex;
+            if (lane == 0) guard[0] = m;
+        }
+        __syncthreads();
+        // ... then the running sums themselves, from the thread's offset (the values are read again)
+        {
+            double acc = (incl - run) + part[wid];
+#pragma unroll
+            for (int j = 0; j < EPT; j++) {
+                bool ok;
+                const float v = value(j, ok);
+                acc += ok ? (double)v : 0.0;
+                if (tid * EPT + j < Ti) P[tid * EPT + j] = acc;
+            }
+        }
+        __syncthreads();
+        const int hw = W / 2;
+        auto window_sum = [&](int t) {
+            const int lo = max(0, t - hw), hi = min(Ti - 1, t - hw + W - 1);
+            return P[hi] - (lo > 0 ? P[lo - 1] : 0.0);
+        };
+        if (mem_t16) {
+            // groups of <= 32 members (one per year): the packed member table of k_qdm_lanes, [16][G] words of two 16-bit time
+            // indexes — coalesced, all sixteen words of a lane in flight.  Waves 2j and 2j + 1 share the groups [64j, 64j + 64):
+            // the even wave adds members 0..15, the odd one members 16..31, in member order; the halves meet in `half`.
+            double *half = reinterpret_cast<double *>(smem + Cfg::off_idx0) + Cfg::TPAD;  // [2][G] behind P (2 T bytes are left: G <= T / 8)
+            for (int gb = 0; gb < G; gb += (NW / 2) * 64) {
+                const int g = gb + (wid >> 1) * 64 + lane, h = wid & 1;
+                uint32_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) w[u] = g < G ? (uint32_t)mem_t16[(size_t)(8 * h + u) * G + g] : 0xFFFFFFFFu;
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t t0 = w[u] & 0xFFFFu, t1 = w[u] >> 16;
+                    if (t0 != 0xFFFFu) acc += window_sum((int)t0);
+                    if (t1 != 0xFFFFu) acc += window_sum((int)t1);
+                }
+                if (g < G) half[(size_t)h * G + g] = acc;
+            }
+            __syncthreads();
+            for (int g = tid; g < G; g += NT) gsum[g] = half[g] + half[(size_t)G + g];
+        } else {
+            for (int g = tid; g < G; g += NT) {
+                const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
+                double acc = 0.0;
+                for (int pb = p0; pb < p1; pb += 8) {  // eight member indexes in flight
+                    int tt[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) tt[u] = mem_idx[min(pb + u, p1 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (pb + u < p1) acc += window_sum(tt[u]);
+                }
+                gsum[g] = acc;
+            }
+        }
+        __syncthreads();
+    }
+};
+
 // P10: every group row holds < 1024 values (day-of-year windows over up to ~33 years): the three per-lane counts share ONE
 // register (10-bit fields), one prefix scan and one bpermute per bisection step serve all three streams.
 // DQM: group means from running float64 sums updated by the same toggles (one per stream), normalisation of the selected
 // order statistics, scaling — with the guards of cell_group_quantiles (train_cell.hpp).
 // Vals: where the values come from (LdsVals: float32 keys in LDS; GlobalF64Vals: the float64 series in global memory).
-template <int EPT, bool P10, bool DQM, typename Vals>
+// PRESUM (DQM): the group sums were formed by GroupSumHook (`gsum` [G], `guard` in LDS) instead of running sums kept by the toggles.
+template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false>
 __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
                                                       const typename Vals::value_type *__restrict__ q, int Q, int kind, int mode,
                                                       int arr, int64_t c, typename Vals::value_type *__restrict__ af,
                                                       typename Vals::value_type *out_hq, typename Vals::value_type *scaling,
-                                                      bool &flag_cell)
+                                                      bool &flag_cell, const double *gsum = nullptr, const double *guard = nullptr)
 {
     using R = typename Vals::value_type;
     using Cfg = CellCfg3<EPT>;
@@ -58,7 +189,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             const int r = (int)rank[t];
             if (r < nvalid) {
                 const uint32_t m = 1u << (r & 31);
-                if (DQM) {
+                if (DQM && !PRESUM) {
                     const uint32_t old = atomicXor(&bits[r >> 5], m);
                     const R v = vals.at_time(t);
                     dloc += (old & m) ? -(double)v : (double)v;
@@ -99,7 +230,8 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
 #pragma unroll
             for (int u = 0; u < 4; u++) ts[u] = s0 + u <= nA ? tog64[(size_t)(gb + s0 + u) * 64 + lane] : -1;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { flip(bC, ts[u], dlocC); lds_wave_fence(); }  // (DQM reads the old bit: one list at a time)
+            for (int u = 0; u < 4; u++) { flip(bC, ts[u], dlocC); if (DQM && !PRESUM) lds_wave_fence(); }  // (running sums read the old bit: one list at a time)
+            lds_wave_fence();
         }
     }
     // ---- lock-step walk; the next lists are prefetched under the select
@@ -143,7 +275,17 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         const bool vs = sid == 0 || (sid == 1 && vB) || (sid == 2 && vC);
         const bool act = vs && k < Q;
         R mu = (R)0, inv = (R)0;
-        if (DQM) {
+        if (DQM && PRESUM) {
+            const double gs = gsum[vs && sid < 3 ? g : 0];
+            mu = ns ? (R)(gs / (double)ns) : nan_of<R>();
+            inv = invert<R>(mu, kind);
+            if (vs && sid < 3 && ns && (!isfinite(mu) || (kind == '*' && !(inv > (R)0 && isfinite(inv))))) flag_cell = true;
+            // The sums are differences of float64 running sums over time: absolute error ~ eps * n_time * max |x|.  The
+            // multiplicative kind divides by the mean: keep it below ~3e-9 of the group sum, else the generic kernel redoes the
+            // cell with fresh sums (a group mean next to zero beside large values).  The additive kind is guarded above (IQR).
+            constexpr double LIM = 1.0e3;
+            if (kind == '*' && vs && sid < 3 && ns && !(guard[0] <= LIM * fabs(gs))) flag_cell = true;
+        } else if (DQM) {
             // it == 0: dlocA holds the sum of the built vector (B and C start from it), dlocC the fast-forward of C on top
             // (the totals sit in lane 0; read into scalar registers: the running sums are wave-uniform and stay out of the VGPRs)
             auto uni = [](double v) {
@@ -281,7 +423,8 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
                                                        const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, int G,
                                                        const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af,
                                                        float *out_hq, float *scaling, int *__restrict__ flag_count,
-                                                       int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64)
+                                                       int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64,
+                                                       const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx, const int *__restrict__ mem_t16, int W)
 {
     using Cfg = CellCfg<EPT>;
     using Cfg3 = CellCfg3<EPT>;
@@ -291,6 +434,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
     uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0), *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
     uint32_t *bits_all = reinterpret_cast<uint32_t *>(smem + Cfg3::off_bits);
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg3::off_misc);
+    double *gsum = reinterpret_cast<double *>(smem + Cfg3::lds_bytes);  // DQM: [G] group sums + [1] guard (the launch adds (G + 1) * 8 bytes)
     const int tid = threadIdx.x, wid = tid >> 6;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const int npass_arr = mode == 0 ? 1 : 2;
@@ -300,13 +444,15 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             __asm__ volatile("" : "+v"(lane));
             const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;  // hist first, then ref (see k_train_cell)
             int nvalid;
-            const uint16_t *sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid);  // no rank[] in the union region
-            uint16_t *rank = sorted == idx0 ? idx1 : idx0;                               // the buffer the sort left free
+            const uint16_t *sorted;  // (no rank[] in the union region)
+            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W});
+            else sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid);
+            uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
             __syncthreads();
             const LdsVals vals{keys, sorted, TPAD};
-            cell_group_quantiles3<EPT, P10, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode,
-                                                 arr, c, af, out_hq, scaling, flag_cell);
+            cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
+                                                               kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
