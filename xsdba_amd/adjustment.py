@@ -50,23 +50,15 @@ def update_history(hist_str: str, *inputs, new_name: str | None = None) -> str:
 
 
 def _device_resident(da):
-    """Large host series are moved to the GPU ONCE, before the adjustment code sees them (blocks page-locked on the fly,
-    DMA at the PCIe rate): everything downstream — trained tables included — then stays on the device, and a result is
-    downloaded only when its ``values`` are asked for.  Small inputs (< XSDBA_AMD_DEVICE_MIN_MB, default 64 MB) keep the
-    plain path: one library call per stage with host pointers.  Layouts the kernels read directly are (cells..., time) and
-    (time, cells...); anything else stays on the host (the library then copies it once)."""
-    import os
+    """Large host series are moved to the GPU ONCE, before the adjustment code sees them (labeled.to_device_if_large) —
+    unless they are so large that ``map_blocks`` will cut them into blocks of cells (base.block_budget_bytes): those stay on
+    the host and every block is uploaded on its own."""
+    from .base import block_budget_bytes
+    from .labeled import to_device_if_large
 
-    if getattr(da, "device_data", None) is not None or "time" not in da.dims:
+    if getattr(da, "device_data", None) is None and da.values.nbytes > block_budget_bytes() / 3:
         return da
-    v = da.values
-    lim = float(os.environ.get("XSDBA_AMD_DEVICE_MIN_MB", "64")) * 2 ** 20
-    ax = da.dims.index("time")
-    if v.dtype not in (np.float32, np.float64) or v.nbytes < lim or not v.flags.c_contiguous or ax not in (0, v.ndim - 1):
-        return da
-    from ._lib import default_context
-
-    return DataArray(default_context().to_device(v), da.dims, da.coords, da.attrs, da.name)
+    return to_device_if_large(da)
 
 
 class BaseAdjustment(ParametrizableWithDataset):

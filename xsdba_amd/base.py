@@ -361,6 +361,64 @@ def _merge_dimensions(*seqs):
     return out
 
 
+# ---- blocks of cells (the role dask chunks play for the reference, base.py:640-702) -------------------------------------
+def block_budget_bytes() -> float:
+    """Largest host-backed input (all variables of one block call together) handed to the GPU in one piece; beyond it
+    ``map_blocks`` cuts the non-reduced dimensions into blocks.  ``XSDBA_AMD_BLOCK_MAX_MB`` (default 65536: a quarter of an
+    MI355X's HBM, which leaves room for the trained tables and the library's scratch)."""
+    import os
+
+    return float(os.environ.get("XSDBA_AMD_BLOCK_MAX_MB", "65536")) * 2 ** 20
+
+
+def _plan_blocks(ds, base_dims, keep_whole=()):
+    """(dim, step) when the host-backed variables of `ds` exceed the block budget and can be cut along a dimension the block
+    function neither reduces nor creates — never the grouping dimension (`keep_whole`: ranks, trends and windows need the whole
+    series); None otherwise (device-resident inputs are already where they are used)."""
+    base_dims = [d for d in base_dims if d not in keep_whole]
+    variables = list(ds.data_vars.values()) if isinstance(ds, Dataset) else [ds]
+    if any(getattr(v, "device_data", None) is not None for v in variables):
+        return None
+    cut = [v for v in variables if any(d in base_dims and v.sizes[d] > 1 for d in v.dims)]
+    total = sum(v.values.nbytes for v in cut)
+    budget = block_budget_bytes()
+    if not cut or total <= budget:
+        return None
+    big = max(cut, key=lambda v: v.values.nbytes)
+    cands = [d for d in big.dims if d in base_dims and big.sizes[d] > 1]
+    # the outermost such dimension: its blocks are contiguous pieces of a C-ordered cube
+    dim = cands[0]
+    n = big.sizes[dim]
+    step = max(1, int(n * budget // total))
+    return (dim, step) if step < n else None
+
+
+def _isel_block(ds, dim, sl):
+    def cut(v):
+        return v.isel({dim: sl}) if dim in v.dims else v
+
+    if isinstance(ds, Dataset):
+        return Dataset({k: cut(v) for k, v in ds.data_vars.items()}, attrs=ds.attrs)
+    return cut(ds)
+
+
+def _concat_blocks(outs, dim):
+    first = outs[0]
+    merged = {}
+    for name, v0 in first.data_vars.items():
+        if dim not in v0.dims:
+            merged[name] = v0
+            continue
+        ax = v0.dims.index(dim)
+        parts = [np.asarray(o.data_vars[name].transpose(*v0.dims).values) for o in outs]
+        coords = OrderedDict(v0.coords)
+        if dim in v0.coords:
+            coords[dim] = Coordinate(dim, np.concatenate([np.asarray(o.data_vars[name].coords[dim].values) for o in outs]), v0.coords[dim].attrs)
+        merged[name] = DataArray(np.concatenate(parts, axis=ax), v0.dims, coords, v0.attrs, name)
+    return Dataset(merged, attrs=first.attrs)
+
+
+
 def map_blocks(reduces=None, **out_vars):
     """Declare a block function ``func(ds, **kwargs) -> Dataset`` (base.py:563-726).
 
@@ -400,8 +458,25 @@ def map_blocks(reduces=None, **out_vars):
                 if dim not in kwargs and dim not in in_dims:
                     raise ValueError(f"This function adds the {dim} dimension, its coordinate must be provided as a keyword argument.")
             try:
-                out = func(ds, **kwargs)
-                out = as_dataset(out)
+                plan = _plan_blocks(ds, base_dims, keep_whole=(group.dim,) if group is not None else ("time",))
+                if plan is None:
+                    out = as_dataset(func(ds, **kwargs))
+                else:
+                    # inputs larger than the block budget: the non-reduced dimension is cut in blocks, every block is one
+                    # call (uploaded through page-locked pieces, computed, its results brought back), like dask chunks
+                    from .labeled import to_device_if_large
+
+                    bdim, step = plan
+                    n = (ds.sizes if isinstance(ds, Dataset) else ds.sizes)[bdim]
+                    outs = []
+                    for i0 in range(0, n, step):
+                        blk = _isel_block(ds, bdim, slice(i0, min(n, i0 + step)))
+                        blk = (Dataset({k: to_device_if_large(v) for k, v in blk.data_vars.items()}, attrs=blk.attrs)
+                               if isinstance(blk, Dataset) else to_device_if_large(blk))
+                        o = as_dataset(func(blk, **kwargs))
+                        outs.append(Dataset({k: DataArray(np.asarray(v.values), v.dims, v.coords, v.attrs, v.name)
+                                             for k, v in o.data_vars.items()}, attrs=o.attrs))
+                    out = _concat_blocks(outs, bdim)
                 def _ordered(v):
                     order = [d for d in all_dims if d in v.dims]
                     if tuple(order) != tuple(v.dims) and getattr(v, "device_data", None) is not None and getattr(v, "_host", None) is None:

@@ -406,6 +406,26 @@ class DataArray:
 _KEEP_ATTRS = [True]
 
 
+
+def to_device_if_large(da):
+    """Large host series are moved to the GPU ONCE (blocks page-locked on the fly, DMA at the PCIe rate): everything
+    downstream — trained tables included — then stays on the device, and a result is downloaded only when its ``values`` are
+    asked for.  Small inputs (< XSDBA_AMD_DEVICE_MIN_MB, default 64 MB) keep the plain path: one library call per stage with
+    host pointers.  Layouts the kernels read directly are (cells..., time) and (time, cells...); anything else stays on the
+    host (the library then copies it once)."""
+    import os
+
+    if getattr(da, "device_data", None) is not None or "time" not in da.dims:
+        return da
+    v = da.values
+    lim = float(os.environ.get("XSDBA_AMD_DEVICE_MIN_MB", "64")) * 2 ** 20
+    ax = da.dims.index("time")
+    if v.dtype not in (np.float32, np.float64) or v.nbytes < lim or not v.flags.c_contiguous or ax not in (0, v.ndim - 1):
+        return da
+    from ._lib import default_context
+
+    return DataArray(default_context().to_device(v), da.dims, da.coords, da.attrs, da.name)
+
 def _broadcast(a: DataArray, b: DataArray):
     dims = list(a.dims) + [d for d in b.dims if d not in a.dims]
 
