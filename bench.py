@@ -357,9 +357,10 @@ def pmc_traffic(workload, cells, days, kernel):
     no PMC run matches the workload being benchmarked."""
     # the newest set first: "<round>_final_*", then the versioned sets in descending order (v10 before v9)
     def age(f):
+        # "rNN_final*" is the round's last set, "rNN_vK*" an intermediate one, a plain "rNN_*" the first
         m = re.search(r"r(\d+)_", f.name)
-        v = re.search(r"_v(\d+)", f.name)
-        return (int(m.group(1)), int(v.group(1)) if v else 10**6) if m else (-1, -1)  # "rNN_final_*" / "rNN_*" before "rNN_vK_*"
+        v = re.search(r"r\d+_v(\d+)", f.name)
+        return (int(m.group(1)), 10**6 if re.search(r"r\d+_final", f.name) else (int(v.group(1)) if v else 0)) if m else (-1, -1)
 
     for f in sorted((ROOT / "profiles").glob("*traffic*.json"), key=age, reverse=True):
         try:
