@@ -107,6 +107,7 @@ template <typename R> struct CellTab {
     const double *xfirst, *xlast;  // [G] first/last non-NaN abscissa (NaN if none) — nbutils.py:380-389
     const R *yfirst, *ylast;       // [G] first/last non-NaN factor
     int G, Q, any_valid, xstride;
+    bool dense = false;  // no NaN anywhere in the cell's table: every row holds Q pairs, xfirst / xlast are its end abscissae
     const double *spl = nullptr;  // [n] second derivatives of the not-a-knot cubic spline of row 0 (interp = cubic, one group)
 };
 
@@ -197,12 +198,34 @@ template <typename R, typename XF> __device__ __forceinline__ double row_nearest
 // nbutils._extrapolate_on_quantiles (nbutils.py:397-416), for an integer group coordinate r = g0+1.
 // Rows are visited outward (r, r-1, r+1, r-2, ...) while dr^2 < best; exact distance ties keep the
 // first visited node (cKDTree's choice at ties is implementation-defined).
+// rows r-1, r+1, r-2, ... while dr^2 < best (the tail of interp2d_nearest: the element's own row has been searched)
+template <typename R, typename XF>
+__device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, double best, R val, int &node)
+{
+    const int G = ct.G, Q = ct.Q;
+    for (int dr = 1; dr <= G + 1; dr++) {
+        double d2r = (double)dr * (double)dr;
+        if (d2r >= best) break;
+        for (int s = 0; s < 2; s++) {
+            int rr = s ? r + dr : r - dr;
+            if (rr < 0 || rr > G + 1) continue;
+            int g = ext_row(rr, G);
+            int n = ct.rn[g];
+            if (n == 0) continue;
+            int w;
+            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
+            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
+        }
+    }
+    return val;
+}
+
 template <typename R, typename XF>
 __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct, int extrap, int &node)
 {
     node = -1;
     if (x != x || !ct.any_valid) return nan_of<R>();
-    const int G = ct.G, Q = ct.Q, r = g0 + 1;
+    const int Q = ct.Q, r = g0 + 1;
     if ((double)x < ct.xfirst[g0]) return extrap == 0 ? ct.yfirst[g0] : nan_of<R>();
     if ((double)x > ct.xlast[g0]) return extrap == 0 ? ct.ylast[g0] : nan_of<R>();
     double best = __builtin_inf();
@@ -218,21 +241,42 @@ __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct
         }
         if (best <= 1.0) return val;
     }
-    for (int dr = 1; dr <= G + 1; dr++) {
-        double d2r = (double)dr * (double)dr;
-        if (d2r >= best) break;
-        for (int s = 0; s < (dr ? 2 : 1); s++) {
-            int rr = s ? r + dr : r - dr;
-            if (rr < 0 || rr > G + 1) continue;
-            int g = ext_row(rr, G);
-            int n = ct.rn[g];
-            if (n == 0) continue;
-            int w;
-            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
-            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
-        }
+    return nearest_outward<R, XF>(x, r, ct, best, val, node);
+}
+
+// The same on a table without NaN (ct.dense; the series and the table share their type): the row is complete, its end
+// abscissae are the extrapolation bounds (compared as they are: float against float orders like their doubles), the search
+// is a lower bound in a fixed number of steps (no data-dependent trip count, no divergence), and the nearer of the two
+// neighbours is decided on the exact float64 differences — the squares the general routine compares are exact products of
+// those differences, so the decision, ties included (the lower node), is the same.
+template <typename R>
+__device__ __forceinline__ R interp2d_nearest_dense(R x, int g0, const CellTab<R> &ct, int extrap, int &node)
+{
+    node = -1;
+    if (x != x) return nan_of<R>();
+    const int Q = ct.Q, r = g0 + 1;
+    const R *xr = ct.xs + (size_t)g0 * ct.xstride, *yr = ct.ys + (size_t)g0 * Q;
+    if (x < xr[0]) return extrap == 0 ? yr[0] : nan_of<R>();
+    if (x > xr[Q - 1]) return extrap == 0 ? yr[Q - 1] : nan_of<R>();
+    int lo = 0;
+    for (int n = Q; n > 1;) {  // first place whose abscissa is >= x (it exists: x <= xr[Q - 1])
+        const int half = n >> 1;
+        lo = xr[lo + half - 1] < x ? lo + half : lo;
+        n -= half;
     }
-    return val;
+    lo += xr[lo] < x ? 1 : 0;
+    const double d1 = (double)xr[lo] - (double)x;
+    int w = lo;
+    double d = d1;
+    if (lo > 0) {
+        const double d0 = (double)x - (double)xr[lo - 1];
+        if (!(d1 < d0)) { w = lo - 1; d = d0; }
+    }
+    const R val = yr[w];
+    node = r * Q + w;
+    const double best = d * d;
+    if (best <= 1.0) return val;
+    return nearest_outward<R, R>(x, r, ct, best, val, node);
 }
 
 template <typename R>

@@ -260,6 +260,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         CellTab<R> ct;
         ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
         ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1; ct.xstride = Q;
+        ct.dense = true;
         return ct;
     }
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -349,6 +350,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
             for (int e = 0; e < EU; e++) {
                 if constexpr (GROUPED) {
                     if (g0[e] < 0) { nd[e] = -1; a[e] = nan_of<R>(); }
+                    else if (ct.dense) a[e] = interp2d_nearest_dense<R>(v[e], g0[e], ct, extrap, nd[e]);
                     else a[e] = interp2d_nearest<R, R>(v[e], g0[e], ct, extrap, nd[e]);
                 } else {
                     a[e] = interp1d_eval<R>((double)v[e], false, ct.xs, ct.ys, ct.rn[0], ct.yfirst[0], ct.ylast[0], interp, extrap, nd[e], ct.spl);

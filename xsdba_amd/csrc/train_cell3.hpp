@@ -244,9 +244,20 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     for (int it = 0; it < nA; it++) {
         const bool vB = it < nB, vC = it < nC;
         const int tA = it > 0 ? preA : -1, tB = vB ? preB : -1, tC = (it > 0 && vC) ? preC : -1;
-        flip(bA, tA, dlocA);
-        flip(bB, tB, dlocB);
-        flip(bC, tC, dlocC);
+        if constexpr (!DQM || PRESUM) {
+            // branch-free: the three rank reads are in flight together, an entry that is no toggle (padding of the table, a NaN
+            // step) XORs a zero mask into a word of its vector
+            const int rA = (int)rank[max(tA, 0)], rB = (int)rank[max(tB, 0)], rC = (int)rank[max(tC, 0)];
+            const uint32_t mA = (tA >= 0 && rA < nvalid) ? 1u << (rA & 31) : 0u, mB = (tB >= 0 && rB < nvalid) ? 1u << (rB & 31) : 0u,
+                           mC = (tC >= 0 && rC < nvalid) ? 1u << (rC & 31) : 0u;
+            (void)__hip_atomic_fetch_xor(&bA[rA >> 5], mA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_xor(&bB[rB >> 5], mB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_xor(&bC[rC >> 5], mC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            flip(bA, tA, dlocA);
+            flip(bB, tB, dlocB);
+            flip(bC, tC, dlocC);
+        }
         if (it + 1 < nA) preA = tog64[(size_t)(gb + it + 1) * 64 + lane];
         if (it + 1 < nB) preB = tog64[(size_t)(gb - it - 1) * 64 + lane];
         if (it + 1 < nC) preC = tog64[(size_t)(gc3 + it + 1) * 64 + lane];
