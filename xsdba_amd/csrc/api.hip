@@ -849,8 +849,19 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
 
 template <typename R>
 int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *scaling, Plan *pl, char kind,
-                 const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0, int min_periods = 0)
+                 const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0, int min_periods = 0,
+                 const double *h_tnum = nullptr)
 {
+    // a time axis that is affine in the step index (daily data in ns since an epoch: exact integers in float64) is computed
+    // in the kernel instead of gathered: checked here on the host copy, value for value, with the kernel's own expression
+    int tn_affine = 0;
+    double tn0 = 0.0, tnd = 0.0;
+    if (h_tnum && T >= 2) {
+        tn0 = h_tnum[0]; tnd = h_tnum[1] - h_tnum[0];
+        tn_affine = 1;
+        for (int64_t t = 0; t < T; t++)
+            if (!(tn0 + tnd * (double)t == h_tnum[t])) { tn_affine = 0; break; }
+    }
     const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
     const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
@@ -865,13 +876,13 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd);
     }
     return check_launch("k_group_trend");
 }
@@ -910,7 +921,8 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         // the trend is always needed on device in cell-major form
         if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
         else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
-        if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst))) return rc;
+        if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, 0, 0,
+                                  is_device_ptr(tnum) ? (const double *)nullptr : tnum))) return rc;
         trend_cm = (const R *)otr.kernel_dst;
     }
     if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
@@ -935,7 +947,8 @@ int trend_impl(xsdba_hip_ctx *ctx, const void *x, int64_t T, int64_t C, int64_t 
     if ((rc = stage_in(ctx, S_Q, tnum, (size_t)T * sizeof(double), &dtn))) return rc;
     SeriesOut otr;
     if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc;
-    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, preserve_mean))) return rc;
+    if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)nullptr, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, preserve_mean, 0,
+                              is_device_ptr(tnum) ? (const double *)nullptr : tnum))) return rc;
     if ((rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
     return sync_if(ctx, true);
 }

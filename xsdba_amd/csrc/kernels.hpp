@@ -420,8 +420,11 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
-                              int preserve_mean, int min_periods)
+                              int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd)
 {
+    // tn_affine: the time axis is tnum[t] == tn0 + tnd * t exactly for every t (host-checked: daily steps in ns since an
+    // epoch are): the coordinate is computed instead of gathered from L2 in the regression and in the trend evaluation
+    auto TN = [&](int64_t t) { return tn_affine ? tn0 + tnd * (double)t : tnum[t]; };
     // min_periods > 0: rolling-mean mode (RollingMeanDetrend, detrending.py:342-356: da.rolling(center=True, min_periods)
     // .mean()): the window means themselves are the result, NaN where fewer than min_periods values are in the window
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -530,14 +533,14 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             double S[2 * POLY_MAX_DEG + 1], B[POLY_MAX_DEG + 1], cc[POLY_MAX_DEG + 1];
             for (int k = 0; k <= 2 * degree; k++) S[k] = 0.0;
             for (int k = 0; k <= degree; k++) B[k] = 0.0;
-            const double xa = p1 > p0 ? tnum[mem_idx[p0]] : 0.0, xb = p1 > p0 ? tnum[mem_idx[p1 - 1]] : 0.0;
+            const double xa = p1 > p0 ? TN(mem_idx[p0]) : 0.0, xb = p1 > p0 ? TN(mem_idx[p1 - 1]) : 0.0;
             const double xm = 0.5 * (xa + xb), hs = xb > xa ? 0.5 * (xb - xa) : 1.0;
             int n = 0;
             for (int p = p0; p < p1; p++) {
                 const int t = mem_idx[p];
                 const R v = m[t];
                 if (v == v) {
-                    const double u = (tnum[t] - xm) / hs;
+                    const double u = (TN(t) - xm) / hs;
                     double pw = 1.0;
                     for (int k = 0; k <= 2 * degree; k++) { S[k] += pw; if (k <= degree) B[k] += pw * (double)v; pw *= u; }
                     n++;
@@ -549,7 +552,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             if (preserve_mean) {
                 double sm = 0.0;
                 for (int p = p0; p < p1; p++) {
-                    const double u = (tnum[mem_idx[p]] - xm) / hs;
+                    const double u = (TN(mem_idx[p]) - xm) / hs;
                     double y = cc[degree];
                     for (int k = degree - 1; k >= 0; k--) y = y * u + cc[k];
                     sm += y;
@@ -565,7 +568,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             R out = nan_of<R>();
             if (g >= 0) {
                 const double *cg = coef + (size_t)ncoef * g;
-                const double u = (tnum[t] - cg[0]) / cg[1];
+                const double u = (TN(t) - cg[0]) / cg[1];
                 double y = cg[3 + degree];
                 for (int k = degree - 1; k >= 0; k--) y = y * u + cg[3 + k];
                 if (preserve_mean) y = kind == '+' ? y - cg[2] : y / cg[2];
@@ -592,7 +595,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 #pragma unroll
                 for (int k = 0; k < NB; k++) tt[k] = mem_idx[min(pb + k, p1 - 1)];
 #pragma unroll
-                for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = tnum[tt[k]]; }
+                for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = TN(tt[k]); }
 #pragma unroll
                 for (int k = 0; k < NB; k++)
                     if (pb + k < p1 && vv[k] == vv[k]) { sx += xx[k]; sy += (double)vv[k]; n++; }
@@ -608,7 +611,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 #pragma unroll
                     for (int k = 0; k < NB; k++) tt[k] = mem_idx[min(pb + k, p1 - 1)];
 #pragma unroll
-                    for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = tnum[tt[k]]; }
+                    for (int k = 0; k < NB; k++) { vv[k] = m[tt[k]]; xx[k] = TN(tt[k]); }
 #pragma unroll
                     for (int k = 0; k < NB; k++)
                         if (pb + k < p1 && vv[k] == vv[k]) { const double dx = xx[k] - xb; sxx += dx * dx; sxy += dx * ((double)vv[k] - yb); }
@@ -631,7 +634,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             for (int p = p0 + hl; p < p1; p += 32) {
                 int t = mem_idx[p];
                 R v = m[t];
-                if (v == v) { sx += tnum[t]; sy += (double)v; cn += 1.0; }
+                if (v == v) { sx += TN(t); sy += (double)v; cn += 1.0; }
             }
             sx = hsum(sx); sy = hsum(sy); cn = hsum(cn);
             const int n = (int)cn;
@@ -642,7 +645,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                 for (int p = p0 + hl; p < p1; p += 32) {
                     int t = mem_idx[p];
                     R v = m[t];
-                    if (v == v) { double dx = tnum[t] - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                    if (v == v) { double dx = TN(t) - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
                 }
                 sxx = hsum(sxx); sxy = hsum(sxy);
                 slope = sxx > 0 ? sxy / sxx : 0.0;
@@ -657,7 +660,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             int gg[NB];
             double xx[NB];
 #pragma unroll
-            for (int k = 0; k < NB; k++) { const int64_t t = t0 + (int64_t)k * blockDim.x, tc = t < T ? t : T - 1; gg[k] = gidx[tc]; xx[k] = tnum[tc]; }
+            for (int k = 0; k < NB; k++) { const int64_t t = t0 + (int64_t)k * blockDim.x, tc = t < T ? t : T - 1; gg[k] = gidx[tc]; xx[k] = TN(tc); }
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 const int64_t t = t0 + (int64_t)k * blockDim.x;
