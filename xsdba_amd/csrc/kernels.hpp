@@ -420,8 +420,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
-                              int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd)
+                              int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd,
+                              const int *__restrict__ mem_t16)
 {
+    // mem_t16: the plan's packed member table ([16][G] words of two 16-bit time indexes; groups of <= 32 members) or null
     // tn_affine: the time axis is tnum[t] == tn0 + tnd * t exactly for every t (host-checked: daily steps in ns since an
     // epoch are): the coordinate is computed instead of gathered from L2 in the regression and in the trend evaluation
     auto TN = [&](int64_t t) { return tn_affine ? tn0 + tnd * (double)t : tnum[t]; };
@@ -580,7 +582,36 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     }
     // per-group least squares.  Many short groups (day-of-year: 365 groups of ~30 members): one LANE per group, a
     // serial loop over its members and no cross-lane reduction at all.
-    if (lane_per_group) {
+    if (lane_per_group && mem_t16 && tn_affine) {
+        // groups of <= 32 members on an affine time axis: the member indexes arrive as 16 coalesced words and nothing else is
+        // gathered from global memory — both passes of the regression read the window means from LDS, in member order
+        for (int g = threadIdx.x; g < G; g += blockDim.x) {
+            uint32_t w[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) w[u] = (uint32_t)mem_t16[(size_t)u * G + g];
+            double sx = 0, sy = 0;
+            int n = 0;
+#pragma unroll
+            for (int y = 0; y < 32; y++) {
+                const uint32_t t = (w[y / 2] >> (16 * (y & 1))) & 0xFFFFu;
+                const R v = t != 0xFFFFu ? m[t] : nan_of<R>();
+                if (v == v) { sx += TN(t); sy += (double)v; n++; }
+            }
+            const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
+            double slope = 0.0;
+            if (degree >= 1 && n >= 2) {
+                double sxx = 0, sxy = 0;
+#pragma unroll
+                for (int y = 0; y < 32; y++) {
+                    const uint32_t t = (w[y / 2] >> (16 * (y & 1))) & 0xFFFFu;
+                    const R v = t != 0xFFFFu ? m[t] : nan_of<R>();
+                    if (v == v) { const double dx = TN(t) - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                }
+                slope = sxx > 0 ? sxy / sxx : 0.0;
+            }
+            coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
+        }
+    } else if (lane_per_group) {
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
             const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
             double sx = 0, sy = 0;
