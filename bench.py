@@ -133,16 +133,16 @@ def main():
     o_af, o_hq = ctx.empty((C, G, Q), f32), ctx.empty((C, G, Q), f32)
     o_scen = ctx.empty((C, T), f32)
     o_sc = ctx.empty((C, G), f32) if method == "dqm" else None
-    o_trend = ctx.empty((C, T), f32) if method == "dqm" else None
     ctx.synchronize()
 
     def step():
         """one pass of the hot path over this rank's cells; returns the device outputs"""
         if method == "dqm":
             af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx, out=(o_af, o_hq, o_sc))
-            scen, trend = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind, ctx=ctx,
-                                         out=(o_scen, o_trend))
-            return [af, hq, sc, scen, trend]
+            # (what DetrendedQuantileMapping.adjust runs: scen only — the trend is a line per group, evaluated by the mapping kernel)
+            scen, _ = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, 1, "nearest", "constant", kind, ctx=ctx,
+                                     out=(o_scen, None), want_trend=False)
+            return [af, hq, sc, scen]
         af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind, ctx=ctx, out=(o_af, o_hq))
         if method == "qdm":
             scen, _ = hip.qdm_adjust(sim, af, q, gidx, W, rank_window, "nearest", "constant", kind, want_sim_q=False, ctx=ctx,

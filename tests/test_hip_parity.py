@@ -809,3 +809,28 @@ def test_train_long_rows_and_other_quantile_counts(hip, method, T, W, Q):
         eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, 365, W, q, "+")
         assert_close(sc, esc, rtol=2e-6, what="scaling")
         assert_close(hq, ehq, rtol=3e-6, atol=3e-5, what="hist_q")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_adjust_without_trend_array_is_identical(hip, kind):
+    """want_trend=False: the mapping kernel evaluates the per-group regression line from the trend kernel's coefficients
+    instead of reading a [cell, time] trend array — same expression, same values: scen must not change by a bit (affine and
+    non-affine time axes, NaNs in sim, time steps in no group)"""
+    rng = np.random.default_rng(5)
+    C, T, G, Q, W = 9, 3650, 365, 20, 31
+    gidx = (np.arange(T) % 365).astype(np.int32)
+    gidx[rng.random(T) < 0.01] = -1
+    base = 280 if kind == "+" else 5
+    sim = (base + rng.gamma(2.0, 2.0, (C, T)) + 0.001 * np.arange(T)).astype(np.float32)
+    sim[rng.random((C, T)) < 0.02] = np.nan
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    hq = np.sort((base + rng.gamma(2.0, 2.0, (C, G, Q))).astype(np.float32), axis=-1)
+    af = (rng.normal(0, 1, (C, G, Q)) if kind == "+" else 1 + 0.2 * rng.random((C, G, Q))).astype(np.float32)
+    sc = (rng.normal(0, 1, (C, G)) if kind == "+" else 1 + 0.1 * rng.random((C, G))).astype(np.float32)
+    for tnum in ((np.arange(T, dtype=np.float64) + 11000.0) * 86400e9, np.cumsum(1.0 + rng.random(T)) * 1e13):
+        for degree in (0, 1):
+            s1, tr = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, degree, "nearest", "constant", kind)
+            s0, none = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, degree, "nearest", "constant", kind, want_trend=False)
+            assert none is None and tr is not None
+            np.testing.assert_array_equal(np.asarray(s0).view(np.uint32), np.asarray(s1).view(np.uint32))

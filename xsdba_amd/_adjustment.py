@@ -396,6 +396,24 @@ def _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P):
     return np.ascontiguousarray(np.repeat(trend, P, axis=0))
 
 
+_DQM_SCEN_ONLY = False  # set by scen_only(): the caller will drop the trend (DetrendedQuantileMapping._adjust takes .scen)
+
+
+class scen_only:
+    """Inside this context ``dqm_adjust`` may leave the trend out of its result: the reference's `DetrendedQuantileMapping.
+    _adjust` (adjustment.py:659-668) keeps `.scen` only, and under dask the trend is then never computed; here the mapping
+    kernel evaluates the per-group regression line itself instead of reading a trend array written for nobody."""
+
+    def __enter__(self):
+        global _DQM_SCEN_ONLY
+        self._old, _DQM_SCEN_ONLY = _DQM_SCEN_ONLY, True
+
+    def __exit__(self, *exc):
+        global _DQM_SCEN_ONLY
+        _DQM_SCEN_ONLY = self._old
+        return False
+
+
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], trend=[])
 def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
     """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
@@ -458,10 +476,13 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
         trend_in = _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P)
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
     else:
-        scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind)
+        scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind,
+                                     want_trend=not _DQM_SCEN_ONLY)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
-    return Dataset({"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen"),
-                    "trend": _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")})
+    out = {"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen")}
+    if trend is not None:
+        out["trend"] = _series_like(sim, trend, cell_dims, cell_shape, group.dim, "trend")
+    return Dataset(out)
 
 
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], sim_q=[])

@@ -259,9 +259,12 @@ class DetrendedQuantileMapping(TrainAdjust):
         return ds, {"group": group, "kind": kind, "adapt_freq_thresh": adapt_freq_thresh, "max_tail_factor": max_tail_factor}
 
     def _adjust(self, sim, interp="nearest", extrapolation="constant", detrend=1):
-        out = dqm_adjust(self.ds.assign(sim=sim), interp=interp, extrapolation=extrapolation, detrend=detrend,
-                         group=self.group, kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh,
-                         max_tail_factor=self.max_tail_factor)
+        from ._adjustment import scen_only
+
+        with scen_only():  # (.scen is all that is kept, like the reference: the trend array need not exist)
+            out = dqm_adjust(self.ds.assign(sim=sim), interp=interp, extrapolation=extrapolation, detrend=detrend,
+                             group=self.group, kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh,
+                             max_tail_factor=self.max_tail_factor)
         scen = out["scen"]
         scen.attrs["units"] = sim.attrs.get("units", "")  # "Detrending needs units." (adjustment.py:669-670)
         return scen

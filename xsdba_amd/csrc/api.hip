@@ -722,10 +722,11 @@ inline unsigned trend_threads()
 template <typename R>
 int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *af, const R *hq, int G, int Q,
                      const int *d_gidx, int interp, int extrap, char kind, R *scen_cm, int *node, const R *scaling,
-                     const R *trend_cm, int tkind = 0, int skip0 = 0)
+                     const R *trend_cm, int tkind = 0, int skip0 = 0, xs::TrendCoef tc = xs::TrendCoef())
 {
     if (!tkind) tkind = (int)kind;
-    const size_t tab = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
+    const size_t tab0 = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
+    const size_t tab = tab0 + (tc.coef ? (size_t)3 * G * sizeof(double) : 0);  // + the regression coefficients of the cell
     const char *name = scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust";
     if (s.st != 1) return fail(XSDBA_E_ARG, "internal: the adjust kernels expect time-contiguous rows");
     // mode switches are template parameters of the kernel: pick the instantiation
@@ -741,10 +742,11 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
             const unsigned nthr = (!getenv("XSDBA_HIP_ADJ_THREADS") && tab > 54 * 1024) ? 768u : adj_threads();
             hipLaunchKernelGGL((xs::k_qm_adjust<R, true, GROUPED, DQM>), dim3((unsigned)C), dim3(nthr), tab, ctx->stream,
                                (const R *)s.dev, T, C, s.sc, af, hq, G, Q, d_gidx, interp, extrap, (int)kind, scen_cm, T, node,
-                               scaling, trend_cm, (unsigned char *)nullptr, (size_t)0, tkind, skip0);
+                               scaling, trend_cm, (unsigned char *)nullptr, (size_t)0, tkind, skip0, tc);
         } else {  // table larger than the LDS: per-block slice of a global scratch buffer, cells walked grid-stride
             const unsigned nblk = (unsigned)std::min<int64_t>(C, 1024);
             void *scratch;
+            if (tc.coef) return fail(XSDBA_E_ARG, "internal: coefficient trends need the table in LDS");
             if ((rc = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc;
             LaunchScope ls(ctx, name);
             hipLaunchKernelGGL((xs::k_qm_adjust<R, false, GROUPED, DQM>), dim3(nblk), dim3(256), 0, ctx->stream, (const R *)s.dev, T,
@@ -850,7 +852,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
 template <typename R>
 int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, const R *scaling, Plan *pl, char kind,
                  const double *d_tnum, int degree, R *trend_cm, int preserve_mean = 0, int min_periods = 0,
-                 const double *h_tnum = nullptr)
+                 const double *h_tnum = nullptr, double *coef_out = nullptr, xs::TrendCoef *tc_out = nullptr)
 {
     // a time axis that is affine in the step index (daily data in ns since an epoch: exact integers in float64) is computed
     // in the kernel instead of gathered: checked here on the host copy, value for value, with the kernel's own expression
@@ -862,6 +864,7 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         for (int64_t t = 0; t < T; t++)
             if (!(tn0 + tnd * (double)t == h_tnum[t])) { tn_affine = 0; break; }
     }
+    if (tc_out) { tc_out->coef = coef_out; tc_out->tnum = d_tnum; tc_out->affine = tn_affine; tc_out->t0 = tn0; tc_out->dt = tnd; }
     const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
     const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
@@ -876,13 +879,13 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32, coef_out);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32, coef_out);
     }
     return check_launch("k_group_trend");
 }
@@ -913,20 +916,35 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
     SeriesOut o, otr;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     const R *trend_cm;
+    xs::TrendCoef tcoef;
     if (trend_given) {
         const void *dtr;
         if ((rc = stage_in(ctx, S_OUT1, trend, (size_t)T * C * sizeof(R), &dtr))) return rc;
         trend_cm = (const R *)dtr;
     } else {
         // the trend is always needed on device in cell-major form
-        if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
-        else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
-        if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, 0, 0,
-                                  is_device_ptr(tnum) ? (const double *)nullptr : tnum))) return rc;
-        trend_cm = (const R *)otr.kernel_dst;
+        // nobody asked for the trend array and it is a line per group: the trend kernel leaves its coefficients and the mapping
+        // kernel evaluates them per element — no [cell][time] array written and read back
+        const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double);
+        // (series long enough for the trend kernel to park its window means in the trend buffer keep the array)
+        const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();  // as launch_trend
+        const bool means_in_regs = pl->W == 1 || T <= (int64_t)24 * tthr;
+        if (!trend && degree <= 1 && means_in_regs && tab_c <= (size_t)ctx->lds_limit && !getenv("XSDBA_HIP_TREND_ARRAY")) {
+            void *cbuf;
+            if ((rc = ensure(ctx, S_CM2, (size_t)C * G * 3 * sizeof(double), &cbuf))) return rc;
+            if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)nullptr, 0, 0,
+                                      is_device_ptr(tnum) ? (const double *)nullptr : tnum, (double *)cbuf, &tcoef))) return rc;
+            trend_cm = nullptr;
+        } else {
+            if (trend) { if ((rc = series_out_begin<R>(ctx, S_OUT1, S_CM2, trend, T, C, ost, osc, &otr))) return rc; }
+            else { if ((rc = ensure(ctx, S_CM2, (size_t)T * C * sizeof(R), &otr.kernel_dst))) return rc; }
+            if ((rc = launch_trend<R>(ctx, s, T, C, (const R *)dsc, pl, kind, (const double *)dtn, degree, (R *)otr.kernel_dst, 0, 0,
+                                      is_device_ptr(tnum) ? (const double *)nullptr : tnum))) return rc;
+            trend_cm = (const R *)otr.kernel_dst;
+        }
     }
     if ((rc = launch_qm_adjust<R>(ctx, s, T, C, (const R *)daf, (const R *)dhq, G, Q, pl->d_gidx, interp, extrap, kind,
-                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, trend_cm, tkind, skip0))) return rc;
+                                  (R *)o.kernel_dst, nullptr, (const R *)dsc, trend_cm, tkind, skip0, tcoef))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;
     if (!trend_given && trend && (rc = series_out_end<R>(ctx, &otr, T, C))) return rc;
     return sync_if(ctx, o.copy_back || otr.copy_back || !is_device_ptr(sim) || (tnum && !is_device_ptr(tnum)) || (trend_given && !is_device_ptr(trend)));

@@ -306,27 +306,38 @@ __device__ __forceinline__ void tab_spline(CellTab<R> &ct, const TabLds<R> &t, i
 // buffer (L2-resident) and the block walks the cells grid-stride.
 // GROUPED (more than one group: 2-D nearest neighbour) and DQM (scaling + trend supplied) are template parameters so
 // that the per-element loop carries no mode branches.  The series are cell-major contiguous rows (time stride 1).
+// DQM without a trend array: the per-group regression coefficients (x_mean, y_mean, slope) of k_group_trend, [cell][G][3]
+// float64, and the time axis; the kernel evaluates the trend of an element itself (same expression, same value)
+struct TrendCoef {
+    const double *coef = nullptr, *tnum = nullptr;
+    int affine = 0;
+    double t0 = 0.0, dt = 0.0;
+};
+
 template <typename R, bool TAB_LDS, bool GROUPED, bool DQM>
 __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
                             const R *__restrict__ af, const R *__restrict__ hist_q, int G, int Q,
                             const int *__restrict__ gidx, int interp, int extrap, int kind, R *__restrict__ scen,
                             int64_t osc, int *__restrict__ node, const R *__restrict__ scaling,
                             const R *__restrict__ trend, unsigned char *__restrict__ gscratch, size_t gstride, int tkind,
-                            int skip0)
+                            int skip0, TrendCoef tc = TrendCoef())
 {
     // tkind: the kind of the detrending (PolyDetrend has one of its own, detrending.py:102-120); skip0: mult_skip_zeros —
     // where the trend is 0 the value is kept instead of divided (:112-113)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *tabmem = TAB_LDS ? smem : gscratch + (size_t)blockIdx.x * gstride;
     TabLds<R> tl = tab_carve<R>(tabmem, G, Q);
+    double *cl = reinterpret_cast<double *>(smem + (TAB_LDS ? ((tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) : 0));  // [G][3] when tc.coef
     const int Ti = (int)T;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        if (DQM && tc.coef)
+            for (int i = threadIdx.x; i < 3 * G; i += blockDim.x) cl[i] = tc.coef[(size_t)c * 3 * G + i];  // (tab_stage ends on a barrier)
         CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
         if constexpr (!GROUPED) tab_spline<R>(ct, tl, interp);
         const R *x = sim + c * sc;
         R *o = scen + c * osc;
         const R *scal = DQM ? scaling + (size_t)c * G : nullptr;
-        const R *trc = DQM ? trend + (size_t)c * T : nullptr;
+        const R *trc = (DQM && trend) ? trend + (size_t)c * T : nullptr;
         int *ndc = node ? node + (size_t)c * T : nullptr;
         // EU elements per thread and round: their table searches are independent chains of LDS reads
         constexpr int EU = DQM ? 2 : 4;
@@ -342,7 +353,12 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
                 if constexpr (DQM) {
                     R s = g0[e] >= 0 ? scal[g0[e]] : nan_of<R>();
                     v[e] = apply_corr<R>(v[e], s, kind);
-                    tr[e] = trc[t];
+                    if (trc) tr[e] = trc[t];
+                    else {
+                        const int g = g0[e];
+                        const double xt = tc.affine ? tc.t0 + tc.dt * (double)t : tc.tnum[t];
+                        tr[e] = g >= 0 ? (R)(cl[3 * g + 1] + cl[3 * g + 2] * (xt - cl[3 * g])) : nan_of<R>();
+                    }
                     if (!(skip0 && tr[e] == (R)0)) v[e] = apply_corr<R>(v[e], invert<R>(tr[e], tkind), tkind);
                 }
             }
@@ -421,8 +437,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
                               int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd,
-                              const int *__restrict__ mem_t16)
+                              const int *__restrict__ mem_t16, double *__restrict__ coef_out)
 {
+    // coef_out ([cell][G][3], degree <= 1 without preserve_mean): leave the regression coefficients instead of the trend —
+    // the DQM adjust kernel evaluates it per element (no [cell][time] array written and read back)
     // mem_t16: the plan's packed member table ([16][G] words of two 16-bit time indexes; groups of <= 32 members) or null
     // tn_affine: the time axis is tnum[t] == tn0 + tnd * t exactly for every t (host-checked: daily steps in ns since an
     // epoch are): the coordinate is computed instead of gathered from L2 in the regression and in the trend evaluation
@@ -685,6 +703,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         }
     }
     __syncthreads();
+    if (coef_out) {
+        for (int i = threadIdx.x; i < 3 * G; i += blockDim.x) coef_out[(size_t)c * 3 * G + i] = coef[i];
+        return;
+    }
     {
         constexpr int NB = 4;
         for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {

@@ -207,8 +207,10 @@ def qm_adjust_linear2d(sim, af, hist_q, group_coord, new_group, extrap="constant
 
 
 def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="nearest", extrap="constant", kind="+",
-               ctx=None, out=None, trend_in=None, trend_kind=None, mult_skip_zeros=False):
-    """_adjustment.dqm_adjust -> (scen, trend) each [C, T].  ``trend_in`` ([C, T]): use this trend instead of fitting one
+               ctx=None, out=None, trend_in=None, trend_kind=None, mult_skip_zeros=False, want_trend=True):
+    """_adjustment.dqm_adjust -> (scen, trend) each [C, T] (``want_trend=False``: trend is None and, for a fitted line per
+    group, never exists as an array: the mapping kernel evaluates the regression coefficients per element).
+    ``trend_in`` ([C, T]): use this trend instead of fitting one
     (``degree`` and ``time_num`` are then ignored); ``trend_kind`` / ``mult_skip_zeros``: the detrending object's own kind
     and option (detrending.py:102-120), default: the kind of the adjustment."""
     ctx = ctx or default_context()
@@ -228,7 +230,7 @@ def dqm_adjust(sim, af, hist_q, scaling, gidx, W, time_num, degree=1, interp="ne
         tn, degree = None, (-1 if tk == kind and not mult_skip_zeros else (-2 if tk == "+" else (-4 if mult_skip_zeros else -3)))
     else:
         tn = time_num if isinstance(time_num, DeviceArray) else np.ascontiguousarray(time_num, np.float64)
-        trend = out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)
+        trend = (out[1] if out else _out(ctx, s.dev, (s.C, s.T), s.dtype)) if want_trend else None
     check(load().xsdba_hip_dqm_adjust(ctx.handle, s.ptr, dtype_code(s.dtype), _i64(s.T), _i64(s.C), _i64(s.st), _i64(s.sc),
                                       _vp(af), _vp(hist_q), _vp(scaling), C.c_int(G), C.c_int(Q), _vp(g), C.c_int(W),
                                       _vp(tn), C.c_int(degree), C.c_int(INTERP[interp]), C.c_int(EXTRAP[extrap]),
