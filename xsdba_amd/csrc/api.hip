@@ -726,7 +726,7 @@ int launch_qm_adjust(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C
 {
     if (!tkind) tkind = (int)kind;
     const size_t tab0 = (xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15;
-    const size_t tab = tab0 + (tc.coef ? (size_t)3 * G * sizeof(double) : 0);  // + the regression coefficients of the cell
+    const size_t tab = tab0 + (tc.coef ? (size_t)3 * G * sizeof(double) + (((size_t)G * sizeof(float) + 15) & ~(size_t)15) : 0);  // + the regression coefficients and the scaling factors of the cell
     const char *name = scaling ? "k_qm_adjust(dqm)" : "k_qm_adjust";
     if (s.st != 1) return fail(XSDBA_E_ARG, "internal: the adjust kernels expect time-contiguous rows");
     // mode switches are template parameters of the kernel: pick the instantiation
@@ -925,7 +925,7 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         // the trend is always needed on device in cell-major form
         // nobody asked for the trend array and it is a line per group: the trend kernel leaves its coefficients and the mapping
         // kernel evaluates them per element — no [cell][time] array written and read back
-        const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double);
+        const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double) + (((size_t)G * sizeof(float) + 15) & ~(size_t)15);
         // (series long enough for the trend kernel to park its window means in the trend buffer keep the array)
         const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();  // as launch_trend
         const bool means_in_regs = pl->W == 1 || T <= (int64_t)24 * tthr;

@@ -330,17 +330,21 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
     double *cl = reinterpret_cast<double *>(smem + (TAB_LDS ? ((tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) : 0));  // [G][3] when tc.coef
     const int Ti = (int)T;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
-        if (DQM && tc.coef)
-            for (int i = threadIdx.x; i < 3 * G; i += blockDim.x) cl[i] = tc.coef[(size_t)c * 3 * G + i];  // (tab_stage ends on a barrier)
+        if (DQM && tc.coef) {  // (tab_stage ends on a barrier)
+            for (int i = threadIdx.x; i < 3 * G; i += blockDim.x) cl[i] = tc.coef[(size_t)c * 3 * G + i];
+            // the cell's scaling factors ride behind the coefficients: read from LDS per element instead of gathered from L2
+            float *sl = reinterpret_cast<float *>(cl + 3 * G);
+            for (int i = threadIdx.x; i < G; i += blockDim.x) sl[i] = (float)scaling[(size_t)c * G + i];
+        }
         CellTab<R> ct = tab_stage<R>(tl, hist_q + (size_t)c * G * Q, Q, af + (size_t)c * G * Q, G, Q);
         if constexpr (!GROUPED) tab_spline<R>(ct, tl, interp);
         const R *x = sim + c * sc;
         R *o = scen + c * osc;
-        const R *scal = DQM ? scaling + (size_t)c * G : nullptr;
+        const R *scal = DQM ? ((tc.coef && sizeof(R) == 4) ? reinterpret_cast<const R *>(cl + 3 * G) : scaling + (size_t)c * G) : nullptr;
         const R *trc = (DQM && trend) ? trend + (size_t)c * T : nullptr;
         int *ndc = node ? node + (size_t)c * T : nullptr;
         // EU elements per thread and round: their table searches are independent chains of LDS reads
-        constexpr int EU = DQM ? 2 : 4;
+        constexpr int EU = 4;
         for (int t0 = threadIdx.x; t0 < Ti; t0 += EU * blockDim.x) {
             R v[EU], tr[EU], a[EU];
             int g0[EU], nd[EU];
