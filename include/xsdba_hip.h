@@ -202,7 +202,9 @@ int xsdba_hip_qm_adjust_cubic2d(xsdba_hip_ctx *ctx, const void *sim, int dtype, 
 /* ---- a15-a17: _adjustment.dqm_adjust (_adjustment.py:679-780; adjustment.py:659-668): nearest
  * broadcast of `scaling`, PolyDetrend(degree) fitted per group on the window means against `time_num`
  * (detrending.py:165-208; float64 abscissa, e.g. ns since 1970 as xarray.polyfit uses), quantile
- * mapping of the detrended series, retrend.  trend (nullable) has the layout of scen.
+ * mapping of the detrended series, retrend.  trend (nullable) has the layout of scen; with trend == NULL and degree <= 1
+ * no trend array exists at all: the fit leaves (x_mean, y_mean, slope) per group and the mapping kernel evaluates the line
+ * per element — what DetrendedQuantileMapping._adjust needs, which keeps `.scen` only (adjustment.py:659-668).
  * degree == XSDBA_TREND_GIVEN: `trend` is read instead of fitted (contiguous [cell][time]; time_num may be null) — the
  * pooled fit of Grouper(add_dims=...), where one trend from the mean over the pooled members (detrending.py:196-199)
  * serves all of them. */
