@@ -834,3 +834,44 @@ def test_dqm_adjust_without_trend_array_is_identical(hip, kind):
             s0, none = hip.dqm_adjust(sim, af, hq, sc, gidx, W, tnum, degree, "nearest", "constant", kind, want_trend=False)
             assert none is None and tr is not None
             np.testing.assert_array_equal(np.asarray(s0).view(np.uint32), np.asarray(s1).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,W,leap", [(10950, 31, False), (3650, 31, False), (7300, 30, False), (10958, 31, True), (10950, 1, False)])
+@pytest.mark.parametrize("kind", ["+", "*"])
+def test_dqm_train_group_sums_vs_running_sums(hip, T, W, leap, kind):
+    """dqm_train on the three-stream kernel forms the group sums from float64 running sums over time (GroupSumHook); the
+    two-stream kernel (XSDBA_HIP_TRAIN3=0) keeps sums updated by the toggles.  Same tables to 2 ulp on every series length
+    class (EPT 4 / 8 / 11), even windows, leap days, NaNs, an all-NaN cell — and against the oracle."""
+    import os
+
+    rng = np.random.default_rng(T + W)
+    C, Q = 6, 20
+    if leap:
+        g, t, y = np.empty(T, np.int32), 0, 0
+        while t < T:
+            n = 366 if y % 4 == 0 else 365
+            m = min(n, T - t)
+            g[t:t + m] = np.arange(m)
+            t += m
+            y += 1
+        gidx, G = g, 366
+    else:
+        gidx, G = (np.arange(T) % 365).astype(np.int32), 365
+    base = (10 + 5 * np.sin(2 * np.pi * gidx / 365.0))[None, :]
+    ref = (base + rng.gamma(2.0, 1.5, (C, T))).astype(np.float32)
+    hist = (base * 1.1 + rng.gamma(2.0, 1.7, (C, T))).astype(np.float32)
+    hist[rng.random((C, T)) < 0.03] = np.nan
+    ref[2] = np.nan
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    os.environ.pop("XSDBA_HIP_TRAIN3", None)
+    a3 = [np.asarray(v) for v in hip.dqm_train(ref, hist, gidx, G, W, q, kind)]
+    os.environ["XSDBA_HIP_TRAIN3"] = "0"
+    try:
+        a2 = [np.asarray(v) for v in hip.dqm_train(ref, hist, gidx, G, W, q, kind)]
+    finally:
+        os.environ.pop("XSDBA_HIP_TRAIN3", None)
+    exp = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+    for name, x3, x2, xe in zip(("af", "hist_q", "scaling"), a3, a2, exp):
+        assert_close(x3, x2, rtol=3e-7, atol=1e-6 if kind == "+" else 0.0, what=f"{name} (three-stream vs two-stream)")
+        assert_close(x3, xe, rtol=3e-7, atol=1e-6 if kind == "+" else 0.0, what=f"{name} (vs oracle)")

@@ -110,3 +110,35 @@ def test_lanes_other_group_shapes(G, members):
     scen, _ = hip.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "*", want_sim_q=False)
     exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "*")
     np.testing.assert_array_equal(np.asarray(scen), exp)
+
+
+@pytest.mark.parametrize("Q", [1, 2, 7, 100, 254])
+def test_lanes_quantile_counts(Q):
+    """any number of nodes the one-byte node code can address (Q < 255); one node: every percent rank maps to it"""
+    from xsdba_amd import hip
+
+    C, T = 4, 3650
+    sim, gidx, G = _case("zero_inflated", C, T, 100 + Q)
+    rng = np.random.default_rng(Q)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+    for extrap in ("constant", "nan"):
+        scen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, "*", want_sim_q=False)
+        exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, "*")
+        np.testing.assert_array_equal(np.asarray(scen), exp)
+
+
+def test_lanes_tiny_and_ragged():
+    """two groups of 32 members; 129 groups (three chunks of 64, the last one lane wide) with 1..9 members each"""
+    from xsdba_amd import hip
+
+    rng = np.random.default_rng(11)
+    for G, sizes in ((2, [32, 32]), (129, list(rng.integers(1, 10, 129)))):
+        gidx = rng.permutation(np.repeat(np.arange(G), sizes)).astype(np.int32)
+        T, C, Q = gidx.size, 3, 9
+        sim = np.round(rng.gamma(2.0, 2.0, (C, T)), 1).astype(np.float32)
+        q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+        af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+        scen, _ = hip.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "+", want_sim_q=False)
+        exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "+")
+        np.testing.assert_array_equal(np.asarray(scen), exp)
