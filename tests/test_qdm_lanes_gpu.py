@@ -142,3 +142,27 @@ def test_lanes_tiny_and_ragged():
         scen, _ = hip.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "+", want_sim_q=False)
         exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "+")
         np.testing.assert_array_equal(np.asarray(scen), exp)
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_inflated", "capped", "nan_sim", "leap", "ungrouped"])
+@pytest.mark.parametrize("kind,extrap", [("*", "constant"), ("+", "nan")])
+def test_rank_window_without_sim_q(name, kind, extrap):
+    """rank_window=True without the sim_q output: k_qdm_cell maps 2r -> node through the per-cell table of the groups that
+    share the middle group's (N, pmin, pmax) and evaluates the others directly — the same values as with sim_q requested
+    (no table) and as the oracle"""
+    import zlib
+
+    from xsdba_amd import hip
+
+    C, T, Q = 6, 10950 if name != "leap" else 10958, 20
+    sim, gidx, G = _case(name, C, T, zlib.crc32(f"rw{name}{kind}".encode()))
+    rng = np.random.default_rng(17)
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    af = (1.0 + 0.3 * rng.standard_normal((C, G, Q))).astype(np.float32)
+    scen, none = hip.qdm_adjust(sim, af, q, gidx, 31, True, "nearest", extrap, kind, want_sim_q=False)
+    full, sim_q = hip.qdm_adjust(sim, af, q, gidx, 31, True, "nearest", extrap, kind, want_sim_q=True)
+    exp, esq = oracle.qdm_adjust(sim, af, q, gidx, 31, True, "nearest", extrap, kind)
+    assert none is None
+    np.testing.assert_array_equal(np.asarray(scen).view(np.uint32), np.asarray(full).view(np.uint32))
+    np.testing.assert_array_equal(np.asarray(scen), exp)
+    np.testing.assert_array_equal(np.asarray(sim_q), esq)

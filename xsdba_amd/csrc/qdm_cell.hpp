@@ -128,6 +128,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             gstat[3 * g + 2] = ((N - (double)nmax) + ((double)nmax + 1.0) / 2.0) / N;
         };
         for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
+        if (tid == 0) gstat[3 * (G / 2)] = 0.0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
         if (af && wid == 0) {
             const R xq = lane < Q ? quantiles[lane] : nan_of<R>();
@@ -258,19 +259,56 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         const R tab_yf = tyfl[0], tab_yl = tyfl[1];
         const bool bad_nodes = af && G > 1 && tmeta[3];
         const R *afc = af ? af + (size_t)c * G * Q : nullptr;
+        // Grouped tables, no sim_q wanted: the node a percent rank maps to depends on (2r, N, pmin, pmax) only, and most groups
+        // share the middle group's triple (full windows, untied extremes).  Its map 2r -> node is tabulated once per cell with
+        // the very expressions evaluated per element below (two float64 divisions and a bisection each); an element of such a
+        // group costs one table byte.  The table lives in the unused tail of gstat (groups beyond G).
+        unsigned char *tabD = reinterpret_cast<unsigned char *>(gstat + 3 * G);
+        const double N0 = gstat[3 * (G / 2)], pmin0 = gstat[3 * (G / 2) + 1], pmax0 = gstat[3 * (G / 2) + 2];
+        const int n0 = (int)N0;
+        const bool use_tab = af && G > 1 && !sim_q && !bad_nodes && n0 > 0 && (size_t)(2 * n0 + 2) <= (size_t)(QC::GMAX - G) * 24 && Q <= 63;
+        auto node_code = [&](double sq) -> int {  // 255: NaN; else node | 0x40 below the first node | 0x80 above the last
+            if (sq != sq) return 255;
+            if (sq < (double)qn[0]) return 0x40;
+            if (sq > (double)qn[Q - 1]) return (Q - 1) | 0x80;
+            int w;
+            (void)row_nearest<R, double>(sq, qn, Q, &w);
+            return w;
+        };
+        if (use_tab) {
+            for (int r2 = tid; r2 < 2 * n0 + 2; r2 += NT) {
+                const double r = (double)r2 / 2.0;
+                const double pr = r / N0;
+                tabD[r2] = (unsigned char)(r2 ? node_code(pmax0 * (pr - pmin0) / (pmax0 - pmin0)) : 255);
+            }
+            __syncthreads();
+        }
         for (int t = tid; t < (int)T; t += NT) {
             const int g = gidx ? gidx[t] : 0;
             const int r2 = r2buf[t];
             const R v = ser.at_time(t);
             double sq = __builtin_nan("");
+            int code = -1;
             if (r2 && g >= 0) {
                 const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
-                const double r = (double)r2 / 2.0;
-                const double pr = r / N;
-                sq = interp == -1 ? r : pmax * (pr - pmin) / (pmax - pmin);  // interp -1 (ranks only): the average ranks themselves
+                if (use_tab && N == N0 && pmin == pmin0 && pmax == pmax0) code = tabD[r2];
+                else {
+                    const double r = (double)r2 / 2.0;
+                    const double pr = r / N;
+                    sq = interp == -1 ? r : pmax * (pr - pmin) / (pmax - pmin);  // interp -1 (ranks only): the average ranks themselves
+                }
             }
             if (sim_q) sim_q[(size_t)c * T + t] = sq;
-            if (af) {
+            if (af && use_tab) {
+                if (code < 0) code = g >= 0 ? node_code(sq) : 255;
+                R a = nan_of<R>();
+                if (code != 255) {
+                    a = afc[(size_t)g * Q + (code & 0x3F)];
+                    flag_cell |= a != a;
+                    if ((code & 0xC0) && extrap != 0) a = nan_of<R>();
+                }
+                scen[(size_t)c * T + t] = apply_corr<R>(v, a, kind);
+            } else if (af) {
                 R a;
                 if (G == 1) {
                     int nd_unused;
