@@ -121,11 +121,12 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             if (re < nvalid && ser.eq_ranks(re, r)) re = run_end(r);
         };
         // extreme percent ranks of a group (utils.rank :631-635: mn / mx of rank / N with average ties), once per group
+        // (phase C parks the three counts of a group; the float64 divisions are done for all groups at once after it, by a
+        //  lane per group, instead of once per group step by a whole wave)
         auto put_stats = [&](int g, int n, int nmin, int nmax) {
-            const double N = (double)n;
-            gstat[3 * g] = N;
-            gstat[3 * g + 1] = (((double)nmin + 1.0) / 2.0) / N;
-            gstat[3 * g + 2] = ((N - (double)nmax) + ((double)nmax + 1.0) / 2.0) / N;
+            gstat[3 * g] = (double)n;
+            gstat[3 * g + 1] = (double)nmin;
+            gstat[3 * g + 2] = (double)nmax;
         };
         for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
         if (tid == 0) gstat[3 * (G / 2)] = 0.0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
@@ -208,15 +209,11 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 const int incl = wave_incl_scan(cl);
                 const int n = __builtin_amdgcn_readlane(incl, 63);
                 if (n == 0) continue;  // no valid value in the ranking row: every member keeps "no rank"
-                int run = incl - cl, myfirst = -1, mylast = -1;
+                int run = incl - cl;
 #pragma unroll
                 for (int j = 0; j < WPL; j++) {
                     pw[lane * WPL + j] = (uint16_t)run;
                     run += __popc(wv[j]);
-                    if (wv[j]) {
-                        if (myfirst < 0) myfirst = (lane * WPL + j) * 32 + __ffs((int)wv[j]) - 1;
-                        mylast = (lane * WPL + j) * 32 + 31 - __clz((int)wv[j]);
-                    }
                 }
                 lds_wave_fence();
                 // members of the row with a global rank below r
@@ -226,9 +223,20 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     return (int)pw[w] + __popc(bits[w] & ((1u << (r & 31)) - 1u));
                 };
                 if (slice == 0) {  // extreme tie counts of the row (wave-uniform work)
+                    // first / last member of the row: the words of the first / last lane that holds any, read into scalars
                     const unsigned long long bm = __ballot(cl > 0);
-                    const int p0 = __shfl(myfirst, __ffsll((long long)bm) - 1, 64);
-                    const int p1 = __shfl(mylast, 63 - __clzll((long long)bm), 64);
+                    const int Lf = __ffsll((long long)bm) - 1, Ll = 63 - __clzll((long long)bm);
+                    int p0 = -1, p1 = -1;
+#pragma unroll
+                    for (int j = WPL - 1; j >= 0; j--) {
+                        const uint32_t wf = (uint32_t)__builtin_amdgcn_readlane((int)wv[j], Lf);
+                        if (wf) p0 = (Lf * WPL + j) * 32 + __ffs((int)wf) - 1;
+                    }
+#pragma unroll
+                    for (int j = 0; j < WPL; j++) {
+                        const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)wv[j], Ll);
+                        if (wl) p1 = (Ll * WPL + j) * 32 + 31 - __clz((int)wl);
+                    }
                     int e0 = p0 + 1, s1 = p1;
                     if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
                     if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
@@ -250,6 +258,12 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 }
                 lds_wave_fence();  // the next toggles rewrite bits / pw
             }
+        }
+        __syncthreads();
+        for (int g = tid; g < G; g += NT) {
+            const double N = gstat[3 * g], nmin = gstat[3 * g + 1], nmax = gstat[3 * g + 2];
+            gstat[3 * g + 1] = ((nmin + 1.0) / 2.0) / N;
+            gstat[3 * g + 2] = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
         }
         __syncthreads();
 
