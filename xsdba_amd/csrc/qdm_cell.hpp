@@ -115,10 +115,22 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             while (lo < hi) { int mid = (lo + hi) >> 1; if (ser.eq_ranks(mid, r)) lo = mid + 1; else hi = mid; }
             return lo;
         };
+        // tie bits: bit r set when the values at ranks r - 1 and r are equal — formed once per cell, in parallel, in the unused
+        // tail of gstat (shared with pass D's node table, which is built later): a tie test in the group walk is then one LDS
+        // read instead of two dependent index -> key round trips per side (the walk waits on LDS latency, not on issue)
+        uint32_t *tieb = reinterpret_cast<uint32_t *>(gstat + 3 * G);
+        const bool have_tb = (size_t)(TPAD / 8) <= (size_t)(QC::GMAX - G) * 24;
+        auto tbit = [&](int r) { return (tieb[r >> 5] >> (r & 31)) & 1u; };
         auto tie_run = [&](int r, int &rs, int &re) {
             rs = r; re = r + 1;
-            if (r > 0 && ser.eq_ranks(r - 1, r)) rs = run_begin(r);
-            if (re < nvalid && ser.eq_ranks(re, r)) re = run_end(r);
+            if (have_tb) {
+                const bool tp = r > 0 && tbit(r), tn = re < nvalid && tbit(re);
+                if (tp) rs = run_begin(r);
+                if (tn) re = run_end(r);
+            } else {
+                if (r > 0 && ser.eq_ranks(r - 1, r)) rs = run_begin(r);
+                if (re < nvalid && ser.eq_ranks(re, r)) re = run_end(r);
+            }
         };
         // extreme percent ranks of a group (utils.rank :631-635: mn / mx of rank / N with average ties), once per group
         // (phase C parks the three counts of a group; the float64 divisions are done for all groups at once after it, by a
@@ -129,6 +141,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             gstat[3 * g + 2] = (double)nmax;
         };
         for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
+        if (have_tb)
+            for (int r0 = 0; r0 < TPAD; r0 += NT) {
+                const int r = r0 + tid;
+                const bool eq = r > 0 && r < nvalid && ser.eq_ranks(r - 1, r);
+                const unsigned long long b = __ballot(eq);
+                if (lane == 0) { tieb[r >> 5] = (uint32_t)b; tieb[(r >> 5) + 1] = (uint32_t)(b >> 32); }
+            }
         if (tid == 0) gstat[3 * (G / 2)] = 0.0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
         if (af && wid == 0) {
@@ -238,8 +257,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                         if (wl) p1 = (Ll * WPL + j) * 32 + 31 - __clz((int)wl);
                     }
                     int e0 = p0 + 1, s1 = p1;
-                    if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
-                    if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
+                    if (have_tb) {
+                        if (e0 < nvalid && tbit(e0)) e0 = run_end(p0);
+                        if (s1 > 0 && tbit(s1)) s1 = run_begin(p1);
+                    } else {
+                        if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
+                        if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
+                    }
                     const int nmin = below(e0), nmax = n - below(s1);
                     if (lane == 0) put_stats(g, n, nmin, nmax);
                 }
