@@ -198,8 +198,26 @@ template <typename R, typename XF> __device__ __forceinline__ double row_nearest
 // nbutils._extrapolate_on_quantiles (nbutils.py:397-416), for an integer group coordinate r = g0+1.
 // Rows are visited outward (r, r-1, r+1, r-2, ...) while dr^2 < best; exact distance ties keep the
 // first visited node (cKDTree's choice at ties is implementation-defined).
+// row_nearest on a complete row (n >= 1 pairs, no compaction): the lower bound in a fixed number of steps
+template <typename R, typename XF> __device__ __forceinline__ double row_nearest_fixed(XF x, const R *xs, int n, int *which)
+{
+    int lo = 0;
+    for (int m = n; m > 1;) {
+        const int half = m >> 1;
+        lo = (XF)xs[lo + half - 1] < x ? lo + half : lo;
+        m -= half;
+    }
+    lo += (XF)xs[lo] < x ? 1 : 0;  // first place whose abscissa is >= x, n if none
+    double best = __builtin_inf();
+    int bi = -1;
+    if (lo > 0) { double d = (double)x - (double)xs[lo - 1]; best = d * d; bi = lo - 1; }
+    if (lo < n) { double d = (double)x - (double)xs[lo]; if (d * d < best) { best = d * d; bi = lo; } }
+    *which = bi;
+    return best;
+}
+
 // rows r-1, r+1, r-2, ... while dr^2 < best (the tail of interp2d_nearest: the element's own row has been searched)
-template <typename R, typename XF>
+template <typename R, typename XF, bool DENSE = false>
 __device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, double best, R val, int &node)
 {
     const int G = ct.G, Q = ct.Q;
@@ -210,10 +228,14 @@ __device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, 
             int rr = s ? r + dr : r - dr;
             if (rr < 0 || rr > G + 1) continue;
             int g = ext_row(rr, G);
-            int n = ct.rn[g];
-            if (n == 0) continue;
             int w;
-            double d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
+            double d2;
+            if (DENSE) d2 = row_nearest_fixed<R, XF>(x, ct.xs + (size_t)g * ct.xstride, Q, &w) + d2r;
+            else {
+                int n = ct.rn[g];
+                if (n == 0) continue;
+                d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
+            }
             if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
         }
     }
@@ -276,7 +298,7 @@ __device__ __forceinline__ R interp2d_nearest_dense(R x, int g0, const CellTab<R
     node = r * Q + w;
     const double best = d * d;
     if (best <= 1.0) return val;
-    return nearest_outward<R, R>(x, r, ct, best, val, node);
+    return nearest_outward<R, R, true>(x, r, ct, best, val, node);
 }
 
 template <typename R>
