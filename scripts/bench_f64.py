@@ -17,3 +17,15 @@ for _ in range(2):
     ctx.synchronize()
     dt = time.perf_counter() - t0
     print(C / dt, "cells/s", {k: round(v["total_ms"], 2) for k, v in ctx.profile_read(reset=True).items() if v["count"]})
+# QDM adjust on the same float64 cube: k_qdm_lanes<double> against the generic kernel (XSDBA_HIP_QDM=count)
+import os
+afq = ctx.to_device((1.0 + 0.1 * np.random.default_rng(0).standard_normal((C, G, Q))))
+for force in (None, "count"):
+    if force: os.environ["XSDBA_HIP_QDM"] = force
+    else: os.environ.pop("XSDBA_HIP_QDM", None)
+    for _ in range(2):
+        ctx.profile_enable(True); ctx.profile_read(reset=True)
+        s2, _ = hip.qdm_adjust(sim, afq, q.astype(np.float64), doy, W, False, "nearest", "constant", "*", want_sim_q=False, ctx=ctx)
+        ctx.synchronize()
+        print("qdm float64", force or "lanes", {k: round(v["total_ms"], 2) for k, v in ctx.profile_read(reset=True).items() if v["count"]})
+os.environ.pop("XSDBA_HIP_QDM", None)

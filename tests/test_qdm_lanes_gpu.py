@@ -166,3 +166,32 @@ def test_rank_window_without_sim_q(name, kind, extrap):
     np.testing.assert_array_equal(np.asarray(scen).view(np.uint32), np.asarray(full).view(np.uint32))
     np.testing.assert_array_equal(np.asarray(scen), exp)
     np.testing.assert_array_equal(np.asarray(sim_q), esq)
+
+
+@pytest.mark.parametrize("name", ["plain", "zero_inflated", "nan_sim", "neg_zero", "leap", "ungrouped"])
+@pytest.mark.parametrize("kind,extrap", [("*", "constant"), ("+", "nan")])
+def test_lanes_float64(name, kind, extrap):
+    """the float64 instantiation (64-bit keys beside their payload) against the oracle and the generic kernel"""
+    import zlib
+
+    from xsdba_amd import hip
+
+    C, T, Q = 7, 10950 if name != "leap" else 10958, 20
+    sim32, gidx, G = _case(name, C, T, zlib.crc32(f"f64{name}{kind}".encode()))
+    rng = np.random.default_rng(23)
+    sim = sim32.astype(np.float64)
+    ok = np.isfinite(sim) & (sim != 0)
+    sim[ok] += 1e-9 * rng.standard_normal(int(ok.sum()))  # values no float32 holds
+    q = (np.arange(Q) + 0.5) / Q
+    af = 1.0 + 0.3 * rng.standard_normal((C, G, Q))
+    os.environ.pop("XSDBA_HIP_QDM", None)
+    scen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind, want_sim_q=False)
+    os.environ["XSDBA_HIP_QDM"] = "count"
+    try:
+        gen, _ = hip.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind, want_sim_q=False)
+    finally:
+        os.environ.pop("XSDBA_HIP_QDM", None)
+    exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 31, False, "nearest", extrap, kind)
+    assert np.asarray(scen).dtype == np.float64
+    np.testing.assert_array_equal(np.asarray(scen).view(np.uint64), np.asarray(gen).view(np.uint64))
+    np.testing.assert_array_equal(np.asarray(scen), exp)

@@ -1050,13 +1050,13 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         return check_launch("k_qdm_adjust");
     };
     bool fast = false;
-    if constexpr (std::is_same<R, float>::value) {
+    {
         // exact groups of at most 32 members (one per year of a day-of-year grouping): a lane per group, the members sorted in
         // registers (qdm_lanes.hpp).  XSDBA_HIP_QDM=count pins the generic kernel, =cell the sort kernel.
         const char *force = getenv("XSDBA_HIP_QDM");
         const int nchunk = (G + 63) / 64;
-        const int nw = 4;  // waves per block; any wave takes any (cell, chunk) item
-        const size_t lds = xs::qdm_lanes_lds_bytes(nw, Q, pl->max_mem);
+        const int nw = sizeof(R) == 4 ? 4 : 2;  // waves per block (float64 rows take twice the LDS); any wave takes any (cell, chunk) item
+        const size_t lds = xs::qdm_lanes_lds_bytes(nw, Q, pl->max_mem, sizeof(R));
         if (!ranks_only && !sim_q && !rw && G > 1 && interp == XSDBA_INTERP_NEAREST && pl->d_mem_t32 && s.st == 1 && Q < xs::QL_NAN &&
             T < 65535 && (int64_t)C * nchunk < (1ll << 31) - 1 && lds <= (size_t)ctx->lds_limit && !force) {
             void *flags;
@@ -1064,16 +1064,19 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             // time steps in no group stay NaN (no lane owns them)
-            if (pl->has_ungrouped) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)o.kernel_dst, 0x7FC00000, (size_t)T * C, ctx->stream));
-            if ((rc = set_lds(xs::k_qdm_lanes, lds, ctx, "the factor rows + the member-order buffer"))) return rc;
+            if (pl->has_ungrouped) {
+                hipLaunchKernelGGL(xs::k_fill_nan<R>, dim3((unsigned)(8 * ctx->n_cu)), dim3(256), 0, ctx->stream, (R *)o.kernel_dst, (int64_t)T * C);
+                if ((rc = check_launch("k_fill_nan"))) return rc;
+            }
+            if ((rc = set_lds(xs::k_qdm_lanes<R>, lds, ctx, "the factor rows + the member-order buffer"))) return rc;
             // up to 256 VGPRs: two waves per SIMD, eight per CU
             const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)(8 / nw), (size_t)ctx->lds_limit / lds));
             const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)per_cu * ctx->n_cu);
             {
                 LaunchScope ls(ctx, "k_qdm_lanes");
-                hipLaunchKernelGGL(xs::k_qdm_lanes, dim3(nblk), dim3(64 * nw), lds, ctx->stream, (const float *)s.dev, T, C, s.sc,
-                                   (const float *)daf, (const float *)dqn, G, Q, pl->d_mem_t32, pl->max_mem, extrap, (int)kind,
-                                   (float *)o.kernel_dst, T, flag_count, flag_list);
+                hipLaunchKernelGGL(xs::k_qdm_lanes<R>, dim3(nblk), dim3(64 * nw), lds, ctx->stream, (const R *)s.dev, T, C, s.sc,
+                                   (const R *)daf, (const R *)dqn, G, Q, pl->d_mem_t32, pl->max_mem, extrap, (int)kind,
+                                   (R *)o.kernel_dst, T, flag_count, flag_list);
                 if ((rc = check_launch("k_qdm_lanes"))) return rc;
             }
             // cells with NaN factors (the own-row shortcut does not hold): generic kernel, device-side count

@@ -1,4 +1,5 @@
-// qdm_lanes.hpp — qdm_adjust for SHORT ranking rows (exact day-of-year groups: one member per year, <= 32 members), float32.
+// qdm_lanes.hpp — qdm_adjust for SHORT ranking rows (exact day-of-year groups: one member per year, <= 32 members), float32
+// and float64 (template on the series type; the 64-bit keys of a double travel beside their payload instead of in one word).
 //
 // _adjustment.qdm_adjust (_adjustment.py:783-886) ranks every value of sim inside its group (utils.rank, utils.py:573-638:
 // average ranks, NaN -> NaN, percent ranks rescaled with the extreme ranks) and looks the percent rank up on the quantile
@@ -30,15 +31,16 @@ constexpr int QL_CODES = ((QL_M + 1) * QL_TW + 15) & ~15;
 
 // dynamic LDS of a block of `nwave` waves: the quantile axis and the node table (shared), then per wave the factor rows of its
 // 64 groups and a [max_mem][64] buffer that takes the adjusted values back from sorted order to member order
-__host__ __device__ inline size_t qdm_lanes_wave_bytes(int Q, int max_mem) { return ((size_t)64 * Q + (size_t)max_mem * 64) * 4; }
-__host__ __device__ inline size_t qdm_lanes_lds_bytes(int nwave, int Q, int max_mem)
+__host__ __device__ inline size_t qdm_lanes_wave_bytes(int Q, int max_mem, size_t esz = 4) { return ((size_t)64 * Q + (size_t)max_mem * 64) * esz; }
+__host__ __device__ inline size_t qdm_lanes_lds_bytes(int nwave, int Q, int max_mem, size_t esz = 4)
 {
-    return (((size_t)Q + 3) & ~(size_t)3) * 4 + QL_CODES + (size_t)nwave * qdm_lanes_wave_bytes(Q, max_mem);
+    return (((size_t)Q + 3) & ~(size_t)3) * esz + QL_CODES + (size_t)nwave * qdm_lanes_wave_bytes(Q, max_mem, esz);
 }
 
 // the node of the group's own row nearest to the rescaled percent rank: utils.rank's formula and interp2d_nearest
 // (device_math.hpp) on a NaN-free row of the shared quantile axis, expression for expression
-__device__ __forceinline__ int ql_code(int twor, int N, double pmin, double pmax, const float *xq, int Q, int extrap)
+template <typename R>
+__device__ __forceinline__ int ql_code(int twor, int N, double pmin, double pmax, const R *xq, int Q, int extrap)
 {
     const double r = (double)twor / 2.0;  // = less + (equal + 1) / 2, exact
     const double pr = r / (double)N;
@@ -47,30 +49,40 @@ __device__ __forceinline__ int ql_code(int twor, int N, double pmin, double pmax
     if (sq < (double)xq[0]) return extrap == 0 ? 0 : QL_NAN;
     if (sq > (double)xq[Q - 1]) return extrap == 0 ? Q - 1 : QL_NAN;
     int w;
-    (void)row_nearest<float, double>(sq, xq, Q, &w);
+    (void)row_nearest<R, double>(sq, xq, Q, &w);
     return w;
+}
+
+// every element NaN (time steps in no group are never touched by k_qdm_lanes)
+template <typename R> __global__ void k_fill_nan(R *__restrict__ dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = nan_of<R>();
 }
 
 __device__ __forceinline__ void lds_wave_fence_ql() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Work item = (cell, chunk of 64 groups); a wave owns the items of ONE chunk (its member -> time table stays in registers,
 // two 16-bit indexes per register) and walks the cells; waves never wait for each other after the prologue.
-__global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
-                                                       const float *__restrict__ af, const float *__restrict__ quantiles, int G, int Q,
+template <typename R>
+__global__ __launch_bounds__(256, 2) void k_qdm_lanes(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc,
+                                                       const R *__restrict__ af, const R *__restrict__ quantiles, int G, int Q,
                                                        const int *__restrict__ mem_t32, int max_mem, int extrap, int kind,
-                                                       float *__restrict__ scen, int64_t osc, int *__restrict__ flag_count,
+                                                       R *__restrict__ scen, int64_t osc, int *__restrict__ flag_count,
                                                        int *__restrict__ flag_list)
 {
+    using U = typename KeyOf<R>::U;
+    constexpr U MAXK = KeyOf<R>::MAXK;
+    constexpr U SIGN = (U)1 << (8 * sizeof(R) - 1);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float *xq = reinterpret_cast<float *>(smem);                                          // [Q] the quantile axis
-    unsigned char *codes = smem + (((size_t)Q + 3) & ~(size_t)3) * 4;                     // [QL_M + 1][QL_TW]
+    R *xq = reinterpret_cast<R *>(smem);                                                  // [Q] the quantile axis
+    unsigned char *codes = smem + (((size_t)Q + 3) & ~(size_t)3) * sizeof(R);             // [QL_M + 1][QL_TW]
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wid = tid >> 6, nwave = nt >> 6;
-    float *ysw = reinterpret_cast<float *>(codes + QL_CODES + (size_t)wid * qdm_lanes_wave_bytes(Q, max_mem));  // [64][Q] factor rows
-    float *trw = ysw + (size_t)64 * Q;                                                    // [max_mem][64]
+    R *ysw = reinterpret_cast<R *>(codes + QL_CODES + (size_t)wid * qdm_lanes_wave_bytes(Q, max_mem, sizeof(R)));  // [64][Q] factor rows
+    R *trw = ysw + (size_t)64 * Q;                                                        // [max_mem][64]
 
     // ---- once per block: the quantile axis and the (N, 2r) -> node table of groups whose extremes are not tied
     bool bad_axis = false;
-    for (int i = tid; i < Q; i += nt) { const float v = quantiles[i]; xq[i] = v; bad_axis |= v != v; }
+    for (int i = tid; i < Q; i += nt) { const R v = quantiles[i]; xq[i] = v; bad_axis |= v != v; }
     __syncthreads();
     // (the own row holds the 2-D nearest node only while no node of it is farther than one group step)
     if (tid == 0 && !((double)xq[Q - 1] - (double)xq[0] <= 1.0)) bad_axis = true;
@@ -81,7 +93,7 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
         if (!bad_axis && N >= 1 && tw >= 2 && tw <= 2 * N) {
             const double Nd = (double)N;
             const double pmin = ((1.0 + 1.0) / 2.0) / Nd, pmax = ((Nd - 1.0) + (1.0 + 1.0) / 2.0) / Nd;
-            code = ql_code(tw, N, pmin, pmax, xq, Q, extrap);
+            code = ql_code<R>(tw, N, pmin, pmax, xq, Q, extrap);
         }
         codes[i] = (unsigned char)code;
     }
@@ -114,19 +126,19 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
         // ---- loads: the members of the lane's group (consecutive lanes, consecutive days: coalesced) and the factor rows of
         // the wave's groups (one contiguous piece of the cell's table), all issued before anything is looked at
         const char *xrow = reinterpret_cast<const char *>(sim + c * sc);
-        float x[QL_M];
+        R x[QL_M];
 #pragma unroll
         for (int y = 0; y < QL_M; y++) {
             const uint32_t t = slot_time(y);
-            x[y] = *reinterpret_cast<const float *>(xrow + (t == 0xFFFFu ? 0u : t * 4u));
+            x[y] = *reinterpret_cast<const R *>(xrow + (t == 0xFFFFu ? 0u : t * (uint32_t)sizeof(R)));
         }
         const int nrow = min(64, G - g0), nfac = nrow * Q;
         bool has_nan = bad_axis;
         {
-            const float *yq = af + ((size_t)c * G + g0) * Q;
+            const R *yq = af + ((size_t)c * G + g0) * Q;
             constexpr int NB = 20;  // (20 nodes: the wave's rows in one batch)
             for (int i0 = ln; i0 < nfac; i0 += NB * 64) {
-                float yv[NB];
+                R yv[NB];
 #pragma unroll
                 for (int kq = 0; kq < NB; kq++) yv[kq] = yq[min(i0 + kq * 64, nfac - 1)];
 #pragma unroll
@@ -146,21 +158,88 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
             if (lane == 0) { const int slot = atomicAdd(flag_count, 1); flag_list[slot] = (int)c; }
             continue;
         }
-        uint32_t k[QL_M], p[QL_M];
+        if constexpr (sizeof(R) == 8) {
+            // ---- float64: ranks by COUNTING over the 496 pairs of the lane's members, all in registers (two compares and four
+            // carry-adds per pair) — no sort network on 64-bit keys with a payload beside them (which the compiler either tears
+            // apart or keeps in memory), no key transform (the comparisons treat -0.0 and +0.0 as equal and ignore NaN by
+            // themselves), and the results come out in member order: no way back through LDS either.
+            uint32_t less[QL_M], more[QL_M];
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) {
+                if (slot_time(y) == 0xFFFFu) x[y] = nan_of<R>();  // no such member: counts for nobody
+                less[y] = 0u; more[y] = 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < QL_M; i++)
+#pragma unroll
+                for (int j = i + 1; j < QL_M; j++) {
+                    const uint32_t c1 = x[i] < x[j] ? 1u : 0u, c2 = x[j] < x[i] ? 1u : 0u;
+                    less[j] += c1; more[i] += c1;
+                    less[i] += c2; more[j] += c2;
+                }
+            int N = 0;
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) N += x[y] == x[y] ? 1 : 0;
+            // tie counts of the smallest / largest value: every member with nothing below (above) it shares them
+            int nmin = 1, nmax = 1;
+#pragma unroll
+            for (int y = 0; y < QL_M; y++) {
+                const bool ok = x[y] == x[y];
+                const int eq = N - (int)less[y] - (int)more[y];
+                nmin = (ok && less[y] == 0u) ? eq : nmin;
+                nmax = (ok && more[y] == 0u) ? eq : nmax;
+            }
+            const bool untied = nmin == 1 && nmax == 1;
+            int ln2 = lane;
+            __asm__ volatile("" : "+v"(ln2));
+            const int gq = ln2 * Q;
+            char *orow = reinterpret_cast<char *>(scen + c * osc);
+            auto finish = [&](R xv, uint32_t t, int code) __attribute__((always_inline)) {
+                const R a = code == QL_NAN ? nan_of<R>() : ysw[gq + (code == QL_NAN ? 0 : code)];
+                if (t != 0xFFFFu) *reinterpret_cast<R *>(orow + t * (uint32_t)sizeof(R)) = apply_corr<R>(xv, a, kind);
+            };
+            if (!__any(!untied)) {
+                const unsigned char *crow = codes + N * QL_TW;
+#pragma unroll
+                for (int y = 0; y < QL_M; y++) {
+                    const int twor = 2 * (int)less[y] + (N - (int)less[y] - (int)more[y]) + 1;
+                    finish(x[y], slot_time(y), x[y] == x[y] ? (int)crow[min(twor, QL_TW - 1)] : QL_NAN);
+                }
+            } else {
+                const double Nd = (double)N;
+                const double pmin = (((double)nmin + 1.0) / 2.0) / Nd;
+                const double pmax = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
+#pragma unroll 1
+                for (int j = 0; j < QL_M; j++) {
+                    int jo = j;
+                    __asm__ volatile("" : "+s"(jo));
+                    R xv = (R)0;
+                    uint32_t le = 0u, mo = 0u, t = 0xFFFFu;
+#pragma unroll
+                    for (int u = 0; u < QL_M; u++) { xv = u == jo ? x[u] : xv; le = u == jo ? less[u] : le; mo = u == jo ? more[u] : mo; t = u == jo ? slot_time(u) : t; }
+                    const int twor = 2 * (int)le + (N - (int)le - (int)mo) + 1;
+                    finish(xv, t, (xv == xv && twor <= 2 * N) ? ql_code<R>(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN);
+                }
+            }
+            continue;
+        }
+        U k[QL_M];
+        uint32_t p[QL_M];
 #pragma unroll
         for (int y = 0; y < QL_M; y++) {
             const bool present = slot_time(y) != 0xFFFFu;
-            const uint32_t bits = __float_as_uint(x[y]);
+            U bits;
+            if constexpr (sizeof(R) == 4) bits = __float_as_uint(x[y]); else bits = (U)__double_as_longlong(x[y]);
             // -0.0 ranks as +0.0 (scipy compares values); its sign rides in bit 31 of the payload and returns at the end
-            k[y] = present ? to_key(x[y] + 0.0f) : 0xFFFFFFFFu;
-            p[y] = present ? ((uint32_t)y | (bits == 0x80000000u ? 0x80000000u : 0u)) : 0xFFFFFFu;  // payload: the member slot
+            k[y] = present ? to_key(x[y] + (R)0) : MAXK;
+            p[y] = present ? ((uint32_t)y | (bits == SIGN ? 0x80000000u : 0u)) : 0xFFFFFFu;  // payload: the member slot
         }
         // ---- Batcher's odd-even merge sort of the (key, payload) pairs, in registers.  A pair travels as ONE 64-bit word,
         // key on top (equal keys are then ordered by payload, which no result depends on): a compare-exchange is one
         // 64-bit compare and four selects, and the key and payload networks cannot drift apart in the schedule (as two
         // 32-bit networks the compiler ran all the key min / max first and kept every intermediate key alive for the
         // payload selects: 500 live registers)
-        {
+        if constexpr (sizeof(R) == 4) {
             uint64_t kp[QL_M];
 #pragma unroll
             for (int y = 0; y < QL_M; y++) kp[y] = ((uint64_t)k[y] << 32) | p[y];
@@ -181,7 +260,29 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
                                 if (((i + j) & 1) == 1 || kk == 1) __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
-            for (int y = 0; y < QL_M; y++) { k[y] = (uint32_t)(kp[y] >> 32); p[y] = (uint32_t)kp[y]; }
+            for (int y = 0; y < QL_M; y++) { k[y] = (U)(kp[y] >> 32); p[y] = (uint32_t)kp[y]; }
+        } else {
+            // 64-bit keys: key and payload side by side, ONE compare per exchange decides both (no min / max on the keys alone,
+            // which would let the two networks drift apart)
+#pragma unroll
+            for (int pp = 1; pp < QL_M; pp *= 2)
+#pragma unroll
+                for (int kk = pp; kk >= 1; kk /= 2)
+#pragma unroll
+                    for (int j = kk % pp; j <= QL_M - 1 - kk; j += 2 * kk)
+#pragma unroll
+                        for (int i = 0; i <= (kk - 1 < QL_M - j - kk - 1 ? kk - 1 : QL_M - j - kk - 1); i++)
+                            if ((i + j) / (2 * pp) == (i + j + kk) / (2 * pp)) {
+                                const U ka = k[i + j], kb = k[i + j + kk];
+                                const uint32_t pa = p[i + j], pb = p[i + j + kk];
+                                const bool sw = kb < ka;
+                                U nka = sw ? kb : ka, nkb = sw ? ka : kb;
+                                uint32_t npa = sw ? pb : pa, npb = sw ? pa : pb;
+                                // (all four results are pinned here — as locals: an array element in an asm operand keeps the array
+                                //  in memory —: the payload selects may not be deferred behind the key network)
+                                __asm__ volatile("" : "+v"(nka), "+v"(nkb), "+v"(npa), "+v"(npb));
+                                k[i + j] = nka; k[i + j + kk] = nkb; p[i + j] = npa; p[i + j + kk] = npb;
+                            }
         }
         int ln2 = lane;
         __asm__ volatile("" : "+v"(ln2));
@@ -192,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
         for (int j = 0; j < QL_M; j++) {
             if (j > 0) st = (k[j] == k[j - 1]) ? st : j;
             p[j] |= (uint32_t)st << 24;
-            const bool valid = k[j] != 0xFFFFFFFFu;
+            const bool valid = k[j] != MAXK;
             N += valid ? 1 : 0;
             last_start = valid ? st : last_start;
         }
@@ -208,10 +309,12 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
                 p[j] = (p[j] & 0x80FFFFFFu) | (twor << 24);  // (an absent slot keeps its 24 low bits set)
             }
         }
-        auto park = [&](uint32_t kj, uint32_t pj, int code) __attribute__((always_inline)) {
-            const float a = code == QL_NAN ? nan_of<float>() : ysw[gq + (code == QL_NAN ? 0 : code)];
-            const float v = __uint_as_float(__float_as_uint(from_key(kj)) | (pj & 0x80000000u));
-            const float out = apply_corr<float>(v, a, kind);
+        auto park = [&](U kj, uint32_t pj, int code) __attribute__((always_inline)) {
+            const R a = code == QL_NAN ? nan_of<R>() : ysw[gq + (code == QL_NAN ? 0 : code)];
+            R v;
+            if constexpr (sizeof(R) == 4) v = __uint_as_float(__float_as_uint(from_key(kj)) | (pj & 0x80000000u));
+            else v = __longlong_as_double(__double_as_longlong(from_key(kj)) | (long long)((uint64_t)(pj & 0x80000000u) << 32));
+            const R out = apply_corr<R>(v, a, kind);
             if ((pj & 0xFFFFFFu) != 0xFFFFFFu) trw[(pj & 31u) * 64u + (uint32_t)ln2] = out;
         };
         if (!__any(!untied)) {
@@ -232,11 +335,14 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
             const double pmax = ((Nd - (double)nmax) + ((double)nmax + 1.0) / 2.0) / Nd;
 #pragma unroll 1
             for (int j = 0; j < QL_M; j++) {
-                uint32_t kj = 0u, pj = 0u;
+                U kj = 0;
+                uint32_t pj = 0u;
+                int jo = j;
+                __asm__ volatile("" : "+s"(jo));  // (opaque: with a visible induction variable the chain below is folded into k[j] and the arrays go to memory)
 #pragma unroll
-                for (int u = 0; u < QL_M; u++) { kj = u == j ? k[u] : kj; pj = u == j ? p[u] : pj; }
+                for (int u = 0; u < QL_M; u++) { kj = u == jo ? k[u] : kj; pj = u == jo ? p[u] : pj; }
                 const int twor = (int)((pj >> 24) & 127u);
-                const int code = (kj != 0xFFFFFFFFu && twor <= 2 * N) ? ql_code(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN;
+                const int code = (kj != MAXK && twor <= 2 * N) ? ql_code<R>(twor, N, pmin, pmax, xq, Q, extrap) : QL_NAN;
                 park(kj, pj, code);
             }
         }
@@ -244,13 +350,13 @@ __global__ __launch_bounds__(256, 2) void k_qdm_lanes(const float *__restrict__ 
         lds_wave_fence_ql();
         {
             char *orow = reinterpret_cast<char *>(scen + c * osc);
-            float o[QL_M];
+            R o[QL_M];
 #pragma unroll
             for (int y = 0; y < QL_M; y++) o[y] = trw[(y < max_mem ? y : 0) * 64 + ln2];
 #pragma unroll
             for (int y = 0; y < QL_M; y++) {
                 const uint32_t t = slot_time(y);
-                if (t != 0xFFFFu) *reinterpret_cast<float *>(orow + t * 4u) = o[y];
+                if (t != 0xFFFFu) *reinterpret_cast<R *>(orow + t * (uint32_t)sizeof(R)) = o[y];
             }
         }
         lds_wave_fence_ql();  // (the next item refills the wave's rows)
