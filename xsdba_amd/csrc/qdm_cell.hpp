@@ -241,11 +241,11 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     const int w = r >> 5;
                     return (int)pw[w] + __popc(bits[w] & ((1u << (r & 31)) - 1u));
                 };
-                if (slice == 0) {  // extreme tie counts of the row (wave-uniform work)
-                    // first / last member of the row: the words of the first / last lane that holds any, read into scalars
+                // first / last member of the row: the words of the first / last lane that holds any, read into scalars
+                int p0 = -1, p1 = -1;
+                if (slice == 0) {
                     const unsigned long long bm = __ballot(cl > 0);
                     const int Lf = __ffsll((long long)bm) - 1, Ll = 63 - __clzll((long long)bm);
-                    int p0 = -1, p1 = -1;
 #pragma unroll
                     for (int j = WPL - 1; j >= 0; j--) {
                         const uint32_t wf = (uint32_t)__builtin_amdgcn_readlane((int)wv[j], Lf);
@@ -256,28 +256,48 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                         const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)wv[j], Ll);
                         if (wl) p1 = (Ll * WPL + j) * 32 + 31 - __clz((int)wl);
                     }
-                    int e0 = p0 + 1, s1 = p1;
-                    if (have_tb) {
-                        if (e0 < nvalid && tbit(e0)) e0 = run_end(p0);
-                        if (s1 > 0 && tbit(s1)) s1 = run_begin(p1);
-                    } else {
-                        if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
-                        if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
-                    }
-                    const int nmin = below(e0), nmax = n - below(s1);
-                    if (lane == 0) put_stats(g, n, nmin, nmax);
                 }
-                // average-tie ranks of the elements this row ranks (the exact group)
                 const int *ml = mem_idx + mem_ptr[g];
                 const int mlen = mem_ptr[g + 1] - mem_ptr[g];
-                for (int i0 = slice * 64; i0 < mlen; i0 += nslice * 64) {
-                    const int i = i0 + lane;
-                    const int t = i < mlen ? ml[i] : -1;
-                    const int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
+                if (nslice == 1 && mlen <= 62) {
+                    // the usual case (a wave per group, at most 62 members): the extreme tie counts of the row ride in lanes 62 / 63
+                    // of the members' own pass — the tie run of the first member gives nmin, the one of the last member nmax — instead
+                    // of a chain of dependent LDS reads of their own that the whole wave waits on
+                    const int t = lane < mlen ? ml[lane] : -1;
+                    int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
+                    r = lane == 62 ? p0 : (lane == 63 ? p1 : r);
+                    int bl = 0, bh = 0;
                     if (r < nvalid) {
                         int rs, re;
                         tie_run(r, rs, re);
-                        r2buf[t] = (uint16_t)(below(rs) + below(re) + 1);
+                        bl = below(rs); bh = below(re);
+                        if (lane < 62) r2buf[t] = (uint16_t)(bl + bh + 1);
+                    }
+                    const int nmin = __builtin_amdgcn_readlane(bh, 62), nmax = n - __builtin_amdgcn_readlane(bl, 63);
+                    if (lane == 0) put_stats(g, n, nmin, nmax);
+                } else {
+                    if (slice == 0) {  // extreme tie counts of the row (wave-uniform work)
+                        int e0 = p0 + 1, s1 = p1;
+                        if (have_tb) {
+                            if (e0 < nvalid && tbit(e0)) e0 = run_end(p0);
+                            if (s1 > 0 && tbit(s1)) s1 = run_begin(p1);
+                        } else {
+                            if (e0 < nvalid && ser.eq_ranks(e0, p0)) e0 = run_end(p0);
+                            if (s1 > 0 && ser.eq_ranks(s1 - 1, p1)) s1 = run_begin(p1);
+                        }
+                        const int nmin = below(e0), nmax = n - below(s1);
+                        if (lane == 0) put_stats(g, n, nmin, nmax);
+                    }
+                    // average-tie ranks of the elements this row ranks (the exact group)
+                    for (int i0 = slice * 64; i0 < mlen; i0 += nslice * 64) {
+                        const int i = i0 + lane;
+                        const int t = i < mlen ? ml[i] : -1;
+                        const int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
+                        if (r < nvalid) {
+                            int rs, re;
+                            tie_run(r, rs, re);
+                            r2buf[t] = (uint16_t)(below(rs) + below(re) + 1);
+                        }
                     }
                 }
                 lds_wave_fence();  // the next toggles rewrite bits / pw
