@@ -329,13 +329,17 @@ def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
 
     res = {}
     dev = [wrap(a, C) for a in (ref, hist, sim)]
+    from xsdba_amd._lib import default_context
+
+    api_ctx = default_context()  # the context the mirror launches on (not the one the cubes were generated on)
     run(*dev)  # warm-up (allocations)
     ctx.synchronize()
+    api_ctx.synchronize()
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
         scen = run(*dev)
-    ctx.synchronize()
+    api_ctx.synchronize()
     res["device_inputs_cells_per_s"] = round(C * reps / (time.perf_counter() - t0), 1)
     del scen
     n = min(C, 16384)

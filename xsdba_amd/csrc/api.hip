@@ -87,6 +87,9 @@ struct xsdba_hip_ctx {
     std::vector<std::unique_ptr<Plan>> plans;
     DevBuf scratch[16];
     std::vector<void *> user_allocs;
+    std::vector<size_t> user_sizes;                     // bytes of every user_allocs entry
+    std::vector<std::pair<size_t, void *>> pool;       // buffers given back and kept for the next request of the same size
+    size_t pool_bytes = 0;
     bool profiling = false;
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -1502,6 +1505,7 @@ API int xsdba_hip_destroy(xsdba_hip_ctx *ctx)
     for (auto &p : ctx->plans) free_plan(p.get());
     for (auto &b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (void *p : ctx->user_allocs) (void)hipFree(p);
+    for (auto &e : ctx->pool) (void)hipFree(e.second);
     for (auto &e : ctx->prof) for (auto &pr : e.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -1527,13 +1531,47 @@ API int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream)
     return 0;
 }
 
+// Buffers of 1 MB and more that are given back stay in a per-context pool (XSDBA_HIP_POOL_MB, default 16384) and serve the
+// next request of exactly that size: a train / adjust loop allocates the same tables and series every pass, and hipFree costs a
+// stream synchronisation each time.  Everything the library does with a buffer is ordered on the context's stream, so a pooled
+// buffer may be handed out again while earlier kernels that used it are still queued.
+static size_t pool_cap_bytes()
+{
+    const char *e = getenv("XSDBA_HIP_POOL_MB");
+    return (size_t)(e ? atof(e) : 16384.0) << 20;
+}
+
+static void pool_flush(xsdba_hip_ctx *ctx)
+{
+    if (ctx->pool.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->pool) (void)hipFree(e.second);
+    ctx->pool.clear();
+    ctx->pool_bytes = 0;
+}
+
 API int xsdba_hip_malloc(xsdba_hip_ctx *ctx, size_t bytes, void **dptr)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
     if (!dptr) return fail(XSDBA_E_ARG, "null out pointer");
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+    const size_t n = bytes ? bytes : 1;
+    for (size_t i = ctx->pool.size(); i-- > 0;)
+        if (ctx->pool[i].first == n) {
+            *dptr = ctx->pool[i].second;
+            ctx->pool_bytes -= n;
+            ctx->pool.erase(ctx->pool.begin() + (long)i);
+            ctx->user_allocs.push_back(*dptr);
+            ctx->user_sizes.push_back(n);
+            return 0;
+        }
+    if (hipMalloc(dptr, n) != hipSuccess) {  // out of memory with buffers parked in the pool: give them back and try again
+        (void)hipGetLastError();
+        pool_flush(ctx);
+        HIP_TRY(hipMalloc(dptr, n));
+    }
     ctx->user_allocs.push_back(*dptr);
+    ctx->user_sizes.push_back(n);
     return 0;
 }
 
@@ -1544,9 +1582,16 @@ API int xsdba_hip_free(xsdba_hip_ctx *ctx, void *dptr)
     if (!dptr) return 0;
     auto it = std::find(ctx->user_allocs.begin(), ctx->user_allocs.end(), dptr);
     if (it == ctx->user_allocs.end()) return fail(XSDBA_E_ARG, "pointer was not allocated by xsdba_hip_malloc on this context");
+    const size_t idx = (size_t)(it - ctx->user_allocs.begin()), n = ctx->user_sizes[idx];
+    ctx->user_allocs.erase(it);
+    ctx->user_sizes.erase(ctx->user_sizes.begin() + (long)idx);
+    if (n >= ((size_t)1 << 20) && ctx->pool_bytes + n <= pool_cap_bytes()) {
+        ctx->pool.emplace_back(n, dptr);
+        ctx->pool_bytes += n;
+        return 0;
+    }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipFree(dptr));
-    ctx->user_allocs.erase(it);
     return 0;
 }
 
