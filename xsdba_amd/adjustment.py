@@ -107,10 +107,8 @@ class BaseAdjustment(ParametrizableWithDataset):
 
     @classmethod
     def _check_matching_time_sizes(cls, *inputs):
-        ref_size = inputs[0].sizes["time"]
-        for inp in inputs[1:]:
-            if inp.sizes["time"] != ref_size:
-                raise ValueError(f"Inputs have different size for the time array, this is not supported for {cls.__name__} adjustment.")
+        if len({inp.sizes["time"] for inp in inputs}) > 1:
+            raise ValueError(f"Inputs have different size for the time array, this is not supported for {cls.__name__} adjustment.")
 
     @classmethod
     def _train(cls, ref, hist, **kwargs):
@@ -132,35 +130,45 @@ class TrainAdjust(BaseAdjustment):
     _repr_hide_params = ["hist_calendar", "train_units"]
 
     @classmethod
-    def train(cls, ref, hist, **kwargs):
-        """Train the adjustment object (adjustment.py:227-269)."""
-        want_xr = is_xarray(ref)
-        ref, hist = _device_resident(as_dataarray(ref)), _device_resident(as_dataarray(hist))
-        kwargs = parse_group(cls._train, kwargs)
-        skip_checks = kwargs.pop("skip_input_checks", False)
-        if not skip_checks:
-            if "group" in kwargs:
-                cls._check_inputs(ref, hist, group=kwargs["group"])
-            (ref, hist), train_units = cls._harmonize_units(ref, hist)
-        else:
-            train_units = ""
+    def _vet_training_pair(cls, ref, hist, group, checked: bool):
+        """The checks of `train` (adjustment.py:240-256): calendars and grouping, one unit for both series, and — per class
+        flag — identical time axes or at least equally long ones.  Returns the harmonized pair and the units they are in."""
+        units = ""
+        if checked:
+            if group is not None:
+                cls._check_inputs(ref, hist, group=group)
+            (ref, hist), units = cls._harmonize_units(ref, hist)
         if not cls._allow_diff_training_times:
             cls._check_matching_times(ref, hist)
         elif not cls._allow_diff_time_sizes:
             cls._check_matching_time_sizes(ref, hist)
+        return ref, hist, units
+
+    @classmethod
+    def train(cls, ref, hist, **kwargs):
+        """Train the adjustment object (adjustment.py:227-269): parse the group, check the pair, run the class's `_train` and
+        keep its dataset + parameters (and the calendar / units of the training data) on the new object."""
+        want_xr = is_xarray(ref)
+        ref, hist = (_device_resident(as_dataarray(x)) for x in (ref, hist))
+        kwargs = parse_group(cls._train, kwargs)
+        group = kwargs.get("group")
+        ref, hist, train_units = cls._vet_training_pair(ref, hist, group, not kwargs.pop("skip_input_checks", False))
         ds, params = cls._train(ref, hist, **kwargs)
-        obj = cls(_trained=True, hist_calendar=kwargs["group"]._time_index(hist).calendar if "group" in kwargs else "standard",
-                  train_units=train_units, **params)
+        calendar = "standard" if group is None else group._time_index(hist).calendar
+        obj = cls(_trained=True, hist_calendar=calendar, train_units=train_units, **params)
         obj._xr = want_xr
         obj.set_dataset(ds)
         return obj
 
+    def _describe_adjust_call(self, kwargs) -> str:
+        return f"{self!s}.adjust(sim, {gen_call_string('', **kwargs)[1:-1]})"
+
     def adjust(self, sim, *args, **kwargs):
-        """Return bias-adjusted data (adjustment.py:271-316)."""
+        """Return bias-adjusted data (adjustment.py:271-316): `sim` in the training units through the class's `_adjust`; the
+        result carries sim's attributes, the call in `history` / `bias_adjustment`, and the training units."""
         want_xr = is_xarray(sim)
         sim = _device_resident(as_dataarray(sim))
-        skip_checks = kwargs.pop("skip_input_checks", False)
-        if not skip_checks:
+        if not kwargs.pop("skip_input_checks", False):
             if "group" in self:
                 self._check_inputs(sim, *args, group=self.group)
             (sim, *args), _ = self._harmonize_units(sim, *args, target=self.train_units)
@@ -169,17 +177,12 @@ class TrainAdjust(BaseAdjustment):
             out = out.rename("scen").to_dataset()
         scen = out["scen"]
         scen.attrs.update(sim.attrs)
-        for name, crd in sim.coords.items():
-            if name in scen.coords:
-                scen.coords[name].attrs.update(crd.attrs)
-        params = gen_call_string("", **kwargs)[1:-1]
-        infostr = f"{self!s}.adjust(sim, {params})"
-        scen.attrs["history"] = update_history(f"Bias-adjusted with {infostr}", sim)
-        scen.attrs["bias_adjustment"] = infostr
-        scen.attrs["units"] = self.train_units
-        if OPTIONS[EXTRA_OUTPUT]:
-            return out.to_xarray() if want_xr else out
-        return scen.to_xarray() if want_xr else scen
+        for name in set(sim.coords) & set(scen.coords):
+            scen.coords[name].attrs.update(sim.coords[name].attrs)
+        call = self._describe_adjust_call(kwargs)
+        scen.attrs.update(history=update_history(f"Bias-adjusted with {call}", sim), bias_adjustment=call, units=self.train_units)
+        result = out if OPTIONS[EXTRA_OUTPUT] else scen
+        return result.to_xarray() if want_xr else result
 
     def set_dataset(self, ds):
         """Store the trained dataset in ``ds`` with the jsonpickle + repr attributes (adjustment.py:318-325)."""

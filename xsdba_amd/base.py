@@ -23,7 +23,8 @@ from .labeled import Coordinate, DataArray, Dataset, as_dataarray, as_dataset
 
 
 class Parametrizable(UserDict):
-    """Dictionary-like object completely defined by its parameters (base.py:26-72)."""
+    """A mapping that IS its parameters: attribute access reads them, the repr shows the non-default ones and pickling keeps
+    nothing else (the reference's contract, base.py:26-72)."""
 
     _repr_hide_params: list = []
 
@@ -31,26 +32,30 @@ class Parametrizable(UserDict):
         return self.data
 
     def __setstate__(self, state):
-        self.data = {**state}
+        self.data = dict(state)
 
     def __getattr__(self, attr):
-        if attr == "data" or attr not in self.__dict__.get("data", {}):
-            return self.__getattribute__(attr)
-        return self.data[attr]
+        # only reached when normal lookup failed; "data" itself may be missing while unpickling
+        store = self.__dict__.get("data")
+        if attr != "data" and store is not None and attr in store:
+            return store[attr]
+        return self.__getattribute__(attr)
 
     @property
     def parameters(self) -> dict:
-        return {**self.data}
+        return dict(self.data)
+
+    def _is_default(self, name, value) -> bool:
+        par = signature(self.__init__).parameters.get(name)
+        if par is None or par.default is _empty:
+            return False
+        if par.default is None:  # None stands for "nothing given": empty containers count as default too
+            return value in ([], {}, set(), None)
+        return value in [par.default]
 
     def __repr__(self) -> str:
-        defaults = {
-            n: [p.default] if p.default is not None else [[], {}, set(), None]
-            for n, p in signature(self.__init__).parameters.items()
-            if p.default is not _empty
-        }
-        params = ", ".join(f"{k}={v!r}" for k, v in self.items()
-                           if k not in self._repr_hide_params and v not in defaults.get(k, []))
-        return f"{self.__class__.__name__}({params})"
+        shown = [f"{k}={v!r}" for k, v in self.items() if k not in self._repr_hide_params and not self._is_default(k, v)]
+        return f"{type(self).__name__}({', '.join(shown)})"
 
 
 # ---- jsonpickle-compatible encoding of Parametrizable objects (base.py:80-100) -------------------------
@@ -124,14 +129,11 @@ class Grouper(Parametrizable):
                 "takes the complete series, thus the concept of window is not applicable in this case. When using "
                 "`group = 'time'`, `window=1` is expected."
             )
-        if "." in group:
-            dim, prop = group.split(".")
-        else:
-            dim, prop = group, "group"
+        dim, _, prop = group.partition(".")
         if group == "5D":
             dim = "time"
-        if isinstance(add_dims, str):
-            add_dims = [add_dims]
+        prop = prop or "group"
+        add_dims = [add_dims] if isinstance(add_dims, str) else add_dims
         super().__init__(dim=dim, add_dims=list(add_dims or []), prop=prop, name=group, window=window)
 
     @classmethod
@@ -178,26 +180,31 @@ class Grouper(Parametrizable):
             return da[self.dim].rename("group")
         ind = self._time_index(da)
         if interp and self.dim == "time":
-            if self.prop == "month":
+            # fractional positions between group centres (what the interpolation of the factors is evaluated at)
+            if self.prop == "dayofyear":
+                i = ind.dayofyear
+            elif self.prop == "month":
                 i = ind.month - 0.5 + ind.day / ind.days_in_month
             elif self.prop == "season":
-                length_year = 360 if ind.calendar == "360_day" else 365 + (0 if ind.calendar in ("noleap", "365_day") else ind.is_leap_year)
-                i = ind.dayofyear / length_year * 4 - 1 / 6
-            elif self.prop == "dayofyear":
-                i = ind.dayofyear
+                if ind.calendar == "360_day":
+                    year_len = 360
+                elif ind.calendar in ("noleap", "365_day"):
+                    year_len = 365
+                else:
+                    year_len = 365 + ind.is_leap_year
+                i = ind.dayofyear / year_len * 4 - 1 / 6
             else:
                 raise ValueError(f"Interpolation is not supported for {self.dim}.{self.prop}.")
         else:
             if self.prop == "season":
                 i = ind.month % 12 // 3
-            elif self.prop == "week":
-                i = ind.week
-            elif self.prop in ("month", "dayofyear", "year", "day"):
+            elif self.prop in ("month", "dayofyear", "year", "day", "week"):
                 i = getattr(ind, self.prop)
             else:
                 raise ValueError(f"Index {self.name} is not supported by {self.__class__.__name__}.")
-            if not np.issubdtype(np.asarray(i).dtype, np.integer):
-                raise ValueError(f"Index {self.name} is not of type int (rather {i.dtype}), but {self.__class__.__name__} requires integer indexes.")
+            kind = np.asarray(i).dtype
+            if not np.issubdtype(kind, np.integer):
+                raise ValueError(f"Index {self.name} is not of type int (rather {kind}), but {self.__class__.__name__} requires integer indexes.")
         return DataArray(np.asarray(i), dims=(self.dim,), coords={self.dim: da.coords[self.dim]}, name=self.prop)
 
     def n_groups(self, da=None) -> int:
@@ -304,41 +311,45 @@ class Grouper(Parametrizable):
 
     @staticmethod
     def filter_dim(da, dim):
+        """The main dimension plus those of the additional ones `da` actually has."""
         if isinstance(dim, str):
             return dim
-        return [dim[0]] + [d for d in dim[1:] if d in da.dims]
+        main, *others = dim
+        return [main, *(d for d in others if d in da.dims)]
 
     @staticmethod
     def filter_add_dims(dim):
+        """What is left of a dimension list without the additional dimensions ("window" is not one)."""
         if isinstance(dim, str):
             return [dim]
-        extra_dim = list(set(dim[1:]) - {"window"})
-        return list(set(dim) - set(extra_dim))
+        dropped = {d for d in dim[1:] if d != "window"}
+        return [d for d in dict.fromkeys(dim) if d not in dropped]
 
 
 _register(Grouper, "xsdba.base")
 
 
 def parse_group(func, kwargs=None, allow_only=None):
-    """Set the ``group`` argument to a :class:`Grouper` (decorator or kwargs parser; base.py:504-538)."""
-    sig = signature(func)
-    default_group = sig.parameters["group"].default if "group" in sig.parameters else None
+    """Make the ``group`` argument of `func` a :class:`Grouper` (base.py:504-538): a string (with the ``window`` / ``add_dims``
+    given beside it) is turned into one, the default of the signature is used when none is given.  With `kwargs`: parse that
+    dictionary and return it; without: return `func` wrapped so that every call is parsed."""
+    par = signature(func).parameters.get("group")
+    fallback = par.default if par is not None else None
 
-    def _update_kwargs(_kwargs, allowed=None):
-        if default_group or "group" in _kwargs:
-            _kwargs.setdefault("group", default_group)
-            if not isinstance(_kwargs["group"], Grouper):
-                _kwargs = Grouper.from_kwargs(**_kwargs)
-        if allowed is not None and "group" in _kwargs and _kwargs["group"].prop not in allowed:
-            raise ValueError(f"Grouping on {_kwargs['group'].prop_name} is not allowed for this function. Should be one of {allowed}.")
-        return _kwargs
+    def normalise(kw):
+        if fallback or "group" in kw:
+            if not isinstance(kw.setdefault("group", fallback), Grouper):
+                kw = Grouper.from_kwargs(**kw)
+        grp = kw.get("group")
+        if allow_only is not None and grp is not None and grp.prop not in allow_only:
+            raise ValueError(f"Grouping on {grp.prop_name} is not allowed for this function. Should be one of {allow_only}.")
+        return kw
 
     if kwargs is not None:
-        return _update_kwargs(kwargs, allowed=allow_only)
+        return normalise(kwargs)
 
     def _parse_group(*f_args, **f_kwargs):
-        f_kwargs = _update_kwargs(f_kwargs, allowed=allow_only)
-        return func(*f_args, **f_kwargs)
+        return func(*f_args, **normalise(f_kwargs))
 
     _parse_group.__name__ = getattr(func, "__name__", "parse_group")
     _parse_group.__doc__ = func.__doc__
@@ -347,18 +358,20 @@ def parse_group(func, kwargs=None, allow_only=None):
 
 
 def _merge_dimensions(*seqs):
-    out = list(seqs[0])
-    for seq in seqs[1:]:
-        last_index = 0
-        for e in seq:
-            if e in out:
-                indx = out.index(e)
-                if indx < last_index:
-                    raise ValueError("Dimensions order mismatch, lists are not mergeable.")
-                last_index = indx
-            else:
-                out.insert(last_index + 1, e)
-    return out
+    """One list holding every name of the given lists, the relative order inside each list kept: a name not seen yet goes
+    right behind the last name of its list that was (base.py:585-599)."""
+    merged = list(seqs[0])
+    for names in seqs[1:]:
+        anchor = 0  # position in `merged` of the latest name of `names` found there
+        for name in names:
+            if name not in merged:
+                merged.insert(anchor + 1, name)
+                continue
+            pos = merged.index(name)
+            if pos < anchor:
+                raise ValueError("Dimensions order mismatch, lists are not mergeable.")
+            anchor = pos
+    return merged
 
 
 # ---- blocks of cells (the role dask chunks play for the reference, base.py:640-702) -------------------------------------
