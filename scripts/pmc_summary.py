@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
                 k = row["Kernel_Name"].split("(")[0][:60]
                 acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         for k, cs in acc.items():
-            if not any(s in k for s in ("k_train", "k_qm", "k_qdm", "k_group")):
+            if not any(s in k for s in ("k_train", "k_qm", "k_qdm", "k_group", "k_lin2d")):
                 continue
             print(k)
             for c, v in sorted(cs.items()):
