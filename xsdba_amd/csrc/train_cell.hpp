@@ -57,6 +57,20 @@ __device__ __forceinline__ double wave_total_dpp(double v)
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+// Sum of the per-wave totals tot[0 .. wid) of a 16-wave block: every lane reads one total, a row scan on the DPP path, one
+// readlane — instead of a loop of up to 15 dependent LDS reads in the last wave, on which all the others wait at the barrier.
+__device__ __forceinline__ int waves_before(const uint32_t *tot, int lane, int wid)
+{
+    int v = (int)tot[lane & 15];
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    const int w = __builtin_amdgcn_readfirstlane(wid);
+    const int x = __builtin_amdgcn_readlane(v, (w + 15) & 15);
+    return w ? x : 0;
+}
+
 __device__ __forceinline__ void lds_wave_fence() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int EPT> struct CellCfg {
@@ -131,8 +145,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 int incl = wave_incl_scan(run);
                 if (lane == 63) red[wid] = (uint32_t)incl;
                 __syncthreads();
-                int woff = 0;
-                for (int w = 0; w < wid; w++) woff += (int)red[w];
+                const int woff = waves_before(red, lane, wid);
                 int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
 #pragma unroll
                 for (int i = 0; i < BPT / 2; i++) {
@@ -191,8 +204,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 int incl = wave_incl_scan(run);
                 if (lane == 63) red[wid] = (uint32_t)incl;
                 __syncthreads();
-                int woff = 0;
-                for (int w = 0; w < wid; w++) woff += (int)red[w];
+                const int woff = waves_before(red, lane, wid);
                 const int off = woff + incl - run;
 #pragma unroll
                 for (int k = 0; k < 16; k++) {
@@ -285,8 +297,20 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         }
         if (lane == 0) { red[3 * wid] = (uint32_t)nv; red[3 * wid + 1] = kmin; red[3 * wid + 2] = kmax; }
         __syncthreads();
-        nv = 0; kmin = 0xFFFFFFFFu; kmax = 0u;
-        for (int w = 0; w < Cfg::NWAVE; w++) { nv += (int)red[3 * w]; kmin = min(kmin, red[3 * w + 1]); kmax = max(kmax, red[3 * w + 2]); }
+        {   // all-reduce over the 16 waves: a lane per wave (in every row of 16), rotations inside the row
+            static_assert(Cfg::NWAVE == 16, "one DPP row holds the per-wave results");
+            nv = (int)red[3 * (lane & 15)]; kmin = red[3 * (lane & 15) + 1]; kmax = red[3 * (lane & 15) + 2];
+#define XS_ROW_ROR(x, n) __builtin_amdgcn_update_dpp((int)(x), (int)(x), 0x120 + (n), 0xf, 0xf, false)
+            nv += XS_ROW_ROR(nv, 8); kmin = min(kmin, (uint32_t)XS_ROW_ROR(kmin, 8)); kmax = max(kmax, (uint32_t)XS_ROW_ROR(kmax, 8));
+            nv += XS_ROW_ROR(nv, 4); kmin = min(kmin, (uint32_t)XS_ROW_ROR(kmin, 4)); kmax = max(kmax, (uint32_t)XS_ROW_ROR(kmax, 4));
+            nv += XS_ROW_ROR(nv, 2); kmin = min(kmin, (uint32_t)XS_ROW_ROR(kmin, 2)); kmax = max(kmax, (uint32_t)XS_ROW_ROR(kmax, 2));
+            nv += XS_ROW_ROR(nv, 1); kmin = min(kmin, (uint32_t)XS_ROW_ROR(kmin, 1)); kmax = max(kmax, (uint32_t)XS_ROW_ROR(kmax, 1));
+#undef XS_ROW_ROR
+            // (equal in every lane: back into scalar registers, the pass count and the shifts of the sort derive from them)
+            nv = __builtin_amdgcn_readfirstlane(nv);
+            kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmin);
+            kmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmax);
+        }
         const int nvalid = nv;
         nvalid_out = nv;
         const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1

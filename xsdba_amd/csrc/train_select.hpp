@@ -77,11 +77,17 @@ __device__ __forceinline__ int sel_block_excl_scan(int v, uint32_t *red, int lan
     const int incl = wave_incl_scan(v);
     if (lane == 63) red[wid] = (uint32_t)incl;
     __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < SEL_NT / 64; w++) { const int r = (int)red[w]; woff += w < wid ? r : 0; tot += r; }
+    // the 8 wave totals: a lane each, scanned on the DPP path (the first half of a row of 16), read back with readlane
+    static_assert(SEL_NT / 64 == 8, "the wave totals fill half a DPP row");
+    int r = (int)red[lane & 7];
+    r += __builtin_amdgcn_update_dpp(0, r, 0x111, 0xf, 0xf, false);
+    r += __builtin_amdgcn_update_dpp(0, r, 0x112, 0xf, 0xf, false);
+    r += __builtin_amdgcn_update_dpp(0, r, 0x114, 0xf, 0xf, false);
+    const int w = __builtin_amdgcn_readfirstlane(wid);
+    const int before = __builtin_amdgcn_readlane(r, (w + 7) & 7);
+    const int woff = w ? before : 0;
+    total = __builtin_amdgcn_readlane(r, 7);
     __syncthreads();
-    total = tot;
     return woff + incl - v;
 }
 
