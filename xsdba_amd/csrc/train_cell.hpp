@@ -101,7 +101,8 @@ template <int EPT> struct CellCfg {
 
 // Phase B: LSD radix sort of the time indexes by the keys in LDS (valid keys lie in [kmin, kmin + range], NaN / padding
 // are 0xFFFFFFFF), then rank[t] = position of t.  Returns the sorted index array (one of the two u16 buffers; the other
-// one is free afterwards).  stop_after == 2: return before building rank[].
+// one is free afterwards).  stop_after == 2: return before building rank[]; 3: rank[] goes into that other buffer
+// (written by the last stable pass).
 template <int EPT>
 __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
                                                               uint32_t kmin, uint32_t range, int stop_after)
@@ -215,11 +216,16 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             __syncthreads();
             {
                 const int pb = tid + 2 * (tid >> 4);
+                // stop_after == 3: the last pass also leaves rank[time step] in the buffer it read from (every thread took its
+                // indexes out of it before the first barrier of the pass) — no separate pass over the sorted order afterwards
+                const bool fuse_rank = stop_after == 3 && p == npass_rest - 1;
+                uint16_t *rk = const_cast<uint16_t *>(src);
 #pragma unroll
                 for (int e = 0; e < EPT; e++) {
                     int d = (int)((dgs >> (4 * e)) & 15u);
                     int pos = (int)base[d * BS + pb] + (int)((lrs >> (4 * e)) & 15u);  // no read-modify-write chain
                     dst[pos] = ids[e];
+                    if (fuse_rank) rk[ids[e]] = (uint16_t)pos;
                 }
             }
             __syncthreads();
@@ -227,6 +233,14 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
         }
         const uint16_t *sorted = cur ? idx1 : idx0;
         if (stop_after == 2) return sorted;
+        if (stop_after == 3) {
+            if (npass_rest == 0) {  // narrow keys: no stable pass to ride on
+                uint16_t *rk = cur ? idx0 : idx1;
+                for (int r = tid; r < TPAD; r += NT) rk[sorted[r]] = (uint16_t)r;
+                __syncthreads();
+            }
+            return sorted;
+        }
         for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
         __syncthreads();
 
@@ -289,13 +303,16 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            nv += __shfl_down(nv, o, 64);
-            kmin = min(kmin, (uint32_t)__shfl_down((int)kmin, o, 64));
-            kmax = max(kmax, (uint32_t)__shfl_down((int)kmax, o, 64));
-        }
-        if (lane == 0) { red[3 * wid] = (uint32_t)nv; red[3 * wid + 1] = kmin; red[3 * wid + 2] = kmax; }
+        // wave reduction on the DPP path (the steps of wave_incl_scan; lanes without a source see the identity): lane 63 holds
+        // the wave's count / min / max — no LDS crossbar round trips in front of the barrier
+#define XS_RED_STEP(ctrl, rmask)                                                                              \
+        nv += __builtin_amdgcn_update_dpp(0, nv, ctrl, rmask, 0xf, false);                                    \
+        kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)kmin, ctrl, rmask, 0xf, false));      \
+        kmax = max(kmax, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmax, ctrl, rmask, 0xf, false));
+        XS_RED_STEP(0x111, 0xf) XS_RED_STEP(0x112, 0xf) XS_RED_STEP(0x114, 0xf) XS_RED_STEP(0x118, 0xf)
+        XS_RED_STEP(0x142, 0xa) XS_RED_STEP(0x143, 0xc)
+#undef XS_RED_STEP
+        if (lane == 63) { red[3 * wid] = (uint32_t)nv; red[3 * wid + 1] = kmin; red[3 * wid + 2] = kmax; }
         __syncthreads();
         {   // all-reduce over the 16 waves: a lane per wave (in every row of 16), rotations inside the row
             static_assert(Cfg::NWAVE == 16, "one DPP row holds the per-wave results");

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
 {
     using Cfg = CellCfg<EPT>;
     using Cfg3 = CellCfg3<EPT>;
-    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
+    constexpr int TPAD = Cfg::TPAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
     uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0), *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
@@ -459,11 +459,10 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;  // hist first, then ref (see k_train_cell)
             int nvalid;
             const uint16_t *sorted;  // (no rank[] in the union region)
-            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W});
-            else sorted = cell_load_sort<EPT>(x, T, smem, red, 2, nvalid);
+            // (stop_after 3: rank[] is written by the sort's last pass into the buffer that pass read from)
+            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W});
+            else sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid);
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
-            for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
-            __syncthreads();
             const LdsVals vals{keys, sorted, TPAD};
             cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
                                                                kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G);
