@@ -105,7 +105,7 @@ template <int EPT> struct CellCfg {
 // (written by the last stable pass).
 template <int EPT>
 __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
-                                                              uint32_t kmin, uint32_t range, int stop_after)
+                                                              uint32_t kmin, uint32_t range, int stop_after, bool hist_zeroed = false)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
@@ -125,8 +125,10 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
         constexpr int D1 = 14, NB1 = 1 << D1;
         {
             uint32_t *hist = cntlo;  // NB1/2 dwords = 32 KB inside the sort scratch (cntlo/cnthi/base region)
-            for (int i = tid; i < NB1 / 2; i += NT) hist[i] = 0u;
-            __syncthreads();
+            if (!hist_zeroed) {  // (cell_load_sort clears it under the series' global loads, in front of a barrier it has anyway)
+                for (int i = tid; i < NB1 / 2; i += NT) hist[i] = 0u;
+                __syncthreads();
+            }
             uint32_t dgp[(EPT + 1) / 2];  // the 14-bit digits of this thread's elements, two per register
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
@@ -251,7 +253,10 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
 // indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
 // (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
 // stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
-struct NoLoadHook { __device__ __forceinline__ void operator()(const uint32_t *, int, int) const {} };
+struct NoLoadHook {
+    static constexpr bool uses_sort_scratch = false;
+    __device__ __forceinline__ void operator()(const uint32_t *, int, int) const {}
+};
 
 // `hook(keys, T, tid)` runs between the load and the sort: the keys of the series are in LDS, everything from off_idx0 up
 // to off_misc is still free (the DQM group sums use it, train_cell3.hpp); it must end on a block barrier if it touches LDS
@@ -284,6 +289,10 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 const int i = 2 * tid + j * 2 * NT;
                 v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
             }
+            if constexpr (!Hook::uses_sort_scratch) {  // the histogram of the sort's first pass, cleared while the loads are in flight
+                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
+                for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+            }
 #pragma unroll
             for (int j = 0; j < NL; j++) {
                 const int i = 2 * tid + j * 2 * NT;
@@ -301,6 +310,10 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 uint32_t k = i < Ti ? to_key(x[i]) : 0xFFFFFFFFu;
                 keys[i] = k;
                 if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
+            }
+            if constexpr (!Hook::uses_sort_scratch) {
+                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
+                for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
         // wave reduction on the DPP path (the steps of wave_incl_scan; lanes without a source see the identity): lane 63 holds
@@ -335,7 +348,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
 
         if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         hook(keys, Ti, tid);
-        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after);
+        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch);
 }
 
 // Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has

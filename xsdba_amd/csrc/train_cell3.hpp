@@ -52,6 +52,7 @@ __device__ __forceinline__ double wave_incl_scan_f64(double v)
 // A lane per group adds its members in member order: a fixed summation order, unlike running sums updated by toggles.
 // Also leaves max |x| over the finite values in guard[0] (the guard of the multiplicative kind, see cell_group_quantiles3).
 template <int EPT> struct GroupSumHook {
+    static constexpr bool uses_sort_scratch = true;  // P[] reaches into it: the sort clears its histogram itself
     unsigned char *smem;
     double *gsum;          // [G] (LDS)
     double *guard;         // [1] (LDS): max |x|
