@@ -332,7 +332,11 @@ def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
     from xsdba_amd._lib import default_context
 
     api_ctx = default_context()  # the context the mirror launches on (not the one the cubes were generated on)
-    run(*dev)  # warm-up (allocations)
+    # warm-up: two passes whose results are alive together, as in the timed loop (`scen = run(...)` holds the previous result
+    # while the next is produced): every buffer size the loop asks for is then in the context's pool twice
+    w1 = run(*dev)
+    w2 = run(*dev)
+    del w1, w2
     ctx.synchronize()
     api_ctx.synchronize()
     t0 = time.perf_counter()
