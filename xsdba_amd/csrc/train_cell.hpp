@@ -344,7 +344,9 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         const int nvalid = nv;
         nvalid_out = nv;
         const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
-        __syncthreads();
+        // red[] is next written behind the first barrier of the sort, which no wave passes before every wave has read it here:
+        // a barrier of its own only when a hook (or the timing aid's early return) comes in between
+        if (Hook::uses_sort_scratch || stop_after == 1) __syncthreads();
 
         if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         hook(keys, Ti, tid);
