@@ -213,12 +213,14 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     {
         const int *l = row_sorted + row_ptr[gb];
         const int len = row_ptr[gb + 1] - row_ptr[gb];
-        for (int i0 = 0; i0 < len; i0 += 512) {
-            int ts[8];
+        // 1024 entries per round (all of a day-of-year window's row): their reads are in flight together — one L2 round trip
+        // where every wave of the block waits at the same time
+        for (int i0 = 0; i0 < len; i0 += 1024) {
+            int ts[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+            for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) flip(bA, ts[u], dlocA);
+            for (int u = 0; u < 16; u++) flip(bA, ts[u], dlocA);
         }
         lds_wave_fence();
         for (int i = lane; i < VS; i += 64) { const uint32_t w = bA[i]; bB[i] = w; bC[i] = w; }
