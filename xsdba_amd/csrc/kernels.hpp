@@ -344,7 +344,10 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
         const R *trc = (DQM && trend) ? trend + (size_t)c * T : nullptr;
         int *ndc = node ? node + (size_t)c * T : nullptr;
         // EU elements per thread and round: their table searches are independent chains of LDS reads
-        constexpr int EU = 4;
+#ifndef XS_ADJ_EU
+#define XS_ADJ_EU 4
+#endif
+        constexpr int EU = XS_ADJ_EU;
         for (int t0 = threadIdx.x; t0 < Ti; t0 += EU * blockDim.x) {
             R v[EU], tr[EU], a[EU];
             int g0[EU], nd[EU];
