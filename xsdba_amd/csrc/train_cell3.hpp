@@ -291,10 +291,13 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         R mu = (R)0, inv = (R)0;
         if (DQM && PRESUM) {
             const double gs = gsum[vs && sid < 3 ? g : 0];
-            // sum / n through a refined reciprocal (v_rcp_f64 + one Newton step: within an ulp of the float64 quotient, which
-            // the cast to R absorbs) — the IEEE float64 division is ~35 instructions in every lane of every group step
+            // sum / n through a refined reciprocal — the IEEE float64 division is ~35 instructions in every lane of every group
+            // step.  v_rcp_f64 is good to ~2^-23 only: two Newton steps (2^-46, then below the float64 ulp) bring the product
+            // within an ulp of the quotient, which the cast to R absorbs (one step left 1 float32 ulp of difference to the
+            // oracle's mean in ~2 of 10^7 groups, seen on the 259 200-cell check)
             const double dn = (double)ns, r0 = __builtin_amdgcn_rcp(dn);
-            mu = ns ? (R)(gs * __builtin_fma(__builtin_fma(-dn, r0, 1.0), r0, r0)) : nan_of<R>();
+            const double r1 = __builtin_fma(__builtin_fma(-dn, r0, 1.0), r0, r0);
+            mu = ns ? (R)(gs * __builtin_fma(__builtin_fma(-dn, r1, 1.0), r1, r1)) : nan_of<R>();
             inv = invert<R>(mu, kind);
             if (vs && sid < 3 && ns && (!isfinite(mu) || (kind == '*' && !(inv > (R)0 && isfinite(inv))))) flag_cell = true;
             // The sums are differences of float64 running sums over time: absolute error ~ eps * n_time * max |x|.  The
