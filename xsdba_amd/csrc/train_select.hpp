@@ -232,15 +232,24 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 kmin = min(kmin, min(key[2 * j], key[2 * j + 1]));
                 kmx1 = max(kmx1, max(key[2 * j] + 1u, key[2 * j + 1] + 1u));
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64));
-                kmx1 = max(kmx1, (uint32_t)__shfl_xor((int)kmx1, o, 64));
-            }
-            if (lane == 0) { red[16 + 2 * wid] = kmin; red[16 + 2 * wid + 1] = kmx1; }
+            // wave reduction on the DPP path (lane 63 ends up with the wave's extremes), then a lane per wave and rotations
+            // inside the DPP row: no LDS crossbar shuffles, no loop over the waves
+#define XS_SEL_RED(ctrl, rmask)                                                                               \
+            kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)kmin, ctrl, rmask, 0xf, false)); \
+            kmx1 = max(kmx1, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)kmx1, ctrl, rmask, 0xf, false));
+            XS_SEL_RED(0x111, 0xf) XS_SEL_RED(0x112, 0xf) XS_SEL_RED(0x114, 0xf) XS_SEL_RED(0x118, 0xf)
+            XS_SEL_RED(0x142, 0xa) XS_SEL_RED(0x143, 0xc)
+#undef XS_SEL_RED
+            if (lane == 63) { red[16 + 2 * wid] = kmin; red[16 + 2 * wid + 1] = kmx1; }
             __syncthreads();  // (also: tables cleared)
-#pragma unroll
-            for (int w = 0; w < NT / 64; w++) { kmin = min(kmin, red[16 + 2 * w]); kmx1 = max(kmx1, red[16 + 2 * w + 1]); }
+            static_assert(NT / 64 == 8, "the per-wave extremes fill half a DPP row");
+            kmin = red[16 + 2 * (lane & 7)];
+            kmx1 = red[16 + 2 * (lane & 7) + 1];
+#define XS_SEL_ROR(n)                                                                                                  \
+            kmin = min(kmin, (uint32_t)__builtin_amdgcn_update_dpp((int)kmin, (int)kmin, 0x120 + (n), 0xf, 0xf, false)); \
+            kmx1 = max(kmx1, (uint32_t)__builtin_amdgcn_update_dpp((int)kmx1, (int)kmx1, 0x120 + (n), 0xf, 0xf, false));
+            XS_SEL_ROR(4) XS_SEL_ROR(2) XS_SEL_ROR(1)
+#undef XS_SEL_ROR
             // (uniform values: kept in scalar registers)
             kmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmin);
             kmx1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmx1);
