@@ -83,20 +83,33 @@ template <int EPT> struct GroupSumHook {
             amaxf = fmaxf(amaxf, (ok && fabsf(v) <= 3.4028234663852886e38f) ? fabsf(v) : 0.0f);
         }
         const double incl = wave_incl_scan_f64(run);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amaxf = fmaxf(amaxf, __shfl_xor(amaxf, o, 64));
-        if (lane == 63) part[wid] = incl;
-        if (lane == 0) part[NW + wid] = (double)amaxf;
+        // (maxima on the DPP path like the sums: the steps of wave_incl_scan, lanes without a source see 0; lane 63 ends up with
+        //  the wave's — no LDS crossbar shuffles in front of a barrier every wave waits at)
+        auto dpp_max = [&](auto ctrl, auto rmask) {
+            amaxf = fmaxf(amaxf, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(amaxf), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false)));
+        };
+        using std::integral_constant;
+        dpp_max(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+        dpp_max(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+        dpp_max(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+        dpp_max(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
+        dpp_max(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});
+        dpp_max(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});
+        float *pmax = reinterpret_cast<float *>(part + NW);  // [NW] wave maxima
+        if (lane == 63) { part[wid] = incl; pmax[wid] = amaxf; }
         __syncthreads();
         // ... the NW wave totals scanned by the first lanes of wave 0, ...
         if (wid == 0) {
-            const double tot = lane < NW ? part[lane] : 0.0, mx = lane < NW ? part[NW + lane] : 0.0;
+            static_assert(NW == 16, "the wave maxima fill one DPP row");
+            const double tot = lane < NW ? part[lane] : 0.0;
+            amaxf = pmax[lane & (NW - 1)];
             const double ex = wave_incl_scan_f64(tot) - tot;
-            double m = mx;
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+            dpp_max(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});
+            dpp_max(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});
+            dpp_max(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});
+            dpp_max(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});
             if (lane < NW) part[lane] = ex;
-            if (lane == 0) guard[0] = m;
+            if (lane == NW - 1) guard[0] = (double)amaxf;  // (the row's last lane holds the maximum of all sixteen)
         }
         __syncthreads();
         // ... then the running sums themselves, from the thread's offset (the values are read again)
