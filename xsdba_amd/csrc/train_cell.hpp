@@ -117,6 +117,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
     uint16_t *base = reinterpret_cast<uint16_t *>(smem + Cfg::off_base);
     uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
     const int lane = tid & 63, wid = tid >> 6;
+    static_assert(Cfg::NWAVE == 16, "waves_before() scans one DPP row of per-wave totals");
     const int nbits = 32 - __clz((int)(range + 1u) | 0);
         // ---------------- B. LSD radix sort of the time indexes ----------------
         // Pass 1 takes the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no
