@@ -227,7 +227,29 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         ct.any_valid = 1;
         return ct;
     }
-    if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
+    const bool vec16 = xq_row_stride == Q && (n & 3) == 0 &&
+                       ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(t.xs) |
+                         reinterpret_cast<uintptr_t>(t.ys)) & 15) == 0;
+    if (sizeof(R) == 4 && vec16) {  // plain [G][Q] float tables, 16-byte aligned on both sides: four values per load and store
+        const int n4 = n >> 2;
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(xq), *y4 = reinterpret_cast<const uint4 *>(yq);
+        uint4 *dx = reinterpret_cast<uint4 *>(t.xs), *dy = reinterpret_cast<uint4 *>(t.ys);
+        auto nan4 = [](const uint4 &v) {  // any NaN among four float bit patterns
+            auto isn = [](uint32_t b) { return (b & 0x7FFFFFFFu) > 0x7F800000u; };
+            return isn(v.x) || isn(v.y) || isn(v.z) || isn(v.w);
+        };
+        constexpr int NB4 = 3;  // (a 365 x 20 table is 1825 vectors: three per thread of a 768-thread block, all in flight)
+        for (int i0 = threadIdx.x; i0 < n4; i0 += NB4 * blockDim.x) {
+            uint4 xv[NB4], yv[NB4];
+#pragma unroll
+            for (int k = 0; k < NB4; k++) { const int i = min(i0 + k * (int)blockDim.x, n4 - 1); xv[k] = x4[i]; yv[k] = y4[i]; }
+#pragma unroll
+            for (int k = 0; k < NB4; k++) {
+                const int i = i0 + k * (int)blockDim.x;
+                if (i < n4) { dx[i] = xv[k]; dy[i] = yv[k]; has_nan |= nan4(xv[k]) || nan4(yv[k]); }
+            }
+        }
+    } else if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
         // NB elements of each table are requested before the first is stored: one memory latency per batch
         constexpr int NB = 8;
         for (int i0 = threadIdx.x; i0 < n; i0 += NB * blockDim.x) {
