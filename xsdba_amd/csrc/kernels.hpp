@@ -487,6 +487,13 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     R *tr_out = trend_cm + (size_t)c * T;
     for (int i = threadIdx.x; i <= W; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
     R *m = M_LDS ? xs + T : tr_out;
+    // the cell's scaling factors wait in LDS (in the coefficient area, which is written much later): the load below then has one
+    // global round trip per batch — value and group — instead of a dependent second one for the factor of that group
+    R *scl = reinterpret_cast<R *>(coef);
+    if (scaling) {
+        for (int i = threadIdx.x; i < G; i += blockDim.x) scl[i] = scaling[(size_t)c * G + i];
+        __syncthreads();
+    }
     {
         constexpr int NB = 8;  // NB series values (and their groups) are requested before the first is consumed
         for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
@@ -503,7 +510,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                 const int64_t t = t0 + (int64_t)k * blockDim.x;
                 if (t < T) {
                     R w = v[k];
-                    if (scaling) w = apply_corr<R>(w, gg[k] >= 0 ? scaling[(size_t)c * G + gg[k]] : nan_of<R>(), kind);
+                    if (scaling) w = apply_corr<R>(w, gg[k] >= 0 ? scl[gg[k]] : nan_of<R>(), kind);
                     xs[t] = w;
                 }
             }
