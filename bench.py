@@ -20,6 +20,7 @@ import json
 import os
 import re
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -73,21 +74,38 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="eqm_doy31", choices=sorted(WORKLOADS))
-    ap.add_argument("--cells", type=int, default=360 * 180, help="grid cells per GPU (default: the 360x180 grid)")
+    ap.add_argument("--cells", type=int, default=None, help="grid cells per GPU (default: 64 800, the 360x180 grid; 129 600 at 8 GPUs, "
+                    "an eighth of the 1440x720 grid)")
     ap.add_argument("--days", type=int, default=10950)
     ap.add_argument("--nquantiles", type=int, default=20)
     ap.add_argument("--time-major", action="store_true", help="store the cubes as (time, cell) instead of (cell, time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-api-level", action="store_true", help="skip the secondary figure through the drop-in API")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample")
-    ap.add_argument("--gather", action="store_true", help="also time (and verify) the final native RCCL gather of scen to rank 0")
+    ap.add_argument("--gather", action="store_true", help="also time (and verify) the final native RCCL gather of scen to rank 0 "
+                    "(the default with more than one rank)")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of scen")
+    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the gather leg may take before the line is printed without it")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)  # rendezvous only, no GPU work (tests/test_bench_spawn.py)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves.  Nothing has touched HIP in this process (the library is
+        # imported below, in the ranks), and the ranks are CHILD processes — never an exec of this one.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.cells is None:
+        # one GPU: the 360x180 grid of configs[1]; eight: the per-GPU shard of north_star's 1440x720 cube (configs[3] / [4])
+        args.cells = 1440 * 720 // 8 if world == 8 else 360 * 180
+    if world > 1 and not args.no_gather:
+        args.gather = True
+    if args.dry_run:
+        return dry_run(world, rank)
 
     dist = None
     # torch.distributed is rendezvous / barrier / MAX-over-ranks plumbing only, on CPU tensors ("gloo"): the process then
@@ -97,8 +115,10 @@ def main():
     backend = os.environ.get("XSDBA_BENCH_BACKEND", "gloo")
     from xsdba_amd import _lib as xlib
 
-    ndev = max(xlib.device_count(), 1)
-    device = local_rank % ndev
+    ndev = xlib.device_count()
+    if world > max(ndev, 1) and not os.environ.get("XSDBA_BENCH_SHARE_GPU"):
+        raise SystemExit(f"{world} ranks but {ndev} visible GPU(s): one process per GPU (XSDBA_BENCH_SHARE_GPU=1 to rehearse on fewer)")
+    device = local_rank % max(ndev, 1)
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -189,49 +209,6 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    gather_info = None
-    if args.gather:
-        # the one collective of the path: the final gather of the per-rank scen blocks to rank 0 — native (xsdba_hip_gather:
-        # RCCL sends / receives straight from the device buffers on the library's stream); timed separately, never part of
-        # `value`.  Self-check: rank 0 compares rows of every rank's block in the gathered cube with what that rank holds.
-        from xsdba_amd.sharding import comm_info, gather_device, init_comm, shard_plan
-
-        scen_dev = outs[-1] if method != "dqm" else outs[3]
-        # (RCCL prints a version banner on stdout when its first communicator comes up: stdout belongs to the JSON line)
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            init_comm(ctx, rank, world)
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
-        r_rccl, n_rccl = comm_info(ctx)
-        assert (r_rccl, n_rccl) == (rank, world), (r_rccl, n_rccl)
-        assert shard_plan(C * world, world, rank) == (rank * C, C)
-        full = gather_device(ctx, scen_dev, C * world, root=0)  # warm-up (connection set-up) + the buffer
-        barrier()
-        g0 = time.perf_counter()
-        gather_device(ctx, scen_dev, C * world, root=0, out=full)
-        ctx.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
-        probe_rows = [0, C // 2, C - 1]
-        mine = scen_dev.download()[probe_rows]
-        ok = True
-        if dist is not None:
-            box = [None] * world if rank == 0 else None
-            dist.gather_object(mine, box, dst=0)
-        else:
-            box = [mine]
-        if rank == 0:
-            got = full.download()
-            for r, rows in enumerate(box):
-                ok = ok and np.array_equal(got[[r * C + i for i in probe_rows]], rows, equal_nan=True)
-            gather_info = {"ms": round(gather_ms, 3), "ranks_seen_by_rccl": n_rccl, "bytes": int(C * world * T * 4),
-                           "GB/s": round(C * (world - 1) * T * 4 / (gather_ms * 1e-3) / 1e9, 1), "verified": bool(ok)}
-            assert ok, "the gathered cube differs from the per-rank results"
-
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         cells_total = C * world
@@ -269,11 +246,8 @@ def main():
             },
             "roofline": roof,
         }
-        if gather_info is not None:
-            out["gather"] = gather_info
-        if not args.no_api_level and not args.time_major:
-            out["api_level"] = api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
         if not args.no_api_level and not args.time_major and world == 1:
+            out["api_level"] = api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
             # secondary figure: the same step on (time, cell) cubes — what a (time, lat, lon) array is — through the same entry
             # points (the library re-lays every series with a tiled transpose on the way in and out, charged to the step)
             tm = [ctx.synth((C, T), np.float32, gen, i, seed, cell0, ncf, nif, time_major=True) for i in range(3)]
@@ -292,13 +266,129 @@ def main():
             ref, hist, sim = cm
             for a in tm:
                 a.free()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
                                                args.cpu_seconds, args.time_major, rank_window)
+    else:
+        out = None
+
+    if args.gather:
+        # the one collective of the path, last: the final gather of the per-rank scen blocks to rank 0 (timed separately, never
+        # part of `value`).  Guarded: a rank that fails or a collective that does not come back within --gather-timeout must
+        # not cost the line — rank 0 then prints it with the error in "gather" and every rank leaves.
+        printed = threading.Lock()
+
+        def give_up(info=None):
+            if printed.acquire(blocking=False):
+                if rank == 0:
+                    out["gather"] = info or {"error": f"no result within {args.gather_timeout:.0f} s", "verified": False}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        dog = threading.Timer(args.gather_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            info = gather_leg(ctx, dist, outs[3] if method == "dqm" else outs[-1], rank, world, C, T, barrier)
+        except Exception as e:  # noqa: BLE001 - reported in the line
+            info = {"error": f"{type(e).__name__}: {e}"[:300], "verified": False}
+            if world > 1:  # the other ranks may be inside the collective: leave (their watchdogs end them)
+                give_up(info)
+        if not printed.acquire(blocking=False):
+            time.sleep(3600)  # the watchdog is printing
+        dog.cancel()
+        if rank == 0:
+            out["gather"] = info
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def gather_leg(ctx, dist, scen_dev, rank, world, C, T, barrier):
+    """Native gather of the per-rank scen blocks to rank 0 (xsdba_hip_gather: RCCL sends / receives straight from the device
+    buffers on the library's stream).  Self-check: rank 0 compares rows of every rank's block of the gathered cube with what
+    that rank holds.  Returns the "gather" object of the line on rank 0."""
+    from xsdba_amd._lib import DeviceArray
+    from xsdba_amd.sharding import comm_info, gather_device, init_comm, shard_plan
+
+    # (RCCL prints a version banner on stdout when its first communicator comes up: stdout belongs to the JSON line)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        init_comm(ctx, rank, world)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+    r_rccl, n_rccl = comm_info(ctx)
+    assert (r_rccl, n_rccl) == (rank, world), (r_rccl, n_rccl)
+    assert shard_plan(C * world, world, rank) == (rank * C, C)
+    full = gather_device(ctx, scen_dev, C * world, root=0)  # warm-up (connection set-up) + the buffer
+    barrier()
+    g0 = time.perf_counter()
+    gather_device(ctx, scen_dev, C * world, root=0, out=full)
+    ctx.synchronize()
+    gather_ms = (time.perf_counter() - g0) * 1e3
+    probe_rows = [0, C // 2, C - 1]
+
+    def rows_of(dev, rows):  # a few rows of a [cells, T] float32 device array (the gathered cube is tens of GB: never all of it)
+        return np.stack([DeviceArray.from_ptr(ctx, dev.ptr + r * T * 4, (T,), np.float32).download() for r in rows])
+
+    mine = rows_of(scen_dev, probe_rows)
+    if dist is not None:
+        box = [None] * world if rank == 0 else None
+        dist.gather_object(mine, box, dst=0)
+    else:
+        box = [mine]
+    if rank != 0:
+        return None
+    ok = all(np.array_equal(rows_of(full, [r * C + i for i in probe_rows]), rows, equal_nan=True) for r, rows in enumerate(box))
+    return {"ms": round(gather_ms, 3), "ranks_seen_by_rccl": n_rccl, "bytes": int(C * world * T * 4),
+            "GB/s": round(C * (world - 1) * T * 4 / (gather_ms * 1e-3) / 1e9, 1), "verified": bool(ok)}
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run `torch.distributed.run --nproc-per-node N bench.py <same arguments>`
+    as a child process, relay rank 0's JSON line and return the child's status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is None:
+        print(f"bench.py: the {n} ranks printed no result line (status {proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    print(line, flush=True)
+    return proc.returncode
+
+
+def dry_run(world: int, rank: int) -> None:
+    """Rendezvous only (gloo), no GPU work: what tests/test_bench_spawn.py runs on a box without a GPU."""
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo")
+    t = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "ranks_seen": int(t.item()), "dry_run": True}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window):

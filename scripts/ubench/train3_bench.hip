@@ -1,0 +1,155 @@
+// train3_bench.hip — k_train_cell3 (the metric's dominant kernel) in isolation: same plan, same data generator and same
+// launch as xsdba_hip_eqm_train for Grouper("time.dayofyear", 31), but a 3-second build — the bench for kernel experiments —
+// and the phase-stop instantiations (STOP = 1..4) whose differences attribute time and PMC counters to the kernel's phases.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Ixsdba_amd/csrc -o scripts/ubench/build/train3_bench scripts/ubench/train3_bench.hip
+//   scripts/ubench/build/train3_bench [cells=64800] [reps=5] [stop=-1: all phases | 0..4]
+// Prints per phase build: ms per launch and the FNV-1a checksum of (hist_q, af) — two builds of the full kernel (STOP 0) that
+// print the same checksum computed the same tables, bit for bit.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iterator>
+#include <vector>
+
+#include "train_cell3.hpp"
+
+#define CK(x)                                                                                   \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } \
+    } while (0)
+
+struct Plan {
+    int G = 0, max_row = 0;
+    int *d_row_ptr = nullptr, *d_row_sorted = nullptr, *d_tog64 = nullptr;
+};
+
+template <typename T> static T *upload(const std::vector<T> &v)
+{
+    T *d;
+    CK(hipMalloc(&d, std::max<size_t>(v.size(), 1) * sizeof(T)));
+    CK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+// the plan of xsdba_hip_eqm_train (api.hip: get_plan) for day-of-year groups on a noleap calendar and a centred window
+static Plan make_plan(int T, int G, int W)
+{
+    Plan pl;
+    pl.G = G;
+    std::vector<int> row_ptr(G + 1, 0);
+    const int hw = W / 2;
+    for (int t = 0; t < T; t++) {
+        const int lo = std::max(0, t - hw), hi = std::min(T - 1, t - hw + W - 1);
+        row_ptr[t % G + 1] += hi - lo + 1;
+    }
+    for (int i = 0; i < G; i++) { pl.max_row = std::max(pl.max_row, row_ptr[i + 1]); row_ptr[i + 1] += row_ptr[i]; }
+    std::vector<int> rows(row_ptr[G]), rp(row_ptr.begin(), row_ptr.end() - 1);
+    for (int t = 0; t < T; t++)
+        for (int j = 0; j < W; j++) {
+            const int tt = t + j - hw;
+            if (tt >= 0 && tt < T) rows[rp[t % G]++] = tt;
+        }
+    std::vector<int> t64((size_t)G * 64, T);  // (padding: time step T, a padding step of the series)
+    for (int i = 0; i < G; i++) std::sort(rows.begin() + row_ptr[i], rows.begin() + row_ptr[i + 1]);
+    for (int i = 0; i + 1 < G; i++) {
+        std::vector<int> d;
+        std::set_symmetric_difference(rows.begin() + row_ptr[i], rows.begin() + row_ptr[i + 1], rows.begin() + row_ptr[i + 1],
+                                      rows.begin() + row_ptr[i + 2], std::back_inserter(d));
+        if (d.size() > 64) { fprintf(stderr, "toggle list of %zu entries\n", d.size()); exit(1); }
+        std::copy(d.begin(), d.end(), t64.begin() + (size_t)(i + 1) * 64);
+        // the lanes behind the list flip pairs of its own entries (twice = not at all) instead of all hitting the padding step's
+        // one scratch word; an odd lane out keeps the padding step
+        for (size_t j = d.size(), e = 0; j + 1 < 64 && e < d.size(); j += 2, e++) t64[(size_t)(i + 1) * 64 + j] = t64[(size_t)(i + 1) * 64 + j + 1] = d[e];
+    }
+    pl.d_row_ptr = upload(row_ptr);
+    pl.d_row_sorted = upload(rows);
+    pl.d_tog64 = upload(t64);
+    return pl;
+}
+
+static uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
+{
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+template <int STOP>
+static void run(const char *what, const float *ref, const float *hist, int T, int C, const Plan &pl, const float *dq, int Q, float *af, float *hq,
+                int *flags, int reps, bool checksum)
+{
+    constexpr int EPT = 11;
+    auto kern = xs::k_train_cell3<EPT, true, false, STOP>;
+    const size_t lds = xs::CellCfg3<EPT>::lds_bytes;
+    CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned nblk = (unsigned)std::min(C, 4 * 256);
+    CK(hipMemset(flags, 0, 4));
+    auto launch = [&]() {
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), lds, 0, ref, hist, (int64_t)T, (int64_t)T, pl.d_row_ptr, pl.d_row_sorted, pl.G, dq, Q, (int)'+', 1,
+                           af, hq, (float *)nullptr, flags, flags + 1, (int64_t)C, pl.d_tog64, (const int *)nullptr, (const int *)nullptr,
+                           (const int *)nullptr, 31);
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ms(reps);
+    for (int r = 0; r < reps; r++) {
+        CK(hipEventRecord(e0, 0));
+        launch();
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms[r], e0, e1));
+    }
+    std::sort(ms.begin(), ms.end());
+    printf("%-44s stop=%d  %8.3f ms/launch (median of %d, min %.3f)  = %7.3f ms per 64800 cells", what, STOP, ms[reps / 2], reps, ms[0],
+           ms[reps / 2] * 64800.0 / C);
+    if (checksum && STOP == 0) {
+        const size_t n = (size_t)C * pl.G * Q;
+        std::vector<float> h(n);
+        CK(hipMemcpy(h.data(), hq, n * 4, hipMemcpyDeviceToHost));
+        uint64_t c = fnv(h.data(), n * 4);
+        CK(hipMemcpy(h.data(), af, n * 4, hipMemcpyDeviceToHost));
+        c = fnv(h.data(), n * 4, c);
+        int nflag = 0;
+        CK(hipMemcpy(&nflag, flags, 4, hipMemcpyDeviceToHost));
+        printf("  checksum %016llx flagged %d", (unsigned long long)c, nflag);
+    }
+    printf("\n");
+    fflush(stdout);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1));
+}
+
+int main(int argc, char **argv)
+{
+    const int C = argc > 1 ? atoi(argv[1]) : 64800, reps = argc > 2 ? atoi(argv[2]) : 5, stop = argc > 3 ? atoi(argv[3]) : -1;
+    const int T = 10950, G = 365, W = 31, Q = 20;
+    float *ref, *hist, *af, *hq, *dq;
+    int *flags;
+    CK(hipMalloc(&ref, (size_t)C * T * 4));
+    CK(hipMalloc(&hist, (size_t)C * T * 4));
+    CK(hipMalloc(&af, (size_t)C * G * Q * 4));
+    CK(hipMalloc(&hq, (size_t)C * G * Q * 4));
+    CK(hipMalloc(&flags, ((size_t)C + 1) * 4));
+    // bench.py's eqm_doy31 cubes: generator 0, seed 1, arrays 0 (ref) and 1 (hist)
+    hipLaunchKernelGGL(xs::k_synth<float>, dim3(4096), dim3(256), 0, 0, ref, (int64_t)T, (int64_t)C, (int64_t)1, (int64_t)T, 0, 0, (uint64_t)1, (int64_t)0, 0.f, 0.f);
+    hipLaunchKernelGGL(xs::k_synth<float>, dim3(4096), dim3(256), 0, 0, hist, (int64_t)T, (int64_t)C, (int64_t)1, (int64_t)T, 0, 1, (uint64_t)1, (int64_t)0, 0.f, 0.f);
+    std::vector<float> q(Q);
+    for (int k = 0; k < Q; k++) q[k] = (float)((k + 0.5) / Q);
+    dq = upload(q);
+    Plan pl = make_plan(T, G, W);
+    CK(hipDeviceSynchronize());
+    printf("# k_train_cell3<11, P10, EQM>: %d cells x %d days, %d groups, window %d, %d quantiles; max row %d\n", C, T, G, W, Q, pl.max_row);
+    // x0 = ref, x1 = hist in the kernel's argument order (mode 1: hist first, then ref)
+    if (stop < 0 || stop == 1) run<1>("load (+ keys, min / max)", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
+    if (stop < 0 || stop == 2) run<2>("load + sort", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
+    if (stop < 0 || stop == 3) run<3>("load + sort + build / copies / fast-forward", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
+    if (stop < 0 || stop == 4) run<4>("... + group loop without the select", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
+    if (stop < 0 || stop == 0) run<0>("full kernel", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, true);
+    return 0;
+}

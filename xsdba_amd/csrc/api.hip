@@ -68,6 +68,7 @@ struct Plan {
     bool simple = false;  // no time index occurs twice in one group row
     int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
+    int *d_tog64p = nullptr;  // the same table for k_train_cell3: no -1 entries (see get_plan)
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     bool has_ungrouped = false;  // some time step belongs to no group
 };
@@ -105,13 +106,27 @@ namespace {
 
 enum Slot { S_IN0 = 0, S_IN1, S_TAB0, S_TAB1, S_TAB2, S_OUT0, S_OUT1, S_CM0, S_CM1, S_CM2, S_Q, S_MISC, S_SCR, S_FLAGS, S_PARK, S_NSLOTS };
 
+void pool_flush(xsdba_hip_ctx *ctx);
+
+// every device allocation of the library: out of memory while freed user buffers sit in the context's pool (xsdba_hip_malloc /
+// _free below) gives those back and tries once more
+int dev_malloc(xsdba_hip_ctx *ctx, void **p, size_t bytes)
+{
+    if (hipMalloc(p, bytes) == hipSuccess) return 0;
+    (void)hipGetLastError();
+    pool_flush(ctx);
+    HIP_TRY(hipMalloc(p, bytes));
+    return 0;
+}
+
 int ensure(xsdba_hip_ctx *ctx, int slot, size_t bytes, void **out)
 {
     DevBuf &b = ctx->scratch[slot];
     if (b.cap < bytes) {
         if (b.p) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
         size_t cap = bytes + bytes / 8 + 256;
-        HIP_TRY(hipMalloc(&b.p, cap));
+        int rc = dev_malloc(ctx, &b.p, cap);
+        if (rc) return rc;
         b.cap = cap;
     }
     *out = b.p;
@@ -210,7 +225,8 @@ uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull)
 int upload_ints(xsdba_hip_ctx *ctx, const std::vector<int> &v, int **d)
 {
     size_t n = std::max<size_t>(v.size(), 1);
-    HIP_TRY(hipMalloc((void **)d, n * sizeof(int)));
+    int rc = dev_malloc(ctx, (void **)d, n * sizeof(int));
+    if (rc) return rc;
     if (!v.empty()) HIP_TRY(hipMemcpyAsync(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     return 0;
 }
@@ -221,6 +237,7 @@ void free_plan(Plan *p)
     (void)hipFree(p->d_mem_ptr); (void)hipFree(p->d_mem_idx);
     (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
     if (p->d_tog64) (void)hipFree(p->d_tog64);
+    if (p->d_tog64p) (void)hipFree(p->d_tog64p);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
 }
 
@@ -318,6 +335,18 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
             for (int i = 0; i + 1 < G; i++)
                 std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t64.begin() + (size_t)(i + 1) * 64);
             if ((rc = upload_ints(ctx, t64, &pl->d_tog64))) return rc;
+            // k_train_cell3 flips whatever a lane reads, without a test: the lanes behind a list get PAIRS of the list's own
+            // entries (flipped twice = not at all, and spread over the vector instead of all hitting one word), an odd lane out and
+            // the rows without a list get time step T — a padding step of the series (the kernel requires T < TPAD), whose
+            // "rank" is a bit of a scratch word
+            std::vector<int> t64p((size_t)G * 64, (int)T);
+            for (int i = 0; i + 1 < G; i++) {
+                const int b = tog_ptr[(size_t)i], n = tog_ptr[(size_t)i + 1] - b;
+                int *row = t64p.data() + (size_t)(i + 1) * 64;
+                std::copy(tog_idx.begin() + b, tog_idx.begin() + b + n, row);
+                for (int j = n, e = 0; j + 1 < 64 && e < n; j += 2, e++) row[j] = row[j + 1] = tog_idx[(size_t)b + e];
+            }
+            if ((rc = upload_ints(ctx, t64p, &pl->d_tog64p))) return rc;
         }
     }
     if (G > 1 && pl->max_mem <= 32 && T < 65535) {
@@ -371,7 +400,7 @@ int series_in(xsdba_hip_ctx *ctx, int slot_raw, int slot_cm, const void *x, int6
     if (!x) return fail(XSDBA_E_ARG, "null series pointer");
     if (st <= 0 || sc <= 0) return fail(XSDBA_E_ARG, "strides must be positive");
     // a HOST series is staged as exactly T * C dense elements: anything but the two dense layouts would be read past the copy
-    if (!is_device_ptr(x) && !((st == 1 && sc == T) || (sc == 1 && st == C) || C == 1 || T == 1))
+    if (!is_device_ptr(x) && !((st == 1 && sc == T) || (sc == 1 && st == C) || (C == 1 && st == 1) || (T == 1 && sc == 1)))
         return fail(XSDBA_E_ARG, "a host series must be dense: (stride_t, stride_c) = (1, n_time) or (n_cell, 1), got (%lld, %lld)",
                     (long long)st, (long long)sc);
     const void *d;
@@ -577,14 +606,16 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 LaunchScope ls(ctx, "k_train_cell3");
                 hipLaunchKernelGGL((xs::k_train_cell3<EPT, P10, DQM>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, G, (const float *)dq, Q, (int)kind, mode,
-                                   (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C, pl->d_tog64,
+                                   (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C, pl->d_tog64p,
                                    pl->d_mem_ptr, pl->d_mem_idx, (8 * (int64_t)G <= T) ? pl->d_mem_t32 : (const int *)nullptr, pl->W);
                 return check_launch("k_train_cell3");
             };
             const char *t3 = getenv("XSDBA_HIP_TRAIN3");
             const size_t lds3 = (ept == 4 ? xs::CellCfg3<4>::lds_bytes : ept == 8 ? xs::CellCfg3<8>::lds_bytes : xs::CellCfg3<11>::lds_bytes) +
                                 (mode == 2 ? ((size_t)G + 1) * sizeof(double) : 0);
-            const bool three = !dbg && pl->d_tog64 && Q <= 21 && G >= 48 && lds3 <= (size_t)ctx->lds_limit && !(t3 && !strcmp(t3, "0"));
+            // (T < TPAD: the kernel uses time step T, a padding step of the series in LDS, as the "no toggle" entry of its table)
+            const bool three = !dbg && pl->d_tog64p && Q <= 21 && G >= 48 && T < (int64_t)ept * 1024 && lds3 <= (size_t)ctx->lds_limit &&
+                               !(t3 && !strcmp(t3, "0"));
             auto pick3d = [&](auto cfg, auto p10) -> int { return mode == 2 ? go3(cfg, p10, true_type{}) : go3(cfg, p10, false_type{}); };
             auto pick3 = [&](auto cfg) -> int { return pl->max_row <= 1023 ? pick3d(cfg, true_type{}) : pick3d(cfg, false_type{}); };
             if (three)
@@ -1538,10 +1569,14 @@ API int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream)
 static size_t pool_cap_bytes()
 {
     const char *e = getenv("XSDBA_HIP_POOL_MB");
-    return (size_t)(e ? atof(e) : 16384.0) << 20;
+    double mb = e ? atof(e) : 16384.0;
+    if (!(mb >= 0.0)) mb = 0.0;            // negative or unparsable: no pool
+    if (mb > 1.0e9) mb = 1.0e9;
+    return (size_t)mb << 20;
 }
 
-static void pool_flush(xsdba_hip_ctx *ctx)
+namespace {
+void pool_flush(xsdba_hip_ctx *ctx)
 {
     if (ctx->pool.empty()) return;
     (void)hipStreamSynchronize(ctx->stream);
@@ -1549,6 +1584,7 @@ static void pool_flush(xsdba_hip_ctx *ctx)
     ctx->pool.clear();
     ctx->pool_bytes = 0;
 }
+}  // namespace
 
 API int xsdba_hip_malloc(xsdba_hip_ctx *ctx, size_t bytes, void **dptr)
 {
@@ -1565,11 +1601,7 @@ API int xsdba_hip_malloc(xsdba_hip_ctx *ctx, size_t bytes, void **dptr)
             ctx->user_sizes.push_back(n);
             return 0;
         }
-    if (hipMalloc(dptr, n) != hipSuccess) {  // out of memory with buffers parked in the pool: give them back and try again
-        (void)hipGetLastError();
-        pool_flush(ctx);
-        HIP_TRY(hipMalloc(dptr, n));
-    }
+    if ((rc = dev_malloc(ctx, dptr, n))) return rc;
     ctx->user_allocs.push_back(*dptr);
     ctx->user_sizes.push_back(n);
     return 0;
@@ -1585,7 +1617,16 @@ API int xsdba_hip_free(xsdba_hip_ctx *ctx, void *dptr)
     const size_t idx = (size_t)(it - ctx->user_allocs.begin()), n = ctx->user_sizes[idx];
     ctx->user_allocs.erase(it);
     ctx->user_sizes.erase(ctx->user_sizes.begin() + (long)idx);
-    if (n >= ((size_t)1 << 20) && ctx->pool_bytes + n <= pool_cap_bytes()) {
+    const size_t cap = pool_cap_bytes();
+    if (n >= ((size_t)1 << 20) && n <= cap) {
+        if (ctx->pool_bytes + n > cap) {  // full: the oldest entries make room (sizes that are no longer asked for age out)
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            while (!ctx->pool.empty() && ctx->pool_bytes + n > cap) {
+                (void)hipFree(ctx->pool.front().second);
+                ctx->pool_bytes -= ctx->pool.front().first;
+                ctx->pool.erase(ctx->pool.begin());
+            }
+        }
         ctx->pool.emplace_back(n, dptr);
         ctx->pool_bytes += n;
         return 0;
@@ -1720,6 +1761,17 @@ int rccl_load()
         if (r_ != 0) return fail(XSDBA_E_ARG, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));               \
     } while (0)
 
+// inside ncclGroupStart .. ncclGroupEnd: a failed call closes the group (result ignored) before the error is returned, so that
+// later RCCL calls of this thread are not queued into a group nobody ends
+#define RCCL_TRY_IN_GROUP(expr)                                                                                 \
+    do {                                                                                                        \
+        int r_ = (expr);                                                                                        \
+        if (r_ != 0) {                                                                                          \
+            (void)g_rccl.GroupEnd();                                                                            \
+            return fail(XSDBA_E_ARG, "%s failed: %s", #expr, g_rccl.GetErrorString(r_));                        \
+        }                                                                                                       \
+    } while (0)
+
 void shard_block(int64_t n_cell, int n_ranks, int rank, int64_t *first, int64_t *count)
 {
     const int64_t base = n_cell / n_ranks, rem = n_cell % n_ranks;
@@ -1810,12 +1862,12 @@ API int xsdba_hip_gather(xsdba_hip_ctx *ctx, const void *send, int64_t n_local, 
             const size_t total = (size_t)c * row_elems;
             char *base = (char *)recv + (size_t)f * row_elems * esz;
             for (size_t o = 0; o < total; o += PIECE)
-                RCCL_TRY(g_rccl.Recv(base + o * esz, std::min(PIECE, total - o), nccl_dt, r, ctx->comm, ctx->stream));
+                RCCL_TRY_IN_GROUP(g_rccl.Recv(base + o * esz, std::min(PIECE, total - o), nccl_dt, r, ctx->comm, ctx->stream));
         }
     {
         const size_t total = (size_t)n_local * row_elems;
         for (size_t o = 0; o < total; o += PIECE)
-            RCCL_TRY(g_rccl.Send((const char *)send + o * esz, std::min(PIECE, total - o), nccl_dt, root, ctx->comm, ctx->stream));
+            RCCL_TRY_IN_GROUP(g_rccl.Send((const char *)send + o * esz, std::min(PIECE, total - o), nccl_dt, root, ctx->comm, ctx->stream));
     }
     RCCL_TRY(g_rccl.GroupEnd());
     return 0;

@@ -102,10 +102,15 @@ template <int EPT> struct CellCfg {
 // Phase B: LSD radix sort of the time indexes by the keys in LDS (valid keys lie in [kmin, kmin + range], NaN / padding
 // are 0xFFFFFFFF), then rank[t] = position of t.  Returns the sorted index array (one of the two u16 buffers; the other
 // one is free afterwards).  stop_after == 2: return before building rank[]; 3: rank[] goes into that other buffer
-// (written by the last stable pass).
+// (written by the last stable pass), with `nan_rank` (when >= 0) in place of the positions >= nvalid: the three-stream
+// kernel points NaN / padding steps at a scratch word of its bit-vectors and toggles without looking at nvalid.
+#ifndef XS_SORT_STOP
+#define XS_SORT_STOP 0  // (scripts/ubench/train3_bench.hip builds with 1..6 to time the sort's phases; the library never does)
+#endif
 template <int EPT>
 __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
-                                                              uint32_t kmin, uint32_t range, int stop_after, bool hist_zeroed = false)
+                                                              uint32_t kmin, uint32_t range, int stop_after, bool hist_zeroed = false,
+                                                              int nan_rank = -1)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
@@ -140,6 +145,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 atomicAdd(&hist[d >> 1], 1u << (16 * (d & 1)));
             }
             __syncthreads();
+            if constexpr (XS_SORT_STOP == 1) return idx1;
             {
                 constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
                 uint32_t wv[BPT / 2];
@@ -159,6 +165,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 }
             }
             __syncthreads();
+            if constexpr (XS_SORT_STOP == 2) return idx1;
 #pragma unroll
             for (int e = 0; e < EPT; e++) {
                 const uint32_t d = (e & 1) ? (dgp[e >> 1] >> 16) : (dgp[e >> 1] & 0xFFFFu);
@@ -168,6 +175,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             }
             __syncthreads();
         }
+        if constexpr (XS_SORT_STOP == 3) return idx1;
         int cur = 1;
         const int npass_rest = nbits > D1 ? (nbits - D1 + 3) / 4 : 0;
         for (int p = 0; p < npass_rest; p++) {
@@ -192,6 +200,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             cntlo[pi] = (uint32_t)cnt;
             cnthi[pi] = (uint32_t)(cnt >> 32);
             __syncthreads();
+            if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
             {   // transposed scan: thread j owns digit d = j>>6 of threads 16*chunk .. 16*chunk+15
                 const int d = tid >> 6, chunk = tid & 63;
                 const uint32_t *arrp = d < 8 ? cntlo : cnthi;
@@ -217,6 +226,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 }
             }
             __syncthreads();
+            if constexpr (XS_SORT_STOP == 5) { if (p == 0) return idx1; }
             {
                 const int pb = tid + 2 * (tid >> 4);
                 // stop_after == 3: the last pass also leaves rank[time step] in the buffer it read from (every thread took its
@@ -228,10 +238,11 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                     int d = (int)((dgs >> (4 * e)) & 15u);
                     int pos = (int)base[d * BS + pb] + (int)((lrs >> (4 * e)) & 15u);  // no read-modify-write chain
                     dst[pos] = ids[e];
-                    if (fuse_rank) rk[ids[e]] = (uint16_t)pos;
+                    if (fuse_rank) rk[ids[e]] = (uint16_t)((nan_rank >= 0 && pos >= nvalid) ? nan_rank : pos);
                 }
             }
             __syncthreads();
+            if constexpr (XS_SORT_STOP == 6) { if (p == 0) return idx1; }
             cur ^= 1;
         }
         const uint16_t *sorted = cur ? idx1 : idx0;
@@ -239,7 +250,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
         if (stop_after == 3) {
             if (npass_rest == 0) {  // narrow keys: no stable pass to ride on
                 uint16_t *rk = cur ? idx0 : idx1;
-                for (int r = tid; r < TPAD; r += NT) rk[sorted[r]] = (uint16_t)r;
+                for (int r = tid; r < TPAD; r += NT) rk[sorted[r]] = (uint16_t)((nan_rank >= 0 && r >= nvalid) ? nan_rank : r);
                 __syncthreads();
             }
             return sorted;
@@ -263,7 +274,8 @@ struct NoLoadHook {
 // to off_misc is still free (the DQM group sums use it, train_cell3.hpp); it must end on a block barrier if it touches LDS
 template <int EPT, typename Hook = NoLoadHook>
 __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
-                                                          uint32_t *red, int stop_after, int &nvalid_out, const Hook &hook = Hook())
+                                                          uint32_t *red, int stop_after, int &nvalid_out, const Hook &hook = Hook(),
+                                                          int nan_rank = -1)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
@@ -351,7 +363,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
 
         if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
         hook(keys, Ti, tid);
-        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch);
+        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank);
 }
 
 // Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has

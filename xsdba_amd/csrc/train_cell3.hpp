@@ -17,13 +17,68 @@ namespace xs {
 template <int EPT> struct CellCfg3 {
     using Base = CellCfg<EPT>;
     static constexpr int NT = 1024, TPAD = Base::TPAD, WPL = Base::WPL, NWAVE = Base::NWAVE;
-    static constexpr int VSTRIDE = ((TPAD / 32 + WPL - 1) / WPL) * WPL;  // words per vector: whole lanes
-    static constexpr int NLANE = VSTRIDE / WPL;                          // lanes that own words
+    static constexpr int NLANE = (TPAD / 32 + WPL - 1) / WPL;            // lanes that own words
+    static constexpr int VSTRIDE = NLANE * WPL + 4;                      // words per vector: whole lanes + two zero words (the
+                                                                         // select looks two words past the owner lane's own) +
+                                                                         // a scratch word (+ one for an even count)
+    static constexpr int NAN_RANK = (NLANE * WPL + 2) * 32;              // "rank" of NaN / padding steps: a bit of the scratch word
+    static_assert(NAN_RANK + 31 < 65536, "ranks are 16-bit");
+    static_assert(WPL % 2 == 0 && VSTRIDE % 2 == 0, "the vectors are read in 8-byte pieces");
     static constexpr size_t off_bits = Base::off_union;
     static constexpr size_t sel_end = off_bits + (size_t)3 * NWAVE * VSTRIDE * 4;
     static constexpr size_t off_misc = ((Base::sort_end > sel_end ? Base::sort_end : sel_end) + 15) & ~(size_t)15;
     static constexpr size_t lds_bytes = off_misc + 64 * 8;
 };
+
+// NW words (NW even) from an 8-byte aligned LDS address as ds_read_b64 + their wait, in ONE asm statement: left to itself the
+// compiler fuses neighbouring reads into ds_read2_b32 / ds_read2_b64, which take four times the LDS cycles of ds_read_b64 on
+// gfx950 (scripts/ubench/issue_rate.hip: 27 vs 6.8 cycles per wave-instruction at a lane stride of 24 bytes).
+template <int NW> __device__ __forceinline__ void lds_read_words64(const uint32_t *p, uint32_t (&w)[NW])
+{
+    static_assert(NW == 2 || NW == 4 || NW == 6 || NW == 8, "1 to 4 ds_read_b64");
+    const uint32_t a = (uint32_t)(uintptr_t)p;  // (an LDS pointer: the low half of the flat address is the LDS offset)
+    uint64_t v0, v1, v2, v3;
+    if constexpr (NW == 2) __asm__ volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0) : "v"(a) : "memory");
+    if constexpr (NW == 4) __asm__ volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a) : "memory");
+    if constexpr (NW == 6)
+        __asm__ volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a) : "memory");
+    if constexpr (NW == 8)
+        __asm__ volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+    w[0] = (uint32_t)v0; w[1] = (uint32_t)(v0 >> 32);
+    if constexpr (NW >= 4) { w[2] = (uint32_t)v1; w[3] = (uint32_t)(v1 >> 32); }
+    if constexpr (NW >= 6) { w[4] = (uint32_t)v2; w[5] = (uint32_t)(v2 >> 32); }
+    if constexpr (NW >= 8) { w[6] = (uint32_t)v3; w[7] = (uint32_t)(v3 >> 32); }
+}
+
+// the same words of three vectors `stride` bytes apart (the recount of the three streams): 3 * NW / 2 reads, one wait
+template <int NW, int STRIDE> __device__ __forceinline__ void lds_read_words64x3(const uint32_t *p, uint32_t (&wa)[NW], uint32_t (&wb)[NW], uint32_t (&wc)[NW])
+{
+    static_assert(NW == 2 || NW == 4 || NW == 6, "1 to 3 ds_read_b64 per vector");
+    const uint32_t a = (uint32_t)(uintptr_t)p;
+    uint64_t v[9];
+    if constexpr (NW == 2)
+        __asm__ volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:%c4\n\tds_read_b64 %2, %3 offset:%c5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[3]), "=&v"(v[6]) : "v"(a), "i"(STRIDE), "i"(2 * STRIDE) : "memory");
+    if constexpr (NW == 4)
+        __asm__ volatile("ds_read_b64 %0, %6\n\tds_read_b64 %1, %6 offset:8\n\tds_read_b64 %2, %6 offset:%c7\n\tds_read_b64 %3, %6 offset:%c8\n\t"
+                         "ds_read_b64 %4, %6 offset:%c9\n\tds_read_b64 %5, %6 offset:%c10\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(a), "i"(STRIDE), "i"(STRIDE + 8), "i"(2 * STRIDE), "i"(2 * STRIDE + 8) : "memory");
+    if constexpr (NW == 6)
+        __asm__ volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\t"
+                         "ds_read_b64 %3, %9 offset:%c10\n\tds_read_b64 %4, %9 offset:%c11\n\tds_read_b64 %5, %9 offset:%c12\n\t"
+                         "ds_read_b64 %6, %9 offset:%c13\n\tds_read_b64 %7, %9 offset:%c14\n\tds_read_b64 %8, %9 offset:%c15\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8])
+                         : "v"(a), "i"(STRIDE), "i"(STRIDE + 8), "i"(STRIDE + 16), "i"(2 * STRIDE), "i"(2 * STRIDE + 8), "i"(2 * STRIDE + 16) : "memory");
+#pragma unroll
+    for (int i = 0; i < NW / 2; i++) {
+        wa[2 * i] = (uint32_t)v[i]; wa[2 * i + 1] = (uint32_t)(v[i] >> 32);
+        wb[2 * i] = (uint32_t)v[3 + i]; wb[2 * i + 1] = (uint32_t)(v[3 + i] >> 32);
+        wc[2 * i] = (uint32_t)v[6 + i]; wc[2 * i + 1] = (uint32_t)(v[6 + i] >> 32);
+    }
+}
 
 // inclusive wave64 prefix sum of a double on the DPP cross-lane path (the steps of wave_incl_scan on both halves of the value)
 __device__ __forceinline__ double wave_incl_scan_f64(double v)
@@ -175,18 +230,24 @@ template <int EPT> struct GroupSumHook {
 // order statistics, scaling — with the guards of cell_group_quantiles (train_cell.hpp).
 // Vals: where the values come from (LdsVals: float32 keys in LDS; GlobalF64Vals: the float64 series in global memory).
 // PRESUM (DQM): the group sums were formed by GroupSumHook (`gsum` [G], `guard` in LDS) instead of running sums kept by the toggles.
-template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false>
+// STOP (diagnostic instantiations of scripts/ubench/train3_bench.hip only; the library builds STOP = 0): leave after
+// 3 = the build of the middle group + copies + fast-forward, 4 = run the loop with toggles / recount / scan but no select.
+// PADT: `tog64` is the table padded with time step n_time instead of -1 (float32 kernel, n_time < TPAD) and rank[] holds NAN_RANK
+// for NaN / padding steps.
+template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false>
 __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
                                                       const typename Vals::value_type *__restrict__ q, int Q, int kind, int mode,
                                                       int arr, int64_t c, typename Vals::value_type *__restrict__ af,
                                                       typename Vals::value_type *out_hq, typename Vals::value_type *scaling,
-                                                      bool &flag_cell, const double *gsum = nullptr, const double *guard = nullptr)
+                                                      bool &flag_cell, const double *gsum = nullptr, const double *guard = nullptr,
+                                                      int n_time = 0)
 {
     using R = typename Vals::value_type;
     using Cfg = CellCfg3<EPT>;
     constexpr int TPAD = Cfg::TPAD, WPL = Cfg::WPL, VS = Cfg::VSTRIDE, NL = Cfg::NLANE, QL = 21;
+    wid = __builtin_amdgcn_readfirstlane(wid);  // (wave-uniform, and known to be: the group ranges below live in scalar registers)
     const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
     const int r0 = min(G, wid * gpw), r1 = min(G, r0 + gpw), n = r1 - r0;
     if (n <= 0) return;
@@ -230,37 +291,83 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         // where every wave of the block waits at the same time
         for (int i0 = 0; i0 < len; i0 += 1024) {
             int ts[16];
+            if constexpr (PADT) {
+                // all the row entries, then all their ranks, then all the flips in flight; the lanes past the end of the row sit
+                // out (masked off: as flips of the scratch word they would all hit one address and be serialised)
 #pragma unroll
-            for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+                for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; ts[u] = l[min(i, len - 1)]; }
+                int rs[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) flip(bA, ts[u], dlocA);
+                for (int u = 0; u < 16; u++) rs[u] = (int)rank[ts[u]];
+#pragma unroll
+                for (int u = 0; u < 16; u++)
+                    if (i0 + 64 * u + lane < len)
+                        (void)__hip_atomic_fetch_xor(&bA[rs[u] >> 5], 1u << (rs[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; ts[u] = i < len ? l[i] : -1; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) flip(bA, ts[u], dlocA);
+            }
         }
         lds_wave_fence();
         for (int i = lane; i < VS; i += 64) { const uint32_t w = bA[i]; bB[i] = w; bC[i] = w; }
         lds_wave_fence();
     }
-    // ---- C fast-forwards to group gc3 (lists gb+1 .. gc3), four lists in flight
+    // ---- C fast-forwards to group gc3 (lists gb+1 .. gc3)
     if (nC > 0) {
-        for (int s0 = 1; s0 <= nA; s0 += 4) {
-            int ts[4];
+        if constexpr (PADT) {
+            // eight lists in flight (XOR commutes); rows past the last list read row 0, the table's all-padding row
+            for (int s0 = 1; s0 <= nA; s0 += 8) {
+                int ts[8], rs[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) ts[u] = s0 + u <= nA ? tog64[(size_t)(gb + s0 + u) * 64 + lane] : -1;
+                for (int u = 0; u < 8; u++) ts[u] = tog64[(size_t)(s0 + u <= nA ? gb + s0 + u : 0) * 64 + lane];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { flip(bC, ts[u], dlocC); if (DQM && !PRESUM) lds_wave_fence(); }  // (running sums read the old bit: one list at a time)
+                for (int u = 0; u < 8; u++) rs[u] = (int)rank[ts[u]];
+#pragma unroll
+                for (int u = 0; u < 8; u++) (void)__hip_atomic_fetch_xor(&bC[rs[u] >> 5], 1u << (rs[u] & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             lds_wave_fence();
+        } else {
+            for (int s0 = 1; s0 <= nA; s0 += 4) {
+                int ts[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) ts[u] = s0 + u <= nA ? tog64[(size_t)(gb + s0 + u) * 64 + lane] : -1;
+#pragma unroll
+                for (int u = 0; u < 4; u++) { flip(bC, ts[u], dlocC); if (DQM && !PRESUM) lds_wave_fence(); }  // (running sums read the old bit: one list at a time)
+                lds_wave_fence();
+            }
         }
     }
-    // ---- lock-step walk; the next lists are prefetched under the select
-    int preA = -1, preB = -1, preC = -1;
-    if (nA > 1) preA = tog64[(size_t)(gb + 1) * 64 + lane];
+    if constexpr (STOP == 3) { if (bC[lane] == 0x12345u) out_hq[0] = (R)1; return; }
+    // ---- lock-step walk; the next lists are prefetched under the select.  Row 0 of the table is all -1 (list r sits in row r,
+    // there is no list 0): a stream with nothing to toggle reads that row, so that the loads need no branches
+    const int nolist = PADT ? n_time : -1;  // an entry that is no toggle
+    int preA = nolist, preB = nolist, preC = nolist;  // A and C stand on their first group: only B starts with a step (gb -> gb - 1)
     if (nB > 0) preB = tog64[(size_t)gb * 64 + lane];
-    if (nC > 1) preC = tog64[(size_t)(gc3 + 1) * 64 + lane];
     int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case = 3, c_lo = 0;
     R c_gamma = (R)0;
-    for (int it = 0; it < nA; it++) {
+    // this cell's tables (the offsets inside them fit 32 bits: G * Q entries)
+    R *const hq_c = out_hq + (size_t)c * G * (size_t)Q, *const af_c = af + (mode == 0 ? (size_t)0 : (size_t)c * G * (size_t)Q);
+    const bool ref_pass = mode != 0 && arr != 0;
+    // per-lane walk state: the group of this lane's stream moves by gdir per step, its output slot by gdir * Q
+    const int gdir = sid == 1 ? -1 : 1, odir = gdir * Q;
+    const int nlim = sid == 0 ? nA : (sid == 1 ? nB : (sid == 2 ? nC : 0));  // steps in which this lane's stream has a group
+    int g = sid == 0 ? gb : (sid == 1 ? gb - 1 : gc3);
+    int o = g * Q + k;
+    const int fsh = (P10 ? 10 : 16) * (sid < 3 ? sid : 0);  // where this stream's field sits in the packed counts
+    int Lprev4 = -1;  // (owner lane of the previous step) * 4, the bpermute address
+    for (int it = 0; it < nA; it++, g += gdir, o += odir) {
         const bool vB = it < nB, vC = it < nC;
-        const int tA = it > 0 ? preA : -1, tB = vB ? preB : -1, tC = (it > 0 && vC) ? preC : -1;
-        if constexpr (!DQM || PRESUM) {
+        const int tA = preA, tB = preB, tC = preC;
+        if constexpr (PADT) {
+            // nothing to decide: the table's padding is time step T (a padding step of the series: T < TPAD), and the sort gave
+            // every NaN / padding step the "rank" NAN_RANK, a bit of the scratch word behind the vector
+            const int rA = (int)rank[tA], rB = (int)rank[tB], rC = (int)rank[tC];
+            (void)__hip_atomic_fetch_xor(&bA[rA >> 5], 1u << (rA & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_xor(&bB[rB >> 5], 1u << (rB & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void)__hip_atomic_fetch_xor(&bC[rC >> 5], 1u << (rC & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if constexpr (!DQM || PRESUM) {
             // branch-free: the three rank reads are in flight together, an entry that is no toggle (padding of the table, a NaN
             // step) XORs a zero mask into a word of its vector
             const int rA = (int)rank[max(tA, 0)], rB = (int)rank[max(tB, 0)], rC = (int)rank[max(tC, 0)];
@@ -274,33 +381,41 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             flip(bB, tB, dlocB);
             flip(bC, tC, dlocC);
         }
-        if (it + 1 < nA) preA = tog64[(size_t)(gb + it + 1) * 64 + lane];
-        if (it + 1 < nB) preB = tog64[(size_t)(gb - it - 1) * 64 + lane];
-        if (it + 1 < nC) preC = tog64[(size_t)(gc3 + it + 1) * 64 + lane];
+        {   // the lists of the next step (wave-uniform rows: scalar address arithmetic, three plain loads)
+            const int rowA = it + 1 < nA ? gb + it + 1 : 0, rowB = it + 1 < nB ? gb - it - 1 : 0, rowC = it + 1 < nC ? gc3 + it + 1 : 0;
+            preA = tog64[(size_t)rowA * 64 + lane];
+            preB = tog64[(size_t)rowB * 64 + lane];
+            preC = tog64[(size_t)rowC * 64 + lane];
+        }
         lds_wave_fence();
         // per-lane member counts: A | B packed in one register, C in another; two prefix scans
         constexpr int FB = P10 ? 10 : 16;            // field width of A and B
         constexpr int FM = (1 << FB) - 1;
         int clAB = 0, clC = 0;
         if (lane < NL) {
+            // the lane's own words of the three vectors: WPL / 2 8-byte reads each, free of bank conflicts at a lane stride of
+            // WPL * 4 bytes (ds_read_b64 spreads over 64 banks)
+            uint32_t wa[WPL], wb[WPL], wc[WPL];
+            lds_read_words64x3<WPL, VS * 4>(bA + lane * WPL, wa, wb, wc);
+            int ca = 0, cb = 0, cc = 0;
 #pragma unroll
-            for (int j = 0; j < WPL; j++) {
-                clAB += __popc(bA[lane * WPL + j]) + (__popc(bB[lane * WPL + j]) << FB);
-                if (P10) clAB += __popc(bC[lane * WPL + j]) << 20;
-                else clC += __popc(bC[lane * WPL + j]);
-            }
+            for (int j = 0; j < WPL; j++) { ca += __popc(wa[j]); cb += __popc(wb[j]); cc += __popc(wc[j]); }
+            clAB = ca | (cb << FB);
+            if (P10) clAB |= cc << 20;
+            else clC = cc;
         }
         const int inAB = wave_incl_scan(clAB), inC = P10 ? 0 : wave_incl_scan(clC);
         const int exAB = inAB - clAB, exC = inC - clC;
         const int totAB = __builtin_amdgcn_readlane(inAB, 63);
         const int cntA = totAB & FM, cntB = (totAB >> FB) & FM;
         const int cntC = P10 ? ((totAB >> 20) & FM) : __builtin_amdgcn_readlane(inC, 63);
-        const unsigned long long balA = __ballot((clAB & FM) != 0), balB = __ballot(((clAB >> FB) & FM) != 0),
-                                 balC = __ballot(P10 ? ((clAB >> 20) & FM) != 0 : clC != 0);
-        const int ns = sid == 0 ? cntA : (sid == 1 ? cntB : cntC);
-        const int g = sid == 0 ? gb + it : (sid == 1 ? gb - 1 - it : gc3 + it);
-        const bool vs = sid == 0 || (sid == 1 && vB) || (sid == 2 && vC);
+        if constexpr (STOP == 4) { if (cntA + exAB + cntB + cntC == 0x7FFFFFF1) out_hq[0] = (R)1; continue; }
+        const int ns = P10 ? (int)__builtin_amdgcn_ubfe((unsigned)totAB, (unsigned)fsh, 10u) : (sid == 0 ? cntA : (sid == 1 ? cntB : cntC));
+        const bool vs = it < nlim;
         const bool act = vs && k < Q;
+        // the ref pass forms af against the hist quantile written by the first pass: requested here, consumed after the select
+        R hq_prev = (R)0;
+        if (ref_pass && act) hq_prev = hq_c[o];
         R mu = (R)0, inv = (R)0;
         if (DQM && PRESUM) {
             const double gs = gsum[vs && sid < 3 ? g : 0];
@@ -355,27 +470,46 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             c_case = casek; c_lo = lo; c_gamma = gamma;
         }
         nA_prev = cntA; nB_prev = cntB; nC_prev = cntC;
-        // owner lane of member `lo`: the last lane whose exclusive count is <= lo (branch-free bisection; every step reads
-        // both scan registers of the candidate lane and keeps this stream's field)
+        // owner lane of member `lo`: the last lane whose exclusive count is <= lo.  Consecutive groups share 900 of 930 members, so
+        // the owner is nearly always the previous step's lane or a neighbour: four exclusive counts around it are fetched
+        // together (ONE cross-lane latency instead of six dependent ones); a wave in which some lane's owner moved further
+        // (or the first step) runs the bisection.  Lanes NL .. 63 own no words: their exclusive count is the stream's total,
+        // above every `lo`, which ends both searches inside the vector.
+        auto field = [&](int eab, int ec) {
+            if (P10) return (int)__builtin_amdgcn_ubfe((unsigned)eab, (unsigned)fsh, 10u);
+            return sid == 0 ? (eab & 0xFFFF) : (sid == 1 ? (int)((unsigned)eab >> 16) : ec);
+        };
         int L4 = 0, eL = 0;
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const int cand4 = L4 + 4 * s;
-            const int eab = __builtin_amdgcn_ds_bpermute(cand4, exAB);
-            int e;
-            if (P10) e = (eab >> (10 * (sid < 3 ? sid : 0))) & FM;
-            else { const int ec = __builtin_amdgcn_ds_bpermute(cand4, exC); e = sid == 0 ? (eab & 0xFFFF) : (sid == 1 ? (int)((unsigned)eab >> 16) : ec); }
-            const bool ok = e <= lo;
-            L4 = ok ? cand4 : L4;
-            eL = ok ? e : eL;
+        bool miss = true;
+        if (Lprev4 >= 0) {  // (wave-uniform: -1 only in the first step)
+            const int a0 = Lprev4 - 4;  // lanes Lprev - 1 .. Lprev + 2 (the address wraps for Lprev == 0: that count is never used)
+            const int e_m = field(__builtin_amdgcn_ds_bpermute(a0, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0, exC));
+            const int e_0 = field(__builtin_amdgcn_ds_bpermute(a0 + 4, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 4, exC));
+            const int e_1 = field(__builtin_amdgcn_ds_bpermute(a0 + 8, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 8, exC));
+            const int e_2 = field(__builtin_amdgcn_ds_bpermute(a0 + 12, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 12, exC));
+            const bool dn = e_0 > lo, st = e_1 > lo;  // the owner is below Lprev / not above it
+            L4 = dn ? a0 : (st ? Lprev4 : Lprev4 + 4);
+            eL = dn ? e_m : (st ? e_0 : e_1);
+            miss = dn ? (e_m > lo || Lprev4 == 0) : (!st && e_2 <= lo);
         }
-        int L = L4 >> 2;
-        L = min(L, NL - 1);  // (empty streams / idle lanes: stay inside the vector)
-        int rem = lo - eL;
-        const uint32_t *wp = bits_s + L * WPL;
-        uint32_t wv[WPL];
+        if (__any(miss)) {
+            L4 = 0; eL = 0;
 #pragma unroll
-        for (int i = 0; i < WPL; i++) wv[i] = wp[i];
+            for (int s = 32; s > 0; s >>= 1) {
+                const int cand4 = L4 + 4 * s;
+                const int e = field(__builtin_amdgcn_ds_bpermute(cand4, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(cand4, exC));
+                const bool ok = e <= lo;
+                L4 = ok ? cand4 : L4;
+                eL = ok ? e : eL;
+            }
+        }
+        L4 = min(L4, 4 * (NL - 1));  // (empty streams / idle lanes: stay inside the vector)
+        Lprev4 = L4;
+        const int L = L4 >> 2;
+        int rem = lo - eL;
+        // the owner lane's words + the two behind them (the next member is nearly always there: one set bit per ~12 places)
+        uint32_t wv[WPL + 2];
+        lds_read_words64<WPL + 2>(bits_s + L * WPL, wv);
         bool ge[WPL];
         int run = 0, sub = 0, wi = 0;
         uint32_t w = wv[0];
@@ -391,8 +525,8 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         int nw = 0;
         uint32_t nwv = 0u;
 #pragma unroll
-        for (int i = WPL - 1; i >= 1; i--) {
-            const bool cnd = wv[i] != 0u && !ge[i - 1];
+        for (int i = WPL + 1; i >= 1; i--) {
+            const bool cnd = wv[i] != 0u && (i >= WPL || !ge[i < WPL ? i - 1 : 0]);  // a non-empty word behind word wi
             nw = cnd ? i : nw;
             nwv = cnd ? wv[i] : nwv;
         }
@@ -414,6 +548,12 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         int hrank = inword ? lrank + __ffs((int)rest) : wbase + nw * 32 + __ffs((int)nwv) - 1;
         const bool need_slow = casek == 0 && !found && sid < 3;
         if (__any(need_slow)) {
+            // (rare: no member in the 64 places behind the owner lane's words) the first member of the next lane that holds any:
+            // that lane from the ballot of the non-empty lanes of this stream, its first set bit from its words
+            const int mine = P10 ? (clAB >> (10 * (sid < 3 ? sid : 0))) & FM : (sid == 0 ? (clAB & 0xFFFF) : (sid == 1 ? (int)((unsigned)clAB >> 16) : clC));
+            const unsigned long long balA = __ballot((clAB & FM) != 0), balB = __ballot(((clAB >> FB) & FM) != 0),
+                                     balC = __ballot(P10 ? ((clAB >> 20) & FM) != 0 : clC != 0);
+            (void)mine;
             const unsigned long long bal = sid == 0 ? balA : (sid == 1 ? balB : balC);
             const unsigned long long restm = L < 63 ? (bal >> (L + 1)) : 0ull;
             const int L2 = min(restm ? L + __ffsll(restm) : L, NL - 1);
@@ -440,9 +580,8 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             if (res != res && act) flag_cell = true;  // inf - inf: the generic kernel redoes the cell
         }
         if (act) {
-            const size_t o = ((size_t)c * G + g) * (size_t)Q + k;
-            if (mode == 0 || arr == 0) out_hq[o] = res;
-            else af[o] = get_corr<R>(out_hq[o], res, kind);
+            if (!ref_pass) hq_c[o] = res;
+            else af_c[o] = get_corr<R>(hq_prev, res, kind);
         }
         if (DQM && vs && sid < 3 && k == 0) {
             if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced by the factor in the ref pass
@@ -451,12 +590,12 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     }
 }
 
-template <int EPT, bool P10, bool DQM>
+template <int EPT, bool P10, bool DQM, int STOP = 0>
 __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc,
                                                        const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, int G,
                                                        const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af,
                                                        float *out_hq, float *scaling, int *__restrict__ flag_count,
-                                                       int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64,
+                                                       int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64 /* padded with n_time, n_time < TPAD */,
                                                        const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx, const int *__restrict__ mem_t16, int W)
 {
     using Cfg = CellCfg<EPT>;
@@ -479,12 +618,15 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             int nvalid;
             const uint16_t *sorted;  // (no rank[] in the union region)
             // (stop_after 3: rank[] is written by the sort's last pass into the buffer that pass read from)
-            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W});
-            else sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid);
+            // (NaN / padding steps get the rank NAN_RANK: a bit of the scratch word behind every bit-vector)
+            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W}, Cfg3::NAN_RANK);
+            else sorted = cell_load_sort<EPT>(x, T, smem, red, STOP == 1 ? 1 : 3, nvalid, NoLoadHook(), Cfg3::NAN_RANK);
+            if constexpr (STOP == 1) continue;  // (diagnostic: the load alone)
+            if constexpr (STOP == 2) { if (tid == 0 && sorted[nvalid / 2] == 0xFFFF) out_hq[0] = 1.f; __syncthreads(); continue; }  // (load + sort)
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             const LdsVals vals{keys, sorted, TPAD};
-            cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
-                                                               kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G);
+            cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM, STOP, true>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
+                                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
