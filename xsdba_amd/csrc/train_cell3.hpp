@@ -27,7 +27,8 @@ template <int EPT> struct CellCfg3 {
     static constexpr size_t off_bits = Base::off_union;
     static constexpr size_t sel_end = off_bits + (size_t)3 * NWAVE * VSTRIDE * 4;
     static constexpr size_t off_misc = ((Base::sort_end > sel_end ? Base::sort_end : sel_end) + 15) & ~(size_t)15;
-    static constexpr size_t lds_bytes = off_misc + 64 * 8;
+    static constexpr size_t off_lut = off_misc + 64 * 8;   // [256] select-in-a-byte table (byte_select_lut)
+    static constexpr size_t lds_bytes = off_lut + 256 * 4;
 };
 
 // NW words (NW even) from an 8-byte aligned LDS address as ds_read_b64 + their wait, in ONE asm statement: left to itself the
@@ -77,6 +78,21 @@ template <int NW, int STRIDE> __device__ __forceinline__ void lds_read_words64x3
         wa[2 * i] = (uint32_t)v[i]; wa[2 * i + 1] = (uint32_t)(v[i] >> 32);
         wb[2 * i] = (uint32_t)v[3 + i]; wb[2 * i + 1] = (uint32_t)(v[3 + i] >> 32);
         wc[2 * i] = (uint32_t)v[6 + i]; wc[2 * i + 1] = (uint32_t)(v[6 + i] >> 32);
+    }
+}
+
+// Select inside a byte: entry b holds, three bits each, the places of the set bits of b in ascending order (the place of its
+// j-th set bit is (lut[b] >> 3 j) & 7).  Built once per block; replaces the last three levels of the in-word bisection (21
+// dependent vector instructions) by one LDS read and four instructions.
+__device__ __forceinline__ void byte_select_lut(uint32_t *lut, int tid)
+{
+    if (tid < 256) {
+        uint32_t t = 0u;
+        int j = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++)
+            if ((tid >> b) & 1) { t |= (uint32_t)b << (3 * j); j++; }
+        lut[tid] = t;
     }
 }
 
@@ -242,7 +258,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
                                                       int arr, int64_t c, typename Vals::value_type *__restrict__ af,
                                                       typename Vals::value_type *out_hq, typename Vals::value_type *scaling,
                                                       bool &flag_cell, const double *gsum = nullptr, const double *guard = nullptr,
-                                                      int n_time = 0)
+                                                      int n_time = 0, const uint32_t *lut = nullptr)
 {
     using R = typename Vals::value_type;
     using Cfg = CellCfg3<EPT>;
@@ -345,6 +361,13 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     const int nolist = PADT ? n_time : -1;  // an entry that is no toggle
     int preA = nolist, preB = nolist, preC = nolist;  // A and C stand on their first group: only B starts with a step (gb -> gb - 1)
     if (nB > 0) preB = tog64[(size_t)gb * 64 + lane];
+    if constexpr (PADT) {
+        // step 0's flips (B only) now, then the lists of step 1
+        if (nB > 0) { const int r = (int)rank[preB]; (void)__hip_atomic_fetch_xor(&bB[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        preA = tog64[(size_t)(1 < nA ? gb + 1 : 0) * 64 + lane];
+        preB = tog64[(size_t)(1 < nB ? gb - 1 : 0) * 64 + lane];
+        preC = tog64[(size_t)(1 < nC ? gc3 + 1 : 0) * 64 + lane];
+    }
     int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case = 3, c_lo = 0;
     R c_gamma = (R)0;
     // this cell's tables (the offsets inside them fit 32 bits: G * Q entries)
@@ -361,12 +384,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         const bool vB = it < nB, vC = it < nC;
         const int tA = preA, tB = preB, tC = preC;
         if constexpr (PADT) {
-            // nothing to decide: the table's padding is time step T (a padding step of the series: T < TPAD), and the sort gave
-            // every NaN / padding step the "rank" NAN_RANK, a bit of the scratch word behind the vector
-            const int rA = (int)rank[tA], rB = (int)rank[tB], rC = (int)rank[tC];
-            (void)__hip_atomic_fetch_xor(&bA[rA >> 5], 1u << (rA & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            (void)__hip_atomic_fetch_xor(&bB[rB >> 5], 1u << (rB & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            (void)__hip_atomic_fetch_xor(&bC[rC >> 5], 1u << (rC & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // (the flips of this step were issued in the middle of the previous one — before the loop for step 0 — see below)
         } else if constexpr (!DQM || PRESUM) {
             // branch-free: the three rank reads are in flight together, an entry that is no toggle (padding of the table, a NaN
             // step) XORs a zero mask into a word of its vector
@@ -381,12 +399,31 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             flip(bB, tB, dlocB);
             flip(bC, tC, dlocC);
         }
-        {   // the lists of the next step (wave-uniform rows: scalar address arithmetic, three plain loads)
+        int rnA = 0, rnB = 0, rnC = 0;  // PADT: ranks of the next step's flips
+        if constexpr (PADT) {
+            // the lists of step it + 1 (requested a step ago) -> the ranks of its flips, which are issued further down, as soon
+            // as this step has read the vectors for the last time: their LDS latency is then covered by the rest of the step
+            // instead of standing in front of the recount.  The lists of step it + 2 are requested in their place.
+            rnA = (int)rank[preA]; rnB = (int)rank[preB]; rnC = (int)rank[preC];
+            const int rowA = it + 2 < nA ? gb + it + 2 : 0, rowB = it + 2 < nB ? gb - it - 2 : 0, rowC = it + 2 < nC ? gc3 + it + 2 : 0;
+            preA = tog64[(size_t)rowA * 64 + lane];
+            preB = tog64[(size_t)rowB * 64 + lane];
+            preC = tog64[(size_t)rowC * 64 + lane];
+        } else {   // the lists of the next step (wave-uniform rows: scalar address arithmetic, three plain loads)
             const int rowA = it + 1 < nA ? gb + it + 1 : 0, rowB = it + 1 < nB ? gb - it - 1 : 0, rowC = it + 1 < nC ? gc3 + it + 1 : 0;
             preA = tog64[(size_t)rowA * 64 + lane];
             preB = tog64[(size_t)rowB * 64 + lane];
             preC = tog64[(size_t)rowC * 64 + lane];
         }
+        // PADT: the flips of the next step (a stream without a next group would flip the padding step's scratch word 64 times
+        // over: skipped, wave-uniformly)
+        auto next_flips = [&]() {
+            if constexpr (PADT) {
+                if (it + 1 < nA) (void)__hip_atomic_fetch_xor(&bA[rnA >> 5], 1u << (rnA & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (it + 1 < nB) (void)__hip_atomic_fetch_xor(&bB[rnB >> 5], 1u << (rnB & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (it + 1 < nC) (void)__hip_atomic_fetch_xor(&bC[rnC >> 5], 1u << (rnC & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        };
         lds_wave_fence();
         // per-lane member counts: A | B packed in one register, C in another; two prefix scans
         constexpr int FB = P10 ? 10 : 16;            // field width of A and B
@@ -409,7 +446,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         const int totAB = __builtin_amdgcn_readlane(inAB, 63);
         const int cntA = totAB & FM, cntB = (totAB >> FB) & FM;
         const int cntC = P10 ? ((totAB >> 20) & FM) : __builtin_amdgcn_readlane(inC, 63);
-        if constexpr (STOP == 4) { if (cntA + exAB + cntB + cntC == 0x7FFFFFF1) out_hq[0] = (R)1; continue; }
+        if constexpr (STOP == 4) { if (cntA + exAB + cntB + cntC == 0x7FFFFFF1) out_hq[0] = (R)1; next_flips(); continue; }
         const int ns = P10 ? (int)__builtin_amdgcn_ubfe((unsigned)totAB, (unsigned)fsh, 10u) : (sid == 0 ? cntA : (sid == 1 ? cntB : cntC));
         const bool vs = it < nlim;
         const bool act = vs && k < Q;
@@ -510,65 +547,90 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         // the owner lane's words + the two behind them (the next member is nearly always there: one set bit per ~12 places)
         uint32_t wv[WPL + 2];
         lds_read_words64<WPL + 2>(bits_s + L * WPL, wv);
-        bool ge[WPL];
+        // the word holding member `rem` of these words, and the two words behind it
         int run = 0, sub = 0, wi = 0;
-        uint32_t w = wv[0];
+        uint32_t w = wv[0], n1 = wv[1], n2 = wv[2];
 #pragma unroll
         for (int i = 0; i < WPL - 1; i++) {
             run += __popc(wv[i]);
-            ge[i] = rem >= run;
-            w = ge[i] ? wv[i + 1] : w;
-            sub = ge[i] ? run : sub;
-            wi = ge[i] ? i + 1 : wi;
+            const bool ge = rem >= run;
+            w = ge ? wv[i + 1] : w;
+            n1 = ge ? wv[i + 2] : n1;
+            n2 = ge ? wv[i + 3] : n2;
+            sub = ge ? run : sub;
+            wi = ge ? i + 1 : wi;
         }
         rem -= sub;
-        int nw = 0;
-        uint32_t nwv = 0u;
-#pragma unroll
-        for (int i = WPL + 1; i >= 1; i--) {
-            const bool cnd = wv[i] != 0u && (i >= WPL || !ge[i < WPL ? i - 1 : 0]);  // a non-empty word behind word wi
-            nw = cnd ? i : nw;
-            nwv = cnd ? wv[i] : nwv;
-        }
         const uint32_t wsel = w;
         int pos = 0;
+        if (lut) {
+            // the half, the byte, then the byte's table
 #pragma unroll
-        for (int s = 16; s > 0; s >>= 1) {
-            const int cw = __popc(w & ((1u << s) - 1u));
-            const bool g2 = rem >= cw;
-            rem -= g2 ? cw : 0;
-            w = g2 ? (w >> s) : w;
-            pos += g2 ? s : 0;
+            for (int s = 16; s > 4; s >>= 1) {
+                const int cw = __popc(w & ((1u << s) - 1u));
+                const bool g2 = rem >= cw;
+                rem -= g2 ? cw : 0;
+                w = g2 ? (w >> s) : w;
+                pos += g2 ? s : 0;
+            }
+            pos += (int)((lut[w & 0xFFu] >> (3 * rem)) & 7u);
+        } else {
+#pragma unroll
+            for (int s = 16; s > 0; s >>= 1) {
+                const int cw = __popc(w & ((1u << s) - 1u));
+                const bool g2 = rem >= cw;
+                rem -= g2 ? cw : 0;
+                w = g2 ? (w >> s) : w;
+                pos += g2 ? s : 0;
+            }
         }
-        const int wbase = L * WPL * 32;
-        const int lrank = wbase + wi * 32 + pos;
+        const int wbase = L * WPL * 32 + wi * 32;  // place of bit 0 of the word
+        const int lrank = wbase + pos;
+        // the next member: above `pos` in the same word, else the first one of the two words behind (a gap of 65+ places has a
+        // chance of ~1e-3 per lane at one member per 12 places: the wave-uniform branch below is rarely taken)
         const uint32_t rest = (wsel >> pos) >> 1;
-        const bool inword = rest != 0u;
-        const bool found = inword || nw != 0;
-        int hrank = inword ? lrank + __ffs((int)rest) : wbase + nw * 32 + __ffs((int)nwv) - 1;
+        int hrank = rest ? lrank + __ffs((int)rest) : (n1 ? wbase + 31 + __ffs((int)n1) : wbase + 63 + __ffs((int)n2));
+        const bool found = (rest | n1 | n2) != 0u;
         const bool need_slow = casek == 0 && !found && sid < 3;
         if (__any(need_slow)) {
-            // (rare: no member in the 64 places behind the owner lane's words) the first member of the next lane that holds any:
-            // that lane from the ballot of the non-empty lanes of this stream, its first set bit from its words
-            const int mine = P10 ? (clAB >> (10 * (sid < 3 ? sid : 0))) & FM : (sid == 0 ? (clAB & 0xFFFF) : (sid == 1 ? (int)((unsigned)clAB >> 16) : clC));
-            const unsigned long long balA = __ballot((clAB & FM) != 0), balB = __ballot(((clAB >> FB) & FM) != 0),
-                                     balC = __ballot(P10 ? ((clAB >> 20) & FM) != 0 : clC != 0);
-            (void)mine;
-            const unsigned long long bal = sid == 0 ? balA : (sid == 1 ? balB : balC);
-            const unsigned long long restm = L < 63 ? (bal >> (L + 1)) : 0ull;
-            const int L2 = min(restm ? L + __ffsll(restm) : L, NL - 1);
-            const uint32_t *wp2 = bits_s + L2 * WPL;
-            uint32_t w2[WPL];
+            // first the rest of the words read above, ...
+            int nw = 0;
+            uint32_t nwv = 0u;
 #pragma unroll
-            for (int i = 0; i < WPL; i++) w2[i] = wp2[i];
-            int hr2 = 0;
+            for (int i = WPL + 1; i >= 3; i--) {
+                const bool cnd = wv[i] != 0u && i > wi + 2;
+                nw = cnd ? i : nw;
+                nwv = cnd ? wv[i] : nwv;
+            }
+            int hr = L * WPL * 32 + nw * 32 + __ffs((int)nwv) - 1;
+            const bool still = need_slow && nw == 0;
+            if (__any(still)) {
+                // ... then the first member of the next lane that holds any: that lane from the ballot of the non-empty lanes of
+                // this stream, its first set bit from its words
+                const unsigned long long balA = __ballot((clAB & FM) != 0), balB = __ballot(((clAB >> FB) & FM) != 0),
+                                         balC = __ballot(P10 ? ((clAB >> 20) & FM) != 0 : clC != 0);
+                const unsigned long long bal = sid == 0 ? balA : (sid == 1 ? balB : balC);
+                const unsigned long long restm = L < 63 ? (bal >> (L + 1)) : 0ull;
+                const int L2 = min(restm ? L + __ffsll(restm) : L, NL - 1);
+                const uint32_t *wp2 = bits_s + L2 * WPL;
+                uint32_t w2[WPL];
 #pragma unroll
-            for (int i = WPL - 1; i >= 0; i--) hr2 = w2[i] != 0u ? i * 32 + __ffs((int)w2[i]) - 1 : hr2;
-            if (need_slow) hrank = L2 * WPL * 32 + hr2;
+                for (int i = 0; i < WPL; i++) w2[i] = wp2[i];
+                int hr2 = 0;
+#pragma unroll
+                for (int i = WPL - 1; i >= 0; i--) hr2 = w2[i] != 0u ? i * 32 + __ffs((int)w2[i]) - 1 : hr2;
+                if (still) hr = L2 * WPL * 32 + hr2;
+            }
+            if (need_slow) hrank = hr;
         }
+        next_flips();  // the vectors have been read for the last time in this step
         const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
         R v, vhi;
+#if defined(XS_EXP_NOVAL)
+        v = (R)rs0; vhi = (R)rs1;
+#else
         vals.at_ranks(rs0, rs1, v, vhi);
+#endif
         if (DQM) { v = apply_corr<R>(v, inv, kind); vhi = apply_corr<R>(vhi, inv, kind); }
         R res;
         if (casek == 3) res = nan_of<R>();
@@ -608,6 +670,8 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + Cfg3::off_misc);
     double *gsum = reinterpret_cast<double *>(smem + Cfg3::lds_bytes);  // DQM: [G] group sums + [1] guard (the launch adds (G + 1) * 8 bytes)
     const int tid = threadIdx.x, wid = tid >> 6;
+    uint32_t *lut = reinterpret_cast<uint32_t *>(smem + Cfg3::off_lut);
+    byte_select_lut(lut, tid);  // (the first barrier of the first load phase comes before any use)
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const int npass_arr = mode == 0 ? 1 : 2;
         bool flag_cell = false;
@@ -626,7 +690,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             const LdsVals vals{keys, sorted, TPAD};
             cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM, STOP, true>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
-                                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T);
+                                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T, lut);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
