@@ -306,16 +306,29 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
                 for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
             }
+            // keys and their statistics in integer arithmetic (to_key() through compares and selects costs three times the
+            // instructions, and selects on VCC stall each other: scripts/ubench/issue_rate.hip): `ok` is all ones for a number
+            // and 0 for a NaN; a NaN's key is 0xFFFFFFFF — no effect on the minimum — and it enters the maximum as 0
+            auto key_of = [&](float f) {
+                const uint32_t u = __float_as_uint(f);
+                const uint32_t ok = (uint32_t)((int32_t)((u & 0x7FFFFFFFu) - 0x7F800001u) >> 31);
+                const uint32_t vk = (u ^ ((uint32_t)((int32_t)u >> 31) | 0x80000000u)) & ok;  // = to_key(f) for a number, 0 for a NaN
+                nv -= (int)ok;
+                kmax = max(kmax, vk);
+                const uint32_t k = vk | ~ok;
+                kmin = min(kmin, k);
+                return k;
+            };
 #pragma unroll
             for (int j = 0; j < NL; j++) {
                 const int i = 2 * tid + j * 2 * NT;
                 if (i < TPAD) {
                     float a = v2[j].x, b = v2[j].y;
-                    if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
-                    uint32_t k0 = to_key(a), k1 = to_key(b);
+                    if ((j + 1) * 2 * NT > Te) {  // (wave-uniform: only the last rounds can reach past the series)
+                        if (i >= Te) { a = (i == Ti - 1) ? xlast : __builtin_nanf(""); b = __builtin_nanf(""); }
+                    }
+                    const uint32_t k0 = key_of(a), k1 = key_of(b);
                     *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
-                    if (k0 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k0); kmax = max(kmax, k0); }
-                    if (k1 != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k1); kmax = max(kmax, k1); }
                 }
             }
         } else {
