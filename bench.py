@@ -56,15 +56,16 @@ def group_index(group: str, T: int):
     return np.zeros(T, np.int32), 1
 
 
-def algorithmic_bytes_per_cell(method, T, G, Q, itemsize=4):
-    """compulsory HBM traffic per grid cell (train, adjust)."""
+def algorithmic_bytes_per_cell(method, T, G, Q, itemsize=4, trend_array=True):
+    """compulsory HBM traffic per grid cell (train, adjust).  trend_array=False: the DQM adjustment that does not
+    write the [cell, time] trend array (what the timed step runs: the mapping kernel evaluates the trend line itself)."""
     train = 2 * T * itemsize + 2 * G * Q * itemsize + (G * itemsize if method == "dqm" else 0)
     if method == "qdm":
         adjust = T * itemsize + G * Q * itemsize + T * itemsize
     else:
         adjust = T * itemsize + 2 * G * Q * itemsize + T * itemsize
         if method == "dqm":
-            adjust += G * itemsize + T * itemsize
+            adjust += G * itemsize + (T * itemsize if trend_array else 0)
     return train, adjust
 
 
@@ -213,7 +214,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         cells_total = C * world
         value = cells_total / (elapsed / args.steps)
-        tb, ab = algorithmic_bytes_per_cell(method, T, G, Q)
+        tb, ab = algorithmic_bytes_per_cell(method, T, G, Q, trend_array=False)  # (the timed DQM step writes no trend array)
         # dominant kernel: the one with the largest total time inside the timed region (HIP events on the
         # library's stream, recorded around every launch)
         kern = {k: v for k, v in prof.items() if v["count"] > 0}

@@ -760,6 +760,152 @@ def gen_window_handcase():
     return 1
 
 
+def ecdf_rows(rows, value):
+    """utils.ecdf (utils.py:87-105) on a (cells, n) block: (x <= value).sum(dim) / x.notnull().sum(dim)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (rows <= value).sum(axis=-1) / (~np.isnan(rows)).sum(axis=-1)
+
+
+def gen_preproc_deterministic(rng):
+    """The deterministic half of the two pre-processing steps whose replacement draws are random in the reference:
+
+    _processing._adapt_freq (_processing.py:75-142): P0_sim / P0_hist = ecdf(sim, thresh) (:90-92, utils.py:105), P0_ref,
+    dP0 = where(P0_hist == 0, nan, (P0_hist - P0_ref) / P0_hist) (:94), pth = nbutils.vecquantiles(ref, P0_hist).where(dP0 > 0)
+    (:103-105: the reference's own _vecquantiles kernel, executed here), and — for groups without a window — the NUMBER of
+    replaced values per (cell, group): the percent ranks of utils.rank(pct=True, use_random_tiebreak=True) are the set
+    {(k - 1) / (N - 1)} whatever the tie-break draws (utils.py:622-635), so the count of ranks inside
+    [(P0_ref / P0_hist) * P0_sim, P0_sim] (:112) is fixed; only WHICH of the tied values are replaced, and by what, is random.
+
+    processing.jitter (processing.py:178-257): the bounds after np.nextafter (:217-219, 239-243, the very numpy calls) and the
+    masks of the values that are replaced (:228, 252)."""
+    d = {}
+    T = 3650
+    _, month, _, _ = noleap_fields(T)
+    cases = []
+    for dt in (np.float32, np.float64):
+        ref = (rng.gamma(0.8, 6.0, (3, T))).astype(dt)
+        sim = (rng.gamma(0.9, 5.0, (3, T))).astype(dt)
+        ref[rng.random((3, T)) < 0.25] = 0.0
+        sim[rng.random((3, T)) < 0.45] = 0.0            # more dry days in the model than observed: dP0 > 0
+        sim[1, month == 3] = np.abs(sim[1, month == 3]) + 2.0   # a group without dry days in sim: P0_hist = 0 -> dP0 NaN
+        ref[2, month == 7] = 0.0                                   # more dry days in ref: dP0 < 0, nothing is adapted
+        sim[0, rng.random(T) < 0.02] = np.nan
+        ref[0, rng.random(T) < 0.02] = np.nan
+        cases.append((ref, sim))
+    i = 0
+    for ref, sim in cases:
+        for gname, gidx, G, W in (("month", month - 1, 12, 1), ("time", np.zeros(T, np.int32), 1, 1), ("month_w5", month - 1, 12, 5)):
+            thresh = 1.0
+            rs, rr = group_rows(sim, gidx, G, W), group_rows(ref, gidx, G, W)
+            P0_hist = np.stack([ecdf_rows(r, thresh) for r in rs], axis=1)      # [cell, group] (P0_sim: the training branch)
+            P0_ref = np.stack([ecdf_rows(r, thresh) for r in rr], axis=1)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                dP0 = np.where(P0_hist == 0, np.nan, (P0_hist - P0_ref) / P0_hist)
+            pth = np.full(P0_hist.shape, np.nan, sim.dtype)
+            nrep = np.zeros(P0_hist.shape, np.int64)
+            for c in range(sim.shape[0]):
+                for g in range(G):
+                    if dP0[c, g] > 0:
+                        res = np.empty(1, sim.dtype)
+                        with warnings.catch_warnings():
+                            warnings.simplefilter("ignore")
+                            NBU._vecquantiles(rr[g][c], np.asarray(P0_hist[c, g], sim.dtype), res)   # nbutils.py:151-161
+                        pth[c, g] = res[0]
+                        row = rs[g][c]
+                        N = int((~np.isnan(row)).sum())
+                        if N > 1:
+                            rk = np.arange(N) / (N - 1.0)   # the percent ranks of the N valid values, whatever the tie-break
+                            nrep[c, g] = int(((rk >= (P0_ref[c, g] / P0_hist[c, g]) * P0_hist[c, g]) & (rk <= P0_hist[c, g])).sum())
+            k = f"af{i}"
+            d[f"{k}_ref"], d[f"{k}_sim"], d[f"{k}_gidx"], d[f"{k}_GW"], d[f"{k}_thresh"] = ref, sim, gidx.astype(np.int32), np.array([G, W]), np.array(thresh)
+            d[f"{k}_P0_ref"], d[f"{k}_P0_hist"], d[f"{k}_dP0"], d[f"{k}_pth"], d[f"{k}_nrep"] = P0_ref, P0_hist, dP0, pth, nrep
+            i += 1
+    d["n_af"] = np.array(i)
+    # ---- jitter
+    j = 0
+    for dt in (np.float32, np.float64):
+        x = (rng.gamma(0.8, 2.0, (2, 500))).astype(dt)
+        x[0, rng.random(500) < 0.05] = np.nan
+        x[1, :5] = [0.0, 1.0, 2.0, 3.0, 0.999]
+        for lower, minimum, upper, maximum in ((1.0, None, None, None), (None, None, 2.0, 3.0), (1.0, 0.25, 2.0, 3.0)):
+            k = f"jit{j}"
+            notnull = ~np.isnan(x)
+            d[f"{k}_x"] = x
+            d[f"{k}_args"] = np.array([np.nan if v is None else v for v in (lower, minimum, upper, maximum)], np.float64)
+            if lower is not None:
+                jitter_lower = np.array(lower).astype(float)                                   # processing.py:216
+                jitter_min = np.array(minimum if minimum is not None else 0).astype(float)     # :217
+                jitter_min = np.nextafter(jitter_min.astype(x.dtype), np.inf, dtype=x.dtype)   # :218
+                with np.errstate(invalid="ignore"):
+                    d[f"{k}_mask_lower"] = (x < jitter_lower) & notnull                        # :228
+                d[f"{k}_jitter_min"] = np.array(jitter_min, np.float64)
+            if upper is not None:
+                jitter_upper = np.array(upper).astype(float)                                   # :236
+                jitter_max = np.array(maximum).astype(float)                                   # :237
+                if x.dtype.itemsize < 8:                                                       # :240-241
+                    jitter_max = np.nextafter(jitter_max.astype(x.dtype), -np.inf, dtype=x.dtype)
+                with np.errstate(invalid="ignore"):
+                    d[f"{k}_mask_upper"] = (x >= jitter_upper) & notnull                       # :252
+                d[f"{k}_jitter_max"] = np.array(jitter_max, np.float64)
+            j += 1
+    d["n_jit"] = np.array(j)
+    np.savez_compressed(OUT / "preproc_deterministic.npz", **d)
+    return i + j
+
+
+def gen_window_handcase_nonreducing():
+    """The NON-reducing path of Grouper.apply (base.py:347-457) on the reference's own test series layout
+    (tests/test_base.py:122-166: 366 days from 2000-01-01, group time.month, window 5): a function that keeps the grouped
+    dimensions gets the windowed block of its group, the result keeps the window's CENTRE slot (base.py:438-439) and is put back
+    in time order (:442-443).  Two such functions sit on the hot path — utils.rank (utils.py:573-638: average-tie ranks over
+    [time, window], / N, rescaled mx * (r - mn) / (mx - mn)) and the per-group trend of PolyDetrend (detrending.py:196-208:
+    mean over the window, skipna, then a least-squares line in time) — and both are written here with explicit loops over
+    real dates, independent of rolling_construct / group_rows above and of the oracle's row gathering."""
+    import datetime
+
+    start = datetime.date(2000, 1, 1)
+    dates = [start + datetime.timedelta(days=k) for k in range(366)]
+    x = np.array([(k * 37) % 101 + 0.25 * (k % 3) for k in range(366)], np.float64)
+    x[100] = x[103]  # ties, also across window slots
+    x[200] = np.nan
+    month0 = np.array([dt.month - 1 for dt in dates], np.int32)
+    W = 5
+    rank_pct = np.full(366, np.nan)
+    trend = np.full(366, np.nan)
+    day = np.array([(dt - datetime.date(1970, 1, 1)).days for dt in dates], np.float64)
+    for m in range(12):
+        ts = [k for k in range(366) if month0[k] == m]
+        # ---- rank over [time, window]: every (centre k, slot o) pair of the group, out-of-range slots are NaN (skipped)
+        V = np.array([x[k + o] for k in ts for o in range(-(W // 2), W // 2 + 1) if 0 <= k + o < 366])
+        V = V[~np.isnan(V)]
+        N = V.size
+
+        def pct(v):
+            return ((V < v).sum() + ((V == v).sum() + 1) / 2.0) / N
+
+        allp = np.array([pct(v) for v in V])
+        mn, mx = allp.min(), allp.max()
+        for k in ts:
+            if not np.isnan(x[k]):
+                rank_pct[k] = mx * (pct(x[k]) - mn) / (mx - mn)
+        # ---- trend: mean over the window at every centre (skipna), least-squares line against time
+        mv = np.array([np.nanmean([x[k + o] for o in range(-(W // 2), W // 2 + 1) if 0 <= k + o < 366]) for k in ts])
+        tt = day[ts]
+        tc = tt - tt.mean()
+        slope = (tc * (mv - mv.mean())).sum() / (tc * tc).sum()
+        for k, t_ in zip(ts, tc):
+            trend[k] = mv.mean() + slope * t_
+    d = dict(x=x, gidx=month0, W=np.array(W), rank_pct=rank_pct, trend=trend, time_ns=day * 86400e9)
+    np.savez_compressed(OUT / "window_groups_handcase_nonreducing.npz", **d)
+    return 1
+
+
+def main_round3():
+    rng = np.random.default_rng(20260303)
+    print("pre-processing, deterministic half:", gen_preproc_deterministic(rng))
+    print("window handcase, non-reducing functions:", gen_window_handcase_nonreducing())
+
+
 def main_round2():
     rng = np.random.default_rng(20260202)
     print("families:", gen_families(rng))
@@ -779,9 +925,11 @@ def main():
 
 
 if __name__ == "__main__":
-    # `make_golden.py` regenerates the round-1 files, `make_golden.py round2` the files added in round 2 (own seed, so that
+    # `make_golden.py` regenerates the round-1 files, `make_golden.py round2` / `round3` the files added in those rounds (own seeds, so that
     # neither run disturbs the other's vectors)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main_round2()
+    elif len(sys.argv) > 1 and sys.argv[1] == "round3":
+        main_round3()
     else:
         main()

@@ -82,3 +82,31 @@ def test_blocks_equal_one_piece(monkeypatch, clsname, train_kw, kind, adj_kw, di
         assert objb.ds[name].coords["lat"].equals(obj1.ds[name].coords["lat"]) if "lat" in a.dims else True
     np.testing.assert_array_equal(scenb.transpose(*scen1.dims).values, scen1.values)
     assert scenb.attrs["units"] == scen1.attrs["units"]
+    # ... and the blocked result itself is held to the ORACLE on cells of the first and the last block (not only to the
+    # one-piece device call); the grouped-linear case is checked against scipy in tests/test_interp_linear_gpu.py
+    if "interp" not in adj_kw:
+        import oracle
+        from conftest import assert_close, assert_close_or_tie, assert_dqm_close_or_flip
+
+        r, h, s_ = (a.reshape(-1, a.shape[-1]) for a in _data(kind, (7, 5, 3650)))
+        sel = [0, 1, 17, 34]
+        T = r.shape[1]
+        doy = (np.arange(T) % 365).astype(np.int32)
+        q = np.asarray(objb.ds["quantiles"].values, np.float32)
+        got = scenb.transpose("lat", "lon", "time").values.reshape(-1, T)[sel]
+        gaf = objb.ds["af"].transpose("lat", "lon", "dayofyear", "quantiles").values.reshape(35, 365, -1)[sel]
+        if clsname == "DetrendedQuantileMapping":
+            tnum = np.asarray(xs.date_range("2000-01-01", T, "noleap").numeric_ns, np.float64)
+            oaf, ohq, osc = oracle.dqm_train(r[sel], h[sel], doy, 365, 31, q, kind)
+            assert_close(gaf, oaf, rtol=3e-7, atol=3e-5, what="blocked dqm af vs oracle")
+            oscen, otrend = oracle.dqm_adjust(s_[sel], oaf, ohq, osc, doy, 31, tnum, 1, "nearest", "constant", kind)
+            assert_dqm_close_or_flip(got, oscen, s_[sel], osc, otrend, ohq, oaf, doy, kind, rtol=1e-5, what="blocked dqm scen vs oracle")
+        else:
+            oaf, ohq = oracle.eqm_train(r[sel], h[sel], doy, 365, 31, q, kind)
+            np.testing.assert_array_equal(gaf, oaf)
+            if clsname == "QuantileDeltaMapping":
+                oscen, osq = oracle.qdm_adjust(s_[sel], oaf, q, doy, 31, False, "nearest", "constant", kind)
+                assert_close_or_tie(got, oscen, s_[sel], q, oaf, doy, kind, rtol=1e-6, what="blocked qdm scen vs oracle", newx=osq, max_frac=5e-3)
+            else:
+                oscen = oracle.qm_adjust(s_[sel], oaf, ohq, doy, "nearest", "constant", kind)
+                assert_close_or_tie(got, oscen, s_[sel], ohq, oaf, doy, kind, rtol=1e-6, what="blocked eqm scen vs oracle")

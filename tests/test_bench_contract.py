@@ -1,4 +1,4 @@
-"""The bench line's contract, checked on the committed lines of the current round (profiles/r01_final*_bench.json, written by
+"""The bench line's contract, checked on the committed lines of the current round (profiles/r03_*_bench.json, written by
 bench.py on the GPU box): the keys the driver reads, the metric of BASELINE.json, and the arithmetic that ties
 `roofline.achieved` to the algorithmic bytes and the dominant kernel's measured launch time."""
 from __future__ import annotations
@@ -10,7 +10,7 @@ from pathlib import Path
 import pytest
 
 ROOT = Path(__file__).resolve().parents[1]
-LINES = sorted((ROOT / "profiles").glob("r01_final*_bench.json"))
+LINES = sorted((ROOT / "profiles").glob("r03_*_bench.json"))
 
 
 def _bench_module():
@@ -43,7 +43,7 @@ def test_bench_line_contract(path):
     # the algorithmic bytes are SURVEY §8d's per-cell figure times the cells of one launch
     b = _bench_module()
     method = d["config"]["workload"].split(":")[0].split("_")[0]
-    tb, ab = b.algorithmic_bytes_per_cell(method, d["config"]["days"], d["config"]["groups"], 20)
+    tb, ab = b.algorithmic_bytes_per_cell(method, d["config"]["days"], d["config"]["groups"], 20, trend_array=False)
     per_cell = tb if r["kernel"].startswith("k_train") else ab
     assert r["algorithmic_bytes_per_launch"] == per_cell * d["config"]["cells_per_gpu"]
     c = d["cpu_baseline"]
@@ -55,5 +55,6 @@ def test_algorithmic_bytes_match_the_survey():
     # cfg3-like EQM/DQM doy tables, T = 10950, G = 365, Q = 20
     assert b.algorithmic_bytes_per_cell("eqm", 10950, 365, 20) == (146000, 146000)
     assert b.algorithmic_bytes_per_cell("dqm", 10950, 365, 20) == (147460, 191260)
+    assert b.algorithmic_bytes_per_cell("dqm", 10950, 365, 20, trend_array=False) == (147460, 147460)  # the timed step: no trend array
     assert b.algorithmic_bytes_per_cell("qdm", 10950, 365, 20) == (146000, 116800)
     assert b.algorithmic_bytes_per_cell("eqm", 10950, 12, 20) == (89520, 89520)

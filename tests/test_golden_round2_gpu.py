@@ -96,13 +96,14 @@ def test_grouped_interp_at_fractional_group_coordinate(hip, golden, method):
         gc = np.arange(0, G + 2, dtype=np.float64)
         scen = hip.qm_adjust_linear2d(sim, af, hq, gc, newg, extrap, "+", cubic=method == "cubic")
         exp = sim + d[f"out_{i}"]  # the golden vector is the interpolated factor; kind "+" applies it
-        # values to float32 rounding; a handful of elements may sit on a hull edge or a cocircular diagonal, where Qhull's
-        # choice is arbitrary: bounded count, and they must stay inside the table's range of factors
+        # values to float32 rounding, the NaN pattern (queries outside the hull of the nodes) identical: NO element is let off.
+        # (Round 2 allowed 0.2 % of unexplained outliers here; measured on the device path: 0 NaN mismatches, 0 values beyond the
+        # tolerance, in every one of the eight cases — scripts/diag/interp2d_mismatch.py.)
         nan_mismatch = np.isnan(scen) != np.isnan(exp)
         both = ~np.isnan(scen) & ~np.isnan(exp)
         tol = 3e-6 if method == "linear" else 2e-5
         bad = ~np.isclose(scen[both], exp[both], rtol=tol, atol=tol * 10)
-        assert nan_mismatch.sum() + bad.sum() <= 2e-3 * scen.size, (i, method, extrap, int(nan_mismatch.sum()), int(bad.sum()))
+        assert nan_mismatch.sum() == 0 and bad.sum() == 0, (i, method, extrap, int(nan_mismatch.sum()), int(bad.sum()))
         seen += 1
     assert seen == 4
 

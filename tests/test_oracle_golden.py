@@ -355,3 +355,27 @@ def test_window_group_bookkeeping_hand_case(golden):
     # the quantile path gathers the same rows: the median of a windowed day-of-year row of arange is its centre value
     med = oracle.quantile_groups(x, d["doy_gidx"], 366, 5, np.array([0.5]))[0, :, 0]
     np.testing.assert_allclose(med[2:-2], d["x"][2:-2], rtol=1e-14)
+
+
+# ---- round 3: the deterministic half of the pre-processing steps, from the reference's own kernels (make_golden.py round3)
+def test_adapt_freq_deterministic_half_against_reference_kernels(golden):
+    from preproc_golden_checks import check_adapt_freq
+
+    check_adapt_freq(oracle, golden("preproc_deterministic"))
+
+
+def test_jitter_bounds_and_masks_against_reference_lines(golden):
+    from preproc_golden_checks import check_jitter
+
+    check_jitter(oracle, golden("preproc_deterministic"))
+
+
+def test_window_group_bookkeeping_hand_case_nonreducing(golden):
+    """rank and trend through the non-reducing path of Grouper.apply (centre slot, time order): explicit-loop expectations"""
+    d = golden("window_groups_handcase_nonreducing")
+    x, W = d["x"][None, :], int(d["W"])
+    r = oracle.rank_groups(x, d["gidx"], 12, W, rank_window=True)
+    assert np.array_equal(np.isnan(r[0]), np.isnan(d["rank_pct"]))
+    np.testing.assert_allclose(r[0], d["rank_pct"], rtol=1e-14, atol=1e-15)
+    tr = oracle.polydetrend_trend(x, d["gidx"], 12, W, d["time_ns"], 1)
+    np.testing.assert_allclose(tr[0], d["trend"], rtol=1e-12)

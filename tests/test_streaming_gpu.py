@@ -45,6 +45,27 @@ def test_streamed_equals_in_core(method, kind):
             escen = hip.qm_adjust(sim, eaf, ehq, doy, "nearest", "constant", kind)
     assert np.array_equal(af, eaf, equal_nan=True) and np.array_equal(hq, ehq, equal_nan=True)
     assert np.array_equal(scen, escen, equal_nan=True)
+    # ... and the streamed result itself is held to the ORACLE (not only to the one-piece device call) on cells at both ends of
+    # the cube and on both sides of a block boundary
+    import oracle
+    from conftest import assert_close, assert_close_or_tie, assert_dqm_close_or_flip
+
+    sel = [0, 5, 255, 256, 511, 512, C - 1]
+    if method == "dqm":
+        oaf, ohq, osc = oracle.dqm_train(ref[sel], hist[sel], doy, G, W, q, kind)
+        assert_close(af[sel], oaf, rtol=3e-7, atol=3e-5, what="streamed dqm af vs oracle")
+        assert_close(hq[sel], ohq, rtol=3e-7, atol=3e-5, what="streamed dqm hist_q vs oracle")
+        oscen, otrend = oracle.dqm_adjust(sim[sel], oaf, ohq, osc, doy, W, tnum, 1, "nearest", "constant", kind)
+        assert_dqm_close_or_flip(scen[sel], oscen, sim[sel], osc, otrend, ohq, oaf, doy, kind, rtol=1e-5, what="streamed dqm scen vs oracle")
+    else:
+        oaf, ohq = oracle.eqm_train(ref[sel], hist[sel], doy, G, W, q, kind)
+        assert np.array_equal(af[sel], oaf, equal_nan=True) and np.array_equal(hq[sel], ohq, equal_nan=True)
+        if method == "qdm":
+            oscen, osq = oracle.qdm_adjust(sim[sel], oaf, q, doy, W, False, "nearest", "constant", kind)
+            assert_close_or_tie(scen[sel], oscen, sim[sel], q, oaf, doy, kind, rtol=1e-6, what="streamed qdm scen vs oracle", newx=osq, max_frac=5e-3)
+        else:
+            oscen = oracle.qm_adjust(sim[sel], oaf, ohq, doy, "nearest", "constant", kind)
+            assert_close_or_tie(scen[sel], oscen, sim[sel], ohq, oaf, doy, kind, rtol=1e-6, what="streamed eqm scen vs oracle")
     # a caller-provided output cube is filled in place; one block covering everything also works
     out = np.full((C, T), -1.0, np.float32)
     r = train_adjust_streamed(method, ref, hist, sim, doy, G, W, q, kind, block_cells=4096, time_num=tnum, scen=out)
