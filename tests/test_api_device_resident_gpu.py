@@ -107,6 +107,36 @@ def test_device_arrays_in_and_time_major():
         np.testing.assert_array_equal(got, exp.values)
 
 
+@pytest.mark.parametrize("clsname,adj_kw", [("EmpiricalQuantileMapping", {}), ("DetrendedQuantileMapping", {}), ("QuantileDeltaMapping", {"rank_window": False})])
+def test_time_major_inputs_keep_the_same_dims_on_both_paths(monkeypatch, clsname, adj_kw):
+    """(time, lat, lon) inputs — what xarray cubes are: `dims`, the axis order of `.values` and the trained tables do not depend
+    on whether the data were moved to the device first (the size threshold XSDBA_AMD_DEVICE_MIN_MB), and follow the reference's
+    template order (base.py:696-700)"""
+    import warnings
+
+    cls = getattr(xs, clsname)
+    kind = "*" if clsname == "QuantileDeltaMapping" else "+"
+    arrs = [np.ascontiguousarray(np.moveaxis(a, -1, 0)) for a in _data(kind, shape=(4, 5, 1825), seed=5)]
+    ref, hist, sim = (_cube(a, ("time", "lat", "lon"), "K" if kind == "+" else "mm/d") for a in arrs)
+
+    def run():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            obj = cls.train(ref, hist, kind=kind, group=xs.Grouper("time.dayofyear", window=31), nquantiles=20)
+            return obj, obj.adjust(sim, **adj_kw)
+
+    monkeypatch.setenv("XSDBA_AMD_DEVICE_MIN_MB", "1e12")
+    obj_h, scen_h = run()
+    monkeypatch.setenv("XSDBA_AMD_DEVICE_MIN_MB", "0")
+    obj_d, scen_d = run()
+    assert scen_d.device_data is not None and scen_h.device_data is None
+    assert scen_d.dims == scen_h.dims and scen_d.shape == scen_h.shape
+    np.testing.assert_array_equal(scen_d.values, scen_h.values)
+    for name in obj_h.ds.data_vars:
+        assert obj_d.ds[name].dims == obj_h.ds[name].dims, name
+        np.testing.assert_array_equal(obj_d.ds[name].values, obj_h.ds[name].values, err_msg=name)
+
+
 def test_results_are_released_with_their_arrays():
     """owning DeviceArrays give their buffer back when they are collected (no leak over a loop that drops its results)"""
     import gc

@@ -491,10 +491,9 @@ def map_blocks(reduces=None, **out_vars):
                                              for k, v in o.data_vars.items()}, attrs=o.attrs))
                     out = _concat_blocks(outs, bdim)
                 def _ordered(v):
-                    order = [d for d in all_dims if d in v.dims]
-                    if tuple(order) != tuple(v.dims) and getattr(v, "device_data", None) is not None and getattr(v, "_host", None) is None:
-                        return v  # device-resident result: kept as the kernels wrote it, (cells..., time) — labels tell the order
-                    return v.transpose(*order)
+                    # the template order of the reference (base.py:696-700), for device-resident results too: their transpose is a
+                    # relabelling (labeled.DataArray.transpose), the buffer stays as the kernels wrote it
+                    return v.transpose(*[d for d in all_dims if d in v.dims])
 
                 out = Dataset({k: _ordered(v) for k, v in out.data_vars.items()}, attrs=out.attrs)
             except Exception as err:

@@ -78,6 +78,7 @@ class DataArray:
     (``device_data``) so that tables and series never leave the GPU between ``train`` and ``adjust``."""
 
     def __init__(self, data, dims=None, coords=None, attrs=None, name=None):
+        self._dev_dims = None  # device buffer laid out in another dimension order than `dims` (see transpose)
         if _is_device_array(data):
             self._dev, self._host = data, None
         else:
@@ -110,7 +111,10 @@ class DataArray:
     @property
     def values(self):
         if self._host is None:
-            self._host = self._dev.download().reshape(self._dev.shape)
+            h = self._dev.download().reshape(self._dev.shape)
+            if self._dev_dims is not None and tuple(self._dev_dims) != tuple(self.dims):
+                h = h.transpose([self._dev_dims.index(d) for d in self.dims])  # the labelled order, whatever the buffer's
+            self._host = h
         return self._host
 
     @values.setter
@@ -119,12 +123,21 @@ class DataArray:
 
     @property
     def device_data(self):
-        """the DeviceArray behind this array, or None when the data live on the host only"""
+        """the DeviceArray behind this array, or None when the data live on the host only; its axes are `device_dims`"""
         return self._dev
 
     @property
+    def device_dims(self):
+        """dimension order of the device buffer: `dims`, unless the array is a lazily transposed view of device data"""
+        return tuple(self.dims) if self._dev_dims is None else tuple(self._dev_dims)
+
+    @property
     def shape(self):
-        return tuple(self._dev.shape) if self._host is None else self._host.shape
+        if self._host is not None:
+            return self._host.shape
+        if self._dev_dims is None:
+            return tuple(self._dev.shape)
+        return tuple(self._dev.shape[self._dev_dims.index(d)] for d in self.dims)
 
     @property
     def dtype(self):
@@ -226,6 +239,7 @@ class DataArray:
         """the same data (host copy and / or device buffer shared, nothing downloaded) under other labels"""
         out = DataArray.__new__(DataArray)
         out._dev, out._host = self._dev, self._host
+        out._dev_dims = self._dev_dims
         out.dims = tuple(self.dims if dims is None else dims)
         out.coords = OrderedDict(self.coords if coords is None else coords)
         out.attrs = dict(self.attrs if attrs is None else attrs)
@@ -243,6 +257,12 @@ class DataArray:
             raise ValueError(f"{dims} is not a permutation of {self.dims}")
         if tuple(dims) == self.dims:
             return self._like()
+        if self._host is None and self._dev is not None:
+            # device-resident data: nothing moves — the labels change, the buffer keeps its layout (`device_dims`), and `values`
+            # transposes when (if ever) the data are brought to the host
+            out = self._like(dims=tuple(dims))
+            out._dev_dims = self.device_dims
+            return out
         return DataArray(self.values.transpose([self.dims.index(d) for d in dims]), dims, self.coords, self.attrs, self.name)
 
     @property

@@ -82,7 +82,11 @@ def cell_time_view(da: DataArray, dim: str = "time"):
     dev = getattr(da, "device_data", None)
     if dev is not None and getattr(da, "_host", None) is None:
         # device-resident data: (cells..., time) is a reshape of the buffer, (time, cells...) the time-major view of it
-        shape = tuple(da.shape)
+        # (the buffer's own dimension order counts: `da` may be a relabelled — lazily transposed — view of it)
+        pdims = tuple(da.device_dims)
+        ax = pdims.index(dim)
+        cell_dims = tuple(d for d in pdims if d != dim)
+        shape = tuple(dev.shape)
         cell_shape = shape[:ax] + shape[ax + 1:]
         n_cell, n_time = int(np.prod(cell_shape, dtype=np.int64)), shape[ax]
         if ax == len(shape) - 1:
@@ -105,7 +109,7 @@ def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantil
     their sizes taken from `cell_shape`."""
     tail = [prop] + ([last] if last else [])
     dev = getattr(tab, "device_data", None)
-    if dev is not None and tuple(tab.dims) == tuple(cell_dims) + tuple(tail):
+    if dev is not None and getattr(tab, "_host", None) is None and tuple(tab.device_dims) == tuple(cell_dims) + tuple(tail):
         # a device-resident table already laid out (cells..., group(, quantile)): a reshape of the buffer, nothing moves
         n_cell = int(np.prod(tab.shape[:len(cell_dims)], dtype=np.int64))
         return dev.reshape((n_cell,) + tuple(tab.shape[len(cell_dims):]))
