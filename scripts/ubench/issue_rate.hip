@@ -35,7 +35,7 @@ enum Kind {
     K_BPERM_IND, K_BPERM_DEP, K_LDS_B32, K_LDS_B32_S6, K_LDS_B64_S6, K_LDS2_B32_S6, K_LDS_U16_RAND, K_LDS_XOR_RAND, K_LDS_XOR_RTN,
     K_READLANE, K_VALU4_LDS, K_VALU8_LDS_S2, K_SHL64, K_ADD_F64, K_FMA_F64, K_RCP_F64, K_MUL_LO, K_CVT_F64, K_POPC_CHAIN,
     K_MIX_KERNEL, K_VALU_WAITCNT, K_CND_VCC_SALU, K_CND_SGPR_SALU, K_CND_NODEP, K_CND_ADD_ALT, K_CND_1CMP3, K_CND_1CMP3_E64,
-    K_CND_2STREAMS_E64, K_VADD_E64, K_VADD_LIT, K_VOP2_MIX, K_VOP3_MIX, K_VCMP_E32, K_VCMP_E64, K_VALU_SALU_3_1, K_VOP3_SALU_3_1, K_NKIND
+    K_CND_2STREAMS_E64, K_VADD_E64, K_VADD_LIT, K_VOP2_MIX, K_VOP3_MIX, K_VCMP_E32, K_VCMP_E64, K_VALU_SALU_3_1, K_VOP3_SALU_3_1, K_LDS_XOR_C32, K_LDS_XOR_C16, K_LDS_XOR_C4, K_LDS_XOR_SAMEBANK, K_NKIND
 };
 static const char *kind_name[K_NKIND] = {
     "v_add_u32 x32, 8 independent chains", "v_add_u32 x32, one dependent chain", "v_cndmask_b32 (vcc) x32",
@@ -59,6 +59,8 @@ static const char *kind_name[K_NKIND] = {
     "v_add_u32 with a 32-bit literal (8 bytes) x32", "4-byte VOP2 mix (and, lshl, xor, sub, or, lshr, mov, min) x32",
     "8-byte VOP3 mix (lshl_add, and_or, add3, bfe, lshl_or, bcnt, mad_u24, alignbit) x32", "v_cmp_lt_u32 vcc (VOPC, 4 bytes) x32",
     "v_cmp_lt_u32_e64 s[..] (8 bytes) x32", "(3 v_add_u32 + 1 s_add_u32) x8", "(3 v_add_u32_e64 + 1 s_add_u32) x8",
+    "ds_xor_b32 x32, 64 lanes on 32 distinct words (pairs share an address)", "ds_xor_b32 x32, 64 lanes on 16 distinct words",
+    "ds_xor_b32 x32, 64 lanes on 4 distinct words", "ds_xor_b32 x32, 64 distinct words of ONE bank (stride 32 dwords)",
 };
 
 template <int KIND>
@@ -269,6 +271,14 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long *cycles, unsi
         } else if constexpr (KIND == K_VALU_SALU_3_1) {
             __asm__ volatile(R8("v_add_u32 %0, %0, %6\n v_add_u32 %1, %1, %6\n v_add_u32 %2, %2, %6\n s_add_u32 %4, %4, 3\n")
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1) : "v"(tid) : "scc");
+        } else if constexpr (KIND == K_LDS_XOR_C32 || KIND == K_LDS_XOR_C16 || KIND == K_LDS_XOR_C4 || KIND == K_LDS_XOR_SAMEBANK) {
+            const unsigned nd = KIND == K_LDS_XOR_C32 ? 32u : (KIND == K_LDS_XOR_C16 ? 16u : 4u);
+            const unsigned ad = KIND == K_LDS_XOR_SAMEBANK ? wbase * 0u + (unsigned)(tid >> 6) * 8u + lane * 128u   // 64 words, one bank
+                                                           : wbase + (((lane * 2654435761u) >> 8) % nd) * 36u;        // nd distinct words in different banks
+            __asm__ volatile(R4("ds_xor_b32 %0, %1\n ds_xor_b32 %0, %1 offset:4\n ds_xor_b32 %0, %1 offset:12\n ds_xor_b32 %0, %1 offset:20\n"
+                                "ds_xor_b32 %0, %1 offset:28\n ds_xor_b32 %0, %1 offset:36\n ds_xor_b32 %0, %1 offset:44\n ds_xor_b32 %0, %1 offset:52\n"
+                                "s_waitcnt lgkmcnt(0)\n")
+                             :: "v"(ad), "v"(a0) : "memory");
         } else if constexpr (KIND == K_VOP3_SALU_3_1) {
             __asm__ volatile(R8("v_add_u32_e64 %0, %0, %6\n v_add_u32_e64 %1, %1, %6\n v_add_u32_e64 %2, %2, %6\n s_add_u32 %4, %4, 3\n")
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+s"(s0), "+s"(s1) : "v"(tid) : "scc");
@@ -288,7 +298,7 @@ static int instr_per_body(int k)
     switch (k) {
     case K_CND_VCC_SALU: case K_CND_SGPR_SALU: case K_CND_NODEP: case K_CND_ADD_ALT: return 33;
     case K_VCNDMASK: return 33;
-    case K_BPERM_IND: case K_LDS_B32: case K_LDS_B32_S6: case K_LDS_B64_S6: case K_LDS2_B32_S6: case K_LDS_U16_RAND: case K_LDS_XOR_RAND: case K_LDS_XOR_RTN: return 32;  // (+ 4 waits)
+    case K_LDS_XOR_C32: case K_LDS_XOR_C16: case K_LDS_XOR_C4: case K_LDS_XOR_SAMEBANK: case K_BPERM_IND: case K_LDS_B32: case K_LDS_B32_S6: case K_LDS_B64_S6: case K_LDS2_B32_S6: case K_LDS_U16_RAND: case K_LDS_XOR_RAND: case K_LDS_XOR_RTN: return 32;  // (+ 4 waits)
     case K_BPERM_DEP: return 32;
     case K_VALU2_SALU: return 34;
     case K_VALU4_LDS: return 40;

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         int nvalid;
         const uint16_t *sorted;
         if constexpr (sizeof(R) == 8) sorted = cell_load_sort_f64<EPT>(sim + c * sc, T, smem, red, nvalid);
-        else sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid);
+        else {
+            sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid, NoLoadHook(), -1, true);
+            if (!sorted) sorted = idx1;  // (no valid value: not sorted; nothing below reads the order when nvalid == 0)
+        }
         uint16_t *r2buf = (sorted == idx1) ? idx0 : idx1;  // 2 * average rank per time step, 0 = no rank
         const QdmSeries<R> ser{sim + c * sc, keys, sorted};
         // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):

@@ -265,6 +265,7 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
 // indexes sorted by key (NaN / padding last), rank[t] = position of t in that order.  Returns the sorted index array
 // (one of the two u16 buffers; the other one is free afterwards).  All 1024 threads must call it; it ends on a barrier.
 // stop_after (timing aid): 1 = return after the load, 2 = after the sort without building rank[].
+// skip_empty: return nullptr (after the load, nvalid_out = 0) instead of sorting a series that holds no valid value.
 struct NoLoadHook {
     static constexpr bool uses_sort_scratch = false;
     __device__ __forceinline__ void operator()(const uint32_t *, int, int) const {}
@@ -275,7 +276,7 @@ struct NoLoadHook {
 template <int EPT, typename Hook = NoLoadHook>
 __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restrict__ x, int64_t T, unsigned char *smem,
                                                           uint32_t *red, int stop_after, int &nvalid_out, const Hook &hook = Hook(),
-                                                          int nan_rank = -1)
+                                                          int nan_rank = -1, bool skip_empty = false)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
@@ -375,6 +376,10 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         if (Hook::uses_sort_scratch || stop_after == 1) __syncthreads();
 
         if (stop_after == 1) return nullptr;  // timing aid (XSDBA_HIP_DEBUG_PHASE): stop after load/keys
+        // skip_empty: a series without a single valid value (an ocean cell of a land-only variable, a masked cell) is not sorted
+        // — every key is the same, the counting pass would serialise 11 000 atomics on one LDS word —: the caller gets nullptr
+        // (wave-uniform) and writes its all-NaN results directly.  keys[] is complete; the barrier protects red[].
+        if (skip_empty && nvalid == 0) { __syncthreads(); return nullptr; }
         hook(keys, Ti, tid);
         return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank);
 }

@@ -626,11 +626,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         next_flips();  // the vectors have been read for the last time in this step
         const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
         R v, vhi;
-#if defined(XS_EXP_NOVAL)
-        v = (R)rs0; vhi = (R)rs1;
-#else
         vals.at_ranks(rs0, rs1, v, vhi);
-#endif
         if (DQM) { v = apply_corr<R>(v, inv, kind); vhi = apply_corr<R>(vhi, inv, kind); }
         R res;
         if (casek == 3) res = nan_of<R>();
@@ -683,9 +679,26 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             const uint16_t *sorted;  // (no rank[] in the union region)
             // (stop_after 3: rank[] is written by the sort's last pass into the buffer that pass read from)
             // (NaN / padding steps get the rank NAN_RANK: a bit of the scratch word behind every bit-vector)
-            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W}, Cfg3::NAN_RANK);
-            else sorted = cell_load_sort<EPT>(x, T, smem, red, STOP == 1 ? 1 : 3, nvalid, NoLoadHook(), Cfg3::NAN_RANK);
+            if constexpr (DQM) sorted = cell_load_sort<EPT>(x, T, smem, red, 3, nvalid, GroupSumHook<EPT>{smem, gsum, gsum + G, mem_ptr, mem_idx, mem_t16, G, W}, Cfg3::NAN_RANK, true);
+            else sorted = cell_load_sort<EPT>(x, T, smem, red, STOP == 1 ? 1 : 3, nvalid, NoLoadHook(), Cfg3::NAN_RANK, true);
             if constexpr (STOP == 1) continue;  // (diagnostic: the load alone)
+            if (!sorted) {
+                // no valid value in this series (block-uniform): every quantile of the pass is NaN — written with the very
+                // expressions of the walk (NaN quantile; af = correction(hist_q, NaN); the DQM means and their correction)
+                const float nanq = nan_of<float>();
+                const size_t base = (size_t)c * G * (size_t)Q;
+                for (int i = tid; i < G * Q; i += 1024) {
+                    if (mode == 0 || arr == 0) out_hq[base + i] = nanq;
+                    else af[base + i] = get_corr<float>(out_hq[base + i], nanq, kind);
+                }
+                if constexpr (DQM)
+                    for (int g = tid; g < G; g += 1024) {
+                        float &s_ = scaling[(size_t)c * G + g];
+                        s_ = arr == 0 ? nanq : get_corr<float>(s_, nanq, kind);
+                    }
+                __syncthreads();
+                continue;
+            }
             if constexpr (STOP == 2) { if (tid == 0 && sorted[nvalid / 2] == 0xFFFF) out_hq[0] = 1.f; __syncthreads(); continue; }  // (load + sort)
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             const LdsVals vals{keys, sorted, TPAD};

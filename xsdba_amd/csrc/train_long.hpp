@@ -92,17 +92,37 @@ __global__ __launch_bounds__(1024) void k_train_long(
             int nv[2];
             for (int h = 0; h < 2; h++) {
                 const int Th = h ? Ti - T0 : T0;
-                const uint16_t *sorted = cell_load_sort<11>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h]);
-                for (int r = tid; r < HALF; r += NT) {
-                    const int id = sorted[r];
-                    ks[h * HALF + r] = keys[min(id, HALF - 1)];
-                    ts[h * HALF + r] = (uint16_t)id;
+                const uint16_t *sorted = cell_load_sort<11>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h], NoLoadHook(), -1, true);
+                if (sorted) {
+                    for (int r = tid; r < HALF; r += NT) {
+                        const int id = sorted[r];
+                        ks[h * HALF + r] = keys[min(id, HALF - 1)];
+                        ts[h * HALF + r] = (uint16_t)id;
+                    }
+                } else {  // a half without a valid value was not sorted: all its steps are NaN steps, in any order
+                    for (int r = tid; r < HALF; r += NT) { ks[h * HALF + r] = 0xFFFFFFFFu; ts[h * HALF + r] = (uint16_t)r; }
                 }
                 stores_done();
                 __syncthreads();  // the next sort (or the merge) overwrites keys / sorted
             }
             const int nv0 = nv[0], nv1 = nv[1], nvalid = nv0 + nv1;
             if (debug_phase == 1) continue;  // timing aid: the two half sorts only
+            if (nvalid == 0) {
+                // no valid value in the series (block-uniform): every quantile of the pass is NaN — the expressions of the walk
+                const float nanq = nan_of<float>();
+                const size_t base = (size_t)c * G * (size_t)Q;
+                for (int i = tid; i < G * Q; i += NT) {
+                    if (mode == 0 || arr == 0) out_hq[base + i] = nanq;
+                    else af[base + i] = get_corr<float>(out_hq[base + i], nanq, kind);
+                }
+                if constexpr (DQM)
+                    for (int g = tid; g < G; g += NT) {
+                        float &s_ = scaling[(size_t)c * G + g];
+                        s_ = arr == 0 ? nanq : get_corr<float>(s_, nanq, kind);
+                    }
+                __syncthreads();
+                continue;
+            }
             // ---------------- 2. merge: final rank of every time step ----------------
             for (int r = tid; r < HALF; r += NT) { K0[r] = load_l2(ks + r); K1[r] = load_l2(ks + HALF + r); }
             __syncthreads();
