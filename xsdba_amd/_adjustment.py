@@ -17,6 +17,8 @@ frequency adaptation of ``sim`` with the trained ``P0_ref, P0_hist, pth`` in fro
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
+
 import warnings
 
 import numpy as np
@@ -140,8 +142,15 @@ def _nan_like(tab):
     return np.broadcast_to(np.asarray(np.nan, tab.dtype), tuple(tab.shape))
 
 
+@dataclass
 class _TrainBlock:
     """ref and hist of one training call as [cell, time'] series blocks (pooled members folded into time')"""
+
+    r2: object = None        # ref block ([cell, time'] host array or device view)
+    h2: object = None        # hist block
+    gidx_r: object = None    # group of every step of ref's (folded) time axis
+    gidx_h: object = None    # ... of hist's
+    same: bool = True        # ref and hist share the time axis: one fused training call
 
 
 def _prep_train(ds, group):
@@ -396,28 +405,14 @@ def _pooled_trend(s2, sc, gidx, G, group, kind, tnum, degree, P):
     return np.ascontiguousarray(np.repeat(trend, P, axis=0))
 
 
-_DQM_SCEN_ONLY = False  # set by scen_only(): the caller will drop the trend (DetrendedQuantileMapping._adjust takes .scen)
-
-
-class scen_only:
-    """Inside this context ``dqm_adjust`` may leave the trend out of its result: the reference's `DetrendedQuantileMapping.
-    _adjust` (adjustment.py:659-668) keeps `.scen` only, and under dask the trend is then never computed; here the mapping
-    kernel evaluates the per-group regression line itself instead of reading a trend array written for nobody."""
-
-    def __enter__(self):
-        global _DQM_SCEN_ONLY
-        self._old, _DQM_SCEN_ONLY = _DQM_SCEN_ONLY, True
-
-    def __exit__(self, *exc):
-        global _DQM_SCEN_ONLY
-        _DQM_SCEN_ONLY = self._old
-        return False
-
-
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], trend=[])
-def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None) -> Dataset:
+def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_thresh=None, max_tail_factor=None, _outputs=None) -> Dataset:
     """DQM adjustment on one block (_adjustment.py:679-780): scaling, per-group linear detrending of the window
-    means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device."""
+    means, quantile mapping, retrending — one trend kernel + one mapping kernel on the device.
+
+    ``_outputs`` (extension): the declared outputs the caller will keep; None = all of them (scen, trend), like the
+    reference.  `DetrendedQuantileMapping._adjust` keeps `.scen` only (adjustment.py:659-668) and says so: the mapping kernel
+    then evaluates the per-group regression line itself instead of reading a trend array written for nobody."""
     own = None  # a PolyDetrend with a group / kind / options of its own: its trend is fitted first and handed to the mapping
     if isinstance(detrend, PolyDetrend):
         degree = int(detrend.degree)
@@ -477,7 +472,7 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, None, degree, interp, extrapolation, kind, trend_in=trend_in)
     else:
         scen, trend = hip.dqm_adjust(s2, af, hq, sc, gidx, group.window, tnum, degree, interp, extrapolation, kind,
-                                     want_trend=not _DQM_SCEN_ONLY)
+                                     want_trend=_outputs is None or "trend" in _outputs)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
     out = {"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen")}
     if trend is not None:
@@ -486,8 +481,10 @@ def dqm_adjust(ds, *, group, interp, kind, extrapolation, detrend, adapt_freq_th
 
 
 @map_blocks(reduces=[Grouper.PROP, "quantiles"], scen=[], sim_q=[])
-def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, rank_window=None, max_tail_factor=None) -> Dataset:
-    """QDM adjustment on one block (_adjustment.py:783-886)."""
+def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None, rank_window=None, max_tail_factor=None,
+               _outputs=None) -> Dataset:
+    """QDM adjustment on one block (_adjustment.py:783-886).  ``_outputs`` (extension): the declared outputs the caller will
+    keep; None = all of them (scen, sim_q), like the reference."""
     if rank_window is None:
         rank_window = False
         if group.window > 1:
@@ -525,11 +522,9 @@ def qdm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None
         scen, sim_q = hip.qdm_adjust(f2, np.ascontiguousarray(af[::P]), quantiles, gf, group.window, True, interp, extrapolation, kind)
         scen, sim_q = _unfold(scen, P, T), _unfold(sim_q, P, T)
     else:
-        # sim_q (a float64 series as large as two copies of sim) is only produced when somebody will look at it
-        from .options import EXTRA_OUTPUT, OPTIONS
-
+        # sim_q (a float64 series as large as two copies of sim) is only produced when the caller keeps it
         scen, sim_q = hip.qdm_adjust(s2, af, quantiles, gidx, group.window, bool(rank_window), interp, extrapolation, kind,
-                                     want_sim_q=bool(OPTIONS[EXTRA_OUTPUT]))
+                                     want_sim_q=_outputs is None or "sim_q" in _outputs)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)
     out = {"scen": _series_like(sim, scen, cell_dims, cell_shape, group.dim, "scen")}
     if sim_q is not None:

@@ -262,12 +262,10 @@ class DetrendedQuantileMapping(TrainAdjust):
         return ds, {"group": group, "kind": kind, "adapt_freq_thresh": adapt_freq_thresh, "max_tail_factor": max_tail_factor}
 
     def _adjust(self, sim, interp="nearest", extrapolation="constant", detrend=1):
-        from ._adjustment import scen_only
-
-        with scen_only():  # (.scen is all that is kept, like the reference: the trend array need not exist)
-            out = dqm_adjust(self.ds.assign(sim=sim), interp=interp, extrapolation=extrapolation, detrend=detrend,
-                             group=self.group, kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh,
-                             max_tail_factor=self.max_tail_factor)
+        # (.scen is all that is kept, like the reference: the block function is told so and need not write the trend array)
+        out = dqm_adjust(self.ds.assign(sim=sim), interp=interp, extrapolation=extrapolation, detrend=detrend,
+                         group=self.group, kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh,
+                         max_tail_factor=self.max_tail_factor, _outputs=("scen",))
         scen = out["scen"]
         scen.attrs["units"] = sim.attrs.get("units", "")  # "Detrending needs units." (adjustment.py:669-670)
         return scen
@@ -279,7 +277,8 @@ class QuantileDeltaMapping(EmpiricalQuantileMapping):
     def _adjust(self, sim, interp="nearest", extrapolation="constant", rank_window=None):
         out = qdm_adjust(self.ds.assign(sim=sim), group=self.group, interp=interp, extrapolation=extrapolation,
                          kind=self.kind, adapt_freq_thresh=self.adapt_freq_thresh, rank_window=rank_window,
-                         max_tail_factor=self.max_tail_factor)
+                         max_tail_factor=self.max_tail_factor,
+                         _outputs=("scen", "sim_q") if OPTIONS[EXTRA_OUTPUT] else ("scen",))  # (sim_q: float64, twice the size of sim)
         if OPTIONS[EXTRA_OUTPUT]:
             out["sim_q"].attrs.update(long_name="Group-wise quantiles of `sim`.")
             return out

@@ -74,20 +74,40 @@ def init_comm(ctx, rank: int, world: int, token_file: str | None = None) -> None
         else:
             if not token_file:
                 raise ValueError("init_comm needs torch.distributed to be initialised or a token_file shared by the ranks")
+            # A token left by an earlier job (or an earlier init_comm of this one) must never be taken for this one's: rank 0
+            # removes whatever is there before it writes, the others accept only a complete file written after they started
+            # waiting, and rank 0 removes the file once every rank has had time to join (comm_init returns when all have).
             if rank == 0:
+                try:
+                    os.unlink(token_file)
+                except FileNotFoundError:
+                    pass
                 tmp = f"{token_file}.{os.getpid()}.tmp"
                 with open(tmp, "wb") as f:
                     f.write(bytes(buf.raw))
                 os.replace(tmp, token_file)
             else:
                 t0 = time.time()
-                while not os.path.exists(token_file):
+                while True:
+                    try:
+                        st = os.stat(token_file)
+                        if st.st_size == COMM_ID_BYTES and st.st_mtime >= t0 - 1.0:
+                            with open(token_file, "rb") as f:
+                                raw = f.read(COMM_ID_BYTES)
+                            if len(raw) == COMM_ID_BYTES:
+                                buf.raw = raw
+                                break
+                    except FileNotFoundError:
+                        pass
                     if time.time() - t0 > 120:
-                        raise TimeoutError(f"no RCCL token at {token_file}")
+                        raise TimeoutError(f"no fresh RCCL token at {token_file} (a file older than this call is ignored)")
                     time.sleep(0.01)
-                with open(token_file, "rb") as f:
-                    buf.raw = f.read(COMM_ID_BYTES)
     check(load().xsdba_hip_comm_init(ctx.handle, buf, C.c_int(rank), C.c_int(world)), "comm_init")
+    if world > 1 and dist is None and rank == 0:
+        try:
+            os.unlink(token_file)  # every rank has joined: the token has served
+        except OSError:
+            pass
 
 
 def comm_info(ctx) -> tuple[int, int]:
