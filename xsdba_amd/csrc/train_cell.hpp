@@ -203,26 +203,34 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
             {   // transposed scan: thread j owns digit d = j>>6 of threads 16*chunk .. 16*chunk+15
                 const int d = tid >> 6, chunk = tid & 63;
+                // a last pass over fewer than four bits has fewer than sixteen digits: the waves of the digits that cannot occur
+                // (a wave per digit) neither read the counters nor write base rows nobody will look at
+                const int bits_here = min(4, nbits - shift), nd = 1 << bits_here;
+                const bool live = d < nd;  // (wave-uniform)
                 const uint32_t *arrp = d < 8 ? cntlo : cnthi;
                 const int sh = 4 * (d & 7);
                 int run = 0;
                 uint16_t pre[16];
+                if (live) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    int th = 16 * chunk + k;
-                    int cdig = (int)((arrp[th + (th >> 4)] >> sh) & 15u);
-                    pre[k] = (uint16_t)run;
-                    run += cdig;
+                    for (int k = 0; k < 16; k++) {
+                        int th = 16 * chunk + k;
+                        int cdig = (int)((arrp[th + (th >> 4)] >> sh) & 15u);
+                        pre[k] = (uint16_t)run;
+                        run += cdig;
+                    }
                 }
                 int incl = wave_incl_scan(run);
                 if (lane == 63) red[wid] = (uint32_t)incl;
                 __syncthreads();
                 const int woff = waves_before(red, lane, wid);
                 const int off = woff + incl - run;
+                if (live) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    int th = 16 * chunk + k;
-                    base[d * BS + th + 2 * (th >> 4)] = (uint16_t)(off + pre[k]);
+                    for (int k = 0; k < 16; k++) {
+                        int th = 16 * chunk + k;
+                        base[d * BS + th + 2 * (th >> 4)] = (uint16_t)(off + pre[k]);
+                    }
                 }
             }
             __syncthreads();
