@@ -73,6 +73,41 @@ __device__ __forceinline__ int waves_before(const uint32_t *tot, int lane, int w
 
 __device__ __forceinline__ void lds_wave_fence() { __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// NW words (NW even) from an 8-byte aligned LDS address as ds_read_b64 + their wait, in ONE asm statement: left to itself the
+// compiler fuses neighbouring reads into ds_read2_b32 / ds_read2_b64, which take four times the LDS cycles of ds_read_b64 on
+// gfx950 (scripts/ubench/issue_rate.hip: 27 vs 6.8 cycles per wave-instruction at a lane stride of 24 bytes).
+template <int NW> __device__ __forceinline__ void lds_read_words64(const uint32_t *p, uint32_t (&w)[NW])
+{
+    static_assert(NW == 2 || NW == 4 || NW == 6 || NW == 8 || NW == 16, "1 to 4, or 8, ds_read_b64");
+    const uint32_t a = (uint32_t)(uintptr_t)p;  // (an LDS pointer: the low half of the flat address is the LDS offset)
+    uint64_t v0, v1, v2, v3;
+    if constexpr (NW == 2) __asm__ volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0) : "v"(a) : "memory");
+    if constexpr (NW == 4) __asm__ volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a) : "memory");
+    if constexpr (NW == 6)
+        __asm__ volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a) : "memory");
+    if constexpr (NW == 8)
+        __asm__ volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
+    if constexpr (NW == 16) {
+        uint64_t v4, v5, v6, v7;
+        __asm__ volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                         "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7) : "v"(a) : "memory");
+        const uint64_t vv[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+#pragma unroll
+        for (int i = 0; i < 8; i++) { w[2 * i] = (uint32_t)vv[i]; w[2 * i + 1] = (uint32_t)(vv[i] >> 32); }
+        return;
+    }
+    w[0] = (uint32_t)v0; w[1] = (uint32_t)(v0 >> 32);
+    if constexpr (NW >= 4) { w[2] = (uint32_t)v1; w[3] = (uint32_t)(v1 >> 32); }
+    if constexpr (NW >= 6) { w[4] = (uint32_t)v2; w[5] = (uint32_t)(v2 >> 32); }
+    if constexpr (NW >= 8) { w[6] = (uint32_t)v3; w[7] = (uint32_t)(v3 >> 32); }
+}
+
+
+
 template <int EPT> struct CellCfg {
     static constexpr int NT = 1024;
     static constexpr int TPAD = EPT * NT;
@@ -80,8 +115,9 @@ template <int EPT> struct CellCfg {
     static constexpr int WPL = (NWORDS + 63) / 64;  // bit-vector words per lane
     static constexpr int BITW = WPL * 64;
     static constexpr int NWAVE = NT / 64;
-    static constexpr int CNTN = NT + NT / 16;        // padded per-thread counter arrays (stride 17 dwords per 16)
-    static constexpr int BS = NT + 2 * (NT / 16);    // padded base row (u16 units)
+    static constexpr int CNTN = NT + 2 * (NT / 16);  // padded per-thread counter arrays: 18 dwords per 16 threads (8-byte
+                                                     // aligned chunks, conflict-free as ds_read_b64 at a lane stride of 72 bytes)
+    static constexpr int BS = NT + 8 * (NT / 16);    // padded base row (u16 units): 24 per 16 threads (16-byte aligned chunks)
     static constexpr size_t off_keys = 0;
     static constexpr size_t off_idx0 = off_keys + (size_t)TPAD * 4;
     static constexpr size_t off_idx1 = off_idx0 + (size_t)TPAD * 2;
@@ -196,47 +232,63 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 lrs |= ((cnt >> (4 * d)) & 15ull) << (4 * e);  // rank among this thread's earlier equal digits
                 cnt += 1ull << (4 * d);
             }
-            const int pi = tid + (tid >> 4);
+            const int pi = tid + 2 * (tid >> 4);
             cntlo[pi] = (uint32_t)cnt;
             cnthi[pi] = (uint32_t)(cnt >> 32);
             __syncthreads();
             if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
-            {   // transposed scan: thread j owns digit d = j>>6 of threads 16*chunk .. 16*chunk+15
-                const int d = tid >> 6, chunk = tid & 63;
-                // a last pass over fewer than four bits has fewer than sixteen digits: the waves of the digits that cannot occur
-                // (a wave per digit) neither read the counters nor write base rows nobody will look at
+            {   // transposed scan: wave w owns the digits 2w and 2w + 1 (the two nibbles of one byte of the counter words), lane
+                // `chunk` the threads 16*chunk .. 16*chunk+15: both running counts ride in one register, 16 bits each
+                // (a count is at most TPAD < 2^16).  Eight waves do the reading for sixteen digits — every counter word is read by
+                // four threads instead of eight —, and a last pass over fewer than four bits keeps still fewer waves busy: the
+                // waves of digits that cannot occur neither read the counters nor write base rows nobody will look at.
+                const int w2 = tid >> 6, chunk = tid & 63;
                 const int bits_here = min(4, nbits - shift), nd = 1 << bits_here;
-                const bool live = d < nd;  // (wave-uniform)
-                const uint32_t *arrp = d < 8 ? cntlo : cnthi;
-                const int sh = 4 * (d & 7);
-                int run = 0;
-                uint16_t pre[16];
+                const bool live = 2 * w2 < nd;  // (wave-uniform; nd is even)
+                const uint32_t *arrp = w2 < 4 ? cntlo : cnthi;
+                const int sh = 8 * (w2 & 3);
+                uint32_t run = 0u;  // digit 2w in the low half, 2w + 1 in the high half
+                uint32_t pre[16];
                 if (live) {
+                    // the chunk's 16 counter words in eight 8-byte reads (left to itself the compiler emits ds_read2_b32)
+                    uint32_t cw[16];
+                    lds_read_words64<16>(arrp + 18 * chunk, cw);
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
-                        int th = 16 * chunk + k;
-                        int cdig = (int)((arrp[th + (th >> 4)] >> sh) & 15u);
-                        pre[k] = (uint16_t)run;
-                        run += cdig;
+                        const uint32_t b = cw[k] >> sh;
+                        pre[k] = run;
+                        run += (b & 15u) | ((b & 0xF0u) << 12);
                     }
                 }
-                int incl = wave_incl_scan(run);
-                if (lane == 63) red[wid] = (uint32_t)incl;
+                const uint32_t incl = (uint32_t)wave_incl_scan((int)run);
+                if (lane == 63) red[wid] = incl;
                 __syncthreads();
-                const int woff = waves_before(red, lane, wid);
-                const int off = woff + incl - run;
+                // digits before 2w: both halves of the packed totals of the waves before this one; before 2w + 1: + this wave's 2w
+                const uint32_t wb = (uint32_t)waves_before(red, lane, wid);
+                const uint32_t tot_here = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t off0 = (wb & 0xFFFFu) + (wb >> 16), off1 = off0 + (tot_here & 0xFFFFu);
+                const uint32_t ex = incl - run;
+                const uint32_t b0 = off0 + (ex & 0xFFFFu), b1 = off1 + (ex >> 16);
                 if (live) {
+                    // the chunk's 16 bases of either digit: 32 contiguous bytes, 16-byte aligned -> two 16-byte stores each
+                    uint32_t pk0[8], pk1[8];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        int th = 16 * chunk + k;
-                        base[d * BS + th + 2 * (th >> 4)] = (uint16_t)(off + pre[k]);
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t a = pre[2 * k], c = pre[2 * k + 1];
+                        pk0[k] = ((b0 + (a & 0xFFFFu)) & 0xFFFFu) | ((b0 + (c & 0xFFFFu)) << 16);
+                        pk1[k] = ((b1 + (a >> 16)) & 0xFFFFu) | ((b1 + (c >> 16)) << 16);
                     }
+                    uint4 *d0 = reinterpret_cast<uint4 *>(base + (2 * w2) * BS + 24 * chunk), *d1 = reinterpret_cast<uint4 *>(base + (2 * w2 + 1) * BS + 24 * chunk);
+                    d0[0] = make_uint4(pk0[0], pk0[1], pk0[2], pk0[3]);
+                    d0[1] = make_uint4(pk0[4], pk0[5], pk0[6], pk0[7]);
+                    d1[0] = make_uint4(pk1[0], pk1[1], pk1[2], pk1[3]);
+                    d1[1] = make_uint4(pk1[4], pk1[5], pk1[6], pk1[7]);
                 }
             }
             __syncthreads();
             if constexpr (XS_SORT_STOP == 5) { if (p == 0) return idx1; }
             {
-                const int pb = tid + 2 * (tid >> 4);
+                const int pb = tid + 8 * (tid >> 4);
                 // stop_after == 3: the last pass also leaves rank[time step] in the buffer it read from (every thread took its
                 // indexes out of it before the first barrier of the pass) — no separate pass over the sorted order afterwards
                 const bool fuse_rank = stop_after == 3 && p == npass_rest - 1;

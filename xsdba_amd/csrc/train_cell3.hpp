@@ -31,28 +31,6 @@ template <int EPT> struct CellCfg3 {
     static constexpr size_t lds_bytes = off_lut + 256 * 4;
 };
 
-// NW words (NW even) from an 8-byte aligned LDS address as ds_read_b64 + their wait, in ONE asm statement: left to itself the
-// compiler fuses neighbouring reads into ds_read2_b32 / ds_read2_b64, which take four times the LDS cycles of ds_read_b64 on
-// gfx950 (scripts/ubench/issue_rate.hip: 27 vs 6.8 cycles per wave-instruction at a lane stride of 24 bytes).
-template <int NW> __device__ __forceinline__ void lds_read_words64(const uint32_t *p, uint32_t (&w)[NW])
-{
-    static_assert(NW == 2 || NW == 4 || NW == 6 || NW == 8, "1 to 4 ds_read_b64");
-    const uint32_t a = (uint32_t)(uintptr_t)p;  // (an LDS pointer: the low half of the flat address is the LDS offset)
-    uint64_t v0, v1, v2, v3;
-    if constexpr (NW == 2) __asm__ volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0) : "v"(a) : "memory");
-    if constexpr (NW == 4) __asm__ volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a) : "memory");
-    if constexpr (NW == 6)
-        __asm__ volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(a) : "memory");
-    if constexpr (NW == 8)
-        __asm__ volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\tds_read_b64 %2, %4 offset:16\n\tds_read_b64 %3, %4 offset:24\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a) : "memory");
-    w[0] = (uint32_t)v0; w[1] = (uint32_t)(v0 >> 32);
-    if constexpr (NW >= 4) { w[2] = (uint32_t)v1; w[3] = (uint32_t)(v1 >> 32); }
-    if constexpr (NW >= 6) { w[4] = (uint32_t)v2; w[5] = (uint32_t)(v2 >> 32); }
-    if constexpr (NW >= 8) { w[6] = (uint32_t)v3; w[7] = (uint32_t)(v3 >> 32); }
-}
-
 // the same words of three vectors `stride` bytes apart (the recount of the three streams): 3 * NW / 2 reads, one wait
 template <int NW, int STRIDE> __device__ __forceinline__ void lds_read_words64x3(const uint32_t *p, uint32_t (&wa)[NW], uint32_t (&wb)[NW], uint32_t (&wc)[NW])
 {
