@@ -377,10 +377,37 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
 }
 
 // ---- series staging: any (host|device, strides) -> cell-major contiguous device view ---------------
+template <typename K> int set_lds(K kernel, size_t bytes, xsdba_hip_ctx *ctx, const char *what);
+
 template <typename E>
 int launch_transpose(xsdba_hip_ctx *ctx, const E *src, int64_t rows, int64_t cols, int64_t srs, int64_t scs, E *dst,
-                     int64_t drs, int64_t dcs)
+                     int64_t drs, int64_t dcs, bool to_cell_major = false)
 {
+    if (scs == 1 && srs == cols && drs == 1 && dcs == rows && rows >= 64 && cols >= 64) {
+        // both sides dense: the large-tile kernel; the tile is long along the side whose rows are not line-aligned (a cell's
+        // series), which is `rows` for an input (time-major -> cell-major) and `cols` for an output
+        LaunchScope ls(ctx, "k_transpose_dense");
+        if (to_cell_major) {
+            constexpr int TR = 256, TC = 64, NT = 512;
+            auto kern = xs::k_transpose_dense<E, TR, TC, NT>;
+            const size_t lds = (size_t)TR * (TC + 1) * sizeof(E);
+            dim3 grid((unsigned)((cols + TC - 1) / TC), (unsigned)((rows + TR - 1) / TR));
+            if (grid.y > 65535u) return fail(XSDBA_E_ARG, "series too long for the layout kernel");
+            int rc = set_lds(kern, lds, ctx, "k_transpose_dense");
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, src, rows, cols, dst);
+        } else {
+            constexpr int TR = 128, TC = 128, NT = 1024;
+            auto kern = xs::k_transpose_dense<E, TR, TC, NT>;
+            const size_t lds = (size_t)TR * (TC + 1) * sizeof(E);
+            dim3 grid((unsigned)((cols + TC - 1) / TC), (unsigned)((rows + TR - 1) / TR));
+            if (grid.y > 65535u) return fail(XSDBA_E_ARG, "too many cells for the layout kernel");
+            int rc = set_lds(kern, lds, ctx, "k_transpose_dense");
+            if (rc) return rc;
+            hipLaunchKernelGGL(kern, grid, dim3(NT), lds, ctx->stream, src, rows, cols, dst);
+        }
+        return check_launch("k_transpose_dense");
+    }
     dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
     if (grid.y > 65535u) return fail(XSDBA_E_ARG, "series too long for the layout kernel");
     LaunchScope ls(ctx, "k_transpose_tile");
@@ -411,7 +438,7 @@ int series_in(xsdba_hip_ctx *ctx, int slot_raw, int slot_cm, const void *x, int6
     void *cm;
     if ((rc = ensure(ctx, slot_cm, nbytes, &cm))) return rc;
     // rows = time (r), cols = cell (cc): src[t*st + c*sc] -> dst[c*T + t]
-    if ((rc = launch_transpose<R>(ctx, (const R *)d, T, C, st, sc, (R *)cm, 1, T))) return rc;
+    if ((rc = launch_transpose<R>(ctx, (const R *)d, T, C, st, sc, (R *)cm, 1, T, true))) return rc;
     out->dev = cm; out->st = 1; out->sc = T;
     return 0;
 }
@@ -447,7 +474,7 @@ template <typename E> int series_out_end(xsdba_hip_ctx *ctx, SeriesOut *o, int64
     if (!o->user) return 0;
     int rc;
     if (o->need_layout)  // rows = cell, cols = time: src[c*T + t] -> dst[c*osc + t*ost]
-        if ((rc = launch_transpose<E>(ctx, (const E *)o->kernel_dst, C, T, T, 1, (E *)o->dev_final, o->osc, o->ost))) return rc;
+        if ((rc = launch_transpose<E>(ctx, (const E *)o->kernel_dst, C, T, T, 1, (E *)o->dev_final, o->osc, o->ost, false))) return rc;
     if (o->copy_back) HIP_TRY(hipMemcpyAsync(o->user, o->dev_final, o->nbytes, hipMemcpyDeviceToHost, ctx->stream));
     return 0;
 }

@@ -1018,6 +1018,46 @@ __global__ void k_transpose_tile(const E *__restrict__ src, int64_t rows, int64_
     }
 }
 
+// The dense case of the layout change, src[rows][cols] -> dst[cols][rows], both contiguous: a tile of TR rows x TC columns per
+// block of NT threads; a wave issues every load of its TR / (NT/64) rows before the first LDS store, and writes each column
+// as TR / 64 pieces of 256 contiguous bytes.  Measured on 10 950 x 64 800 float32 (profiles/r03_transpose_tiles.txt):
+// time-major -> cell-major 1.36 ms with <256, 64, 512> (the 64 x 64 tile above: 1.65-1.76 ms; the long run per cell matters
+// because a cell's 43 800-byte row is not line-aligned); cell-major -> time-major 1.09 ms with <128, 128, 1024> (1.33 ms);
+// a plain float4 copy of the same bytes takes 1.15-1.24 ms.
+template <typename E, int TR, int TC, int NT>
+__global__ __launch_bounds__(NT) void k_transpose_dense(const E *__restrict__ src, int64_t rows, int64_t cols, E *__restrict__ dst)
+{
+    extern __shared__ __align__(16) unsigned char xs_tr_smem[];
+    E *tile = reinterpret_cast<E *>(xs_tr_smem);  // [TR][TC + 1]
+    constexpr int LD = TC + 1, NW = NT / 64, PER = TR / NW, H = TC / 64, HT = TR / 64, PERC = TC / NW;
+    static_assert(TR % 64 == 0 && TC % 64 == 0 && TR % NW == 0 && TC % NW == 0, "tile shape");
+    const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    E v[PER][H];
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+        for (int h = 0; h < H; h++) {
+            const int64_t r = r0 + wave + i * NW, c = c0 + h * 64 + lane;
+            v[i][h] = (r < rows && c < cols) ? src[r * cols + c] : E(0);
+        }
+#pragma unroll
+    for (int i = 0; i < PER; i++)
+#pragma unroll
+        for (int h = 0; h < H; h++) tile[(wave + i * NW) * LD + h * 64 + lane] = v[i][h];
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < PERC; jj++) {
+        const int j = wave + jj * NW;
+        const int64_t c = c0 + j;
+#pragma unroll
+        for (int h = 0; h < HT; h++) {
+            const int64_t r = r0 + h * 64 + lane;
+            if (r < rows && c < cols) dst[c * rows + r] = tile[(h * 64 + lane) * LD + j];
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // synthetic cubes for bench.py / tests: counter-based, value = f(seed, array, cell, t), so any
 // cell block can be regenerated independently on any rank.  generator 0: seasonal temperature-like
