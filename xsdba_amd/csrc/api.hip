@@ -69,6 +69,7 @@ struct Plan {
     int *d_row_sorted = nullptr, *d_tog_ptr = nullptr, *d_tog_idx = nullptr;
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
     int *d_tog64p = nullptr;  // the same table for k_train_cell3: no -1 entries (see get_plan)
+    int *d_tog128 = nullptr;  // [G][128] padded toggle table of the long series (k_train_long) when every list has <= 128 entries
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     bool has_ungrouped = false;  // some time step belongs to no group
 };
@@ -238,6 +239,7 @@ void free_plan(Plan *p)
     (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
     if (p->d_tog64) (void)hipFree(p->d_tog64);
     if (p->d_tog64p) (void)hipFree(p->d_tog64p);
+    if (p->d_tog128) (void)hipFree(p->d_tog128);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
 }
 
@@ -347,6 +349,14 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
                 for (int j = n, e = 0; j + 1 < 64 && e < n; j += 2, e++) row[j] = row[j + 1] = tog_idx[(size_t)b + e];
             }
             if ((rc = upload_ints(ctx, t64p, &pl->d_tog64p))) return rc;
+        }
+        if (maxlen <= 128 && T > 11 * 1024 && T <= xs::LongCfg::TPAD) {
+            // k_train_long's series: 31 to 61 years of daily steps toggle up to ~124 steps per day-of-year group; the padded
+            // table is one independent load per 64 entries, a step ahead, where the CSR lists cost a pointer chase per step
+            std::vector<int> t128((size_t)G * 128, -1);
+            for (int i = 0; i + 1 < G; i++)
+                std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t128.begin() + (size_t)(i + 1) * 128);
+            if ((rc = upload_ints(ctx, t128, &pl->d_tog128))) return rc;
         }
     }
     if (G > 1 && pl->max_mem <= 32 && T < 65535) {
@@ -679,7 +689,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 hipLaunchKernelGGL((xs::k_train_long<DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
-                                   flag_count, flag_list, C, pl->d_tog64, (unsigned char *)scratch,
+                                   flag_count, flag_list, C, pl->d_tog128, (unsigned char *)scratch,
 #ifdef XSDBA_DIAG
                                    getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
 #else
@@ -689,8 +699,8 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             };
             using std::false_type;
             using std::true_type;
-            rc = mode == 2 ? (pl->d_tog64 ? go(true_type{}, true_type{}) : go(true_type{}, false_type{}))
-                           : (pl->d_tog64 ? go(false_type{}, true_type{}) : go(false_type{}, false_type{}));
+            rc = mode == 2 ? (pl->d_tog128 ? go(true_type{}, true_type{}) : go(true_type{}, false_type{}))
+                           : (pl->d_tog128 ? go(false_type{}, true_type{}) : go(false_type{}, false_type{}));
             if (rc) return rc;
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
             fast = true;

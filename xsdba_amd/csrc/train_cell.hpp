@@ -463,6 +463,11 @@ struct LdsVals {
 // Phase C of the per-cell training kernels: the quantiles of every group of one series from rank[] (LDS, rank of each
 // time step in the sorted order, >= nvalid for NaN) — membership bit-vectors in rank space + select.
 // Geo: TPAD / WPL / BITW / NWAVE of the vectors.  Called by all 1024 threads; no block-level barrier inside.
+// the padded toggle table a geometry walks has 64 * togn_of<Geo>() columns (Geo::TOGN when the geometry names it: the long
+// series of train_long.hpp toggle up to 128 steps per group)
+template <typename Geo, typename = void> struct togn_of { static constexpr int value = 1; };
+template <typename Geo> struct togn_of<Geo, std::void_t<decltype(Geo::TOGN)>> { static constexpr int value = Geo::TOGN; };
+
 template <typename Geo, bool DIAG, bool DQM, bool TOG64, typename Vals, typename Stamp>
 __device__ __forceinline__ void cell_group_quantiles(
     const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid, int lane, int wid,
@@ -506,10 +511,15 @@ __device__ __forceinline__ void cell_group_quantiles(
         // "list r" is the symmetric difference of rows r-1 and r: row r of the padded [G][64] table tog64 (when every
         // list has <= 64 entries, e.g. doy windows: one independent vector load, no pointer chase through SMEM), else
         // tog_idx[tog_ptr[r-1] .. tog_ptr[r])
-        int preA = -1, preA_len = 0, preA_base = 0, preB = -1, preB_len = 0, preB_base = 0;
-        auto load_list = [&](int r, int &pre, int &base, int &len) {
-            if (TOG64) pre = tog64[(size_t)r * 64 + lane];
-            else { base = tog_ptr[r - 1]; len = tog_ptr[r] - base; pre = lane < len ? tog_idx[base + lane] : -1; }
+        constexpr int TOGN = TOG64 ? togn_of<Geo>::value : 1;
+        int preA[TOGN], preB[TOGN], preA_len = 0, preA_base = 0, preB_len = 0, preB_base = 0;
+#pragma unroll
+        for (int u = 0; u < TOGN; u++) preA[u] = preB[u] = -1;
+        auto load_list = [&](int r, int (&pre)[TOGN], int &base, int &len) {
+            if (TOG64) {
+#pragma unroll
+                for (int u = 0; u < TOGN; u++) pre[u] = tog64[(size_t)r * (64 * TOGN) + 64 * u + lane];
+            } else { base = tog_ptr[r - 1]; len = tog_ptr[r] - base; pre[0] = lane < len ? tog_idx[base + lane] : -1; }
         };
         if (cntA > 1) load_list(gc + 1, preA, preA_base, preA_len);  // A, it = 1: gc -> gc+1
         if (cntB > 0) load_list(gc, preB, preB_base, preB_len);      // B, it = 0: gc -> gc-1
@@ -562,11 +572,14 @@ __device__ __forceinline__ void cell_group_quantiles(
                 // wait for tA/tB then never covers the loads just issued.  A: list gA (gA-1 -> gA), none for its
                 // first group; B: list gB+1 (gB+1 -> gB)
                 const bool doA = it > 0;
-                const int tA = doA ? preA : -1, tB = vB ? preB : -1;
+                int tA[TOGN], tB[TOGN], rA[TOGN], rB[TOGN];
+#pragma unroll
+                for (int u = 0; u < TOGN; u++) { tA[u] = doA ? preA[u] : -1; tB[u] = vB ? preB[u] : -1; }
                 const int lenA = doA ? preA_len : 0, lenB = vB ? preB_len : 0, lbA = preA_base, lbB = preB_base;
-                const int rA = tA >= 0 ? (int)rank[tA] : 0x7FFFFFFF, rB = tB >= 0 ? (int)rank[tB] : 0x7FFFFFFF;
-                flip(bitsA, tA, rA, dlocA);
-                flip(bitsB, tB, rB, dlocB);
+#pragma unroll
+                for (int u = 0; u < TOGN; u++) { rA[u] = tA[u] >= 0 ? (int)rank[tA[u]] : 0x7FFFFFFF; rB[u] = tB[u] >= 0 ? (int)rank[tB[u]] : 0x7FFFFFFF; }
+#pragma unroll
+                for (int u = 0; u < TOGN; u++) { flip(bitsA, tA[u], rA[u], dlocA); flip(bitsB, tB[u], rB[u], dlocB); }
                 if (it + 1 < cntA) load_list(gA + 1, preA, preA_base, preA_len);
                 if (it + 1 < cntB) load_list(gB, preB, preB_base, preB_len);
                 if (!TOG64) {  // lists longer than 64 entries (coarse groups)

@@ -19,6 +19,7 @@ struct LongCfg {
     using H = CellCfg<11>;
     static constexpr int NT = 1024, HALF = H::TPAD, TPAD = 2 * HALF;
     static constexpr int NWORDS = TPAD / 32, WPL = (NWORDS + 63) / 64, BITW = WPL * 64, NWAVE = NT / 64;
+    static constexpr int TOGN = 2;  // the padded toggle table of this geometry: [G][128] (60 years of day-of-year windows: 120 steps)
     // merge view of the LDS: [K0 | K1 | rank]; phase-C view: [2 * NWAVE vectors | rank]
     static constexpr size_t off_k0 = 0, off_k1 = (size_t)HALF * 4, off_rank = (size_t)TPAD * 4;
     static constexpr size_t off_bits = 0;
@@ -55,6 +56,19 @@ struct GlobalValsL2 {
     }
 };
 
+// Phase C behind a call: the walk's register allocation is then its own (inlined, its loops shared the 128 registers of a
+// 1024-thread block with whatever the sorts and the merge keep alive across the cell loop, and spilled in its group loop).
+template <bool DQM, bool TOG64>
+__device__ __attribute__((noinline)) void long_phase_c(const float *x, const uint32_t *by_rank, const uint16_t *rank, uint32_t *bits_all, int nvalid,
+                                                       int lane, int wid, const int *row_ptr, const int *row_sorted, const int *tog_ptr,
+                                                       const int *tog_idx, const int *tog64, int G, const float *q, int Q, int kind, int mode,
+                                                       int arr, int64_t c, float *af, float *out_hq, float *scaling, bool &flag_cell)
+{
+    const GlobalValsL2 vals{x, by_rank};
+    cell_group_quantiles<LongCfg, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q,
+                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, 0, nostamp);
+}
+
 template <bool DQM, bool TOG64>
 __global__ __launch_bounds__(1024) void k_train_long(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
@@ -80,7 +94,6 @@ __global__ __launch_bounds__(1024) void k_train_long(
     const int tid = threadIdx.x, wid = tid >> 6;
     const int Ti = (int)T;
     const int T0 = ((Ti / 2) + 1) & ~1;  // even: the second half keeps the 8-byte alignment of the row
-    auto nostamp = [](int) {};
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const int npass_arr = mode == 0 ? 1 : 2;
         bool flag_cell = false;
@@ -88,22 +101,41 @@ __global__ __launch_bounds__(1024) void k_train_long(
             int lane = tid & 63;
             __asm__ volatile("" : "+v"(lane));
             const float *x = ((mode == 0 || arr == 1) ? x0 : x1) + c * sc;
-            // ---------------- 1. sort each half, park (key, time) in rank order ----------------
+            // ---------------- 1. sort each half ----------------
+            // The first half's keys in rank order are parked in the block's global scratch slice (the second sort needs the
+            // whole LDS), and so are the time steps of both halves in rank order.
+            constexpr int EPH = HALF / NT;
             int nv[2];
             for (int h = 0; h < 2; h++) {
                 const int Th = h ? Ti - T0 : T0;
                 const uint16_t *sorted = cell_load_sort<11>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h], NoLoadHook(), -1, true);
-                if (sorted) {
-                    for (int r = tid; r < HALF; r += NT) {
-                        const int id = sorted[r];
-                        ks[h * HALF + r] = keys[min(id, HALF - 1)];
-                        ts[h * HALF + r] = (uint16_t)id;
+                if (h == 0) {
+                    if (sorted) {
+                        for (int r = tid; r < HALF; r += NT) {
+                            const int id = sorted[r];
+                            ks[r] = keys[min(id, HALF - 1)];
+                            ts[r] = (uint16_t)id;
+                        }
+                    } else {  // a half without a valid value was not sorted: all its steps are NaN steps, in any order
+                        for (int r = tid; r < HALF; r += NT) { ks[r] = 0xFFFFFFFFu; ts[r] = (uint16_t)r; }
                     }
-                } else {  // a half without a valid value was not sorted: all its steps are NaN steps, in any order
-                    for (int r = tid; r < HALF; r += NT) { ks[h * HALF + r] = 0xFFFFFFFFu; ts[h * HALF + r] = (uint16_t)r; }
+                    stores_done();
+                    __syncthreads();  // the next sort overwrites keys / sorted
+                } else {
+                    // the second half's keys go straight to their place of the merge (K1 lies over the index buffers)
+                    uint32_t k1r[EPH];
+#pragma unroll
+                    for (int j = 0; j < EPH; j++) {
+                        const int r = tid + j * NT;
+                        const int id = sorted ? (int)sorted[r] : r;
+                        ts[HALF + r] = (uint16_t)id;
+                        k1r[j] = sorted ? keys[min(id, HALF - 1)] : 0xFFFFFFFFu;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < EPH; j++) K1[tid + j * NT] = k1r[j];
+                    stores_done();
                 }
-                stores_done();
-                __syncthreads();  // the next sort (or the merge) overwrites keys / sorted
             }
             const int nv0 = nv[0], nv1 = nv[1], nvalid = nv0 + nv1;
             if (debug_phase == 1) continue;  // timing aid: the two half sorts only
@@ -124,71 +156,76 @@ __global__ __launch_bounds__(1024) void k_train_long(
                 continue;
             }
             // ---------------- 2. merge: final rank of every time step ----------------
-            for (int r = tid; r < HALF; r += NT) { K0[r] = load_l2(ks + r); K1[r] = load_l2(ks + HALF + r); }
+            for (int r = tid; r < HALF; r += NT) K0[r] = load_l2(ks + r);
             __syncthreads();
+            if (debug_phase == 11) continue;
             {
-                // merge path: thread i produces places [i * EPM, (i + 1) * EPM) of the merged order.  One bisection finds how many
-                // of the first i * EPM keys come from the first half (equal keys: the first half first), then the two runs are
-                // merged sequentially from there: ~EPM steps per thread instead of a 15-step bisection per element.
-                constexpr int EPM = L::TPAD / NT;
-                const int r0 = tid * EPM;
-                int a = 0, b = 0;
-                if (r0 < nvalid) {
-                    int lo = max(0, r0 - nv1), hi = min(r0, nv0);
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (K0[mid] <= K1[r0 - 1 - mid]) lo = mid + 1; else hi = mid;
+                // The final rank of a step = its place in its own half + the number of keys of the other half in front of it
+                // (equal keys: the first half first).  A thread owns 11 consecutive places of a half: two full bisections (14
+                // probes each, independent) place its first and last key in the other half, the nine keys between them are
+                // bisected inside that bracket — about 11 places wide on average, so a handful of probes instead of 14 —, all
+                // nine chains in flight together.  Replaces a merge path whose 22 dependent compare-and-advance steps per
+                // thread cost 13.9 ms per 32 400 cells, and one full bisection per element (6.1 ms): profiles/r03_long_phases.txt.
+                auto place_half = [&](auto hsel, const uint32_t (&own)[EPH], const uint32_t (&id)[EPH]) {
+                    constexpr int h = decltype(hsel)::value;
+                    const uint32_t *Koth1 = (h ? K0 : K1) - 1;  // Koth1[n] = the n-th key of the other half, counted from 1
+                    const int nown = h ? nv1 : nv0, noth = h ? nv0 : nv1, toff = h ? T0 : 0, Th = h ? Ti - T0 : T0;
+                    // before(kk, k): a key kk of the other half sorts in front of the key k of this one
+                    auto before = [](uint32_t kk, uint32_t k) { return h ? kk <= k : kk < k; };
+                    int lo = 0, hi = 0;
+#pragma unroll 1
+                    for (int step = 8192; step; step >>= 1) {
+                        const int nl = lo + step, nh = hi + step;
+                        // (a probe past the other half's valid keys reads some word of the LDS and is discarded)
+                        const uint32_t kl = Koth1[nl], kh = Koth1[nh];
+                        lo = (nl <= noth && before(kl, own[0])) ? nl : lo;
+                        hi = (nh <= noth && before(kh, own[EPH - 1])) ? nh : hi;
                     }
-                    a = lo;
-                    b = r0 - lo;
-                }
-                uint32_t src[EPM / 2];  // where each place came from: position in its half, bit 15 = second half; two per register
+                    int pos[EPH];
 #pragma unroll
-                for (int j = 0; j < EPM / 2; j++) src[j] = 0xFFFFFFFFu;
-                uint32_t k0 = a < nv0 ? K0[a] : 0xFFFFFFFFu, k1 = b < nv1 ? K1[b] : 0xFFFFFFFFu;
+                    for (int j = 0; j < EPH; j++) pos[j] = lo;
+                    pos[EPH - 1] = hi;
+                    const int width = hi - lo;
+#pragma unroll 1
+                    for (int step = 8192; step; step >>= 1) {
+                        if (!__any(step <= width)) continue;  // (wave-uniform)
 #pragma unroll
-                for (int j = 0; j < EPM; j++) {
-                    if (r0 + j < nvalid) {
-                        const bool first = a < nv0 && (b >= nv1 || k0 <= k1);
-                        const uint32_t from = first ? (uint32_t)a : ((uint32_t)b | 0x8000u);
-                        by_rank[r0 + j] = first ? k0 : k1;
-                        src[j / 2] = (j & 1) ? ((src[j / 2] & 0x0000FFFFu) | (from << 16)) : ((src[j / 2] & 0xFFFF0000u) | from);
-                        if (first) { a++; k0 = a < nv0 ? K0[a] : 0xFFFFFFFFu; }
-                        else { b++; k1 = b < nv1 ? K1[b] : 0xFFFFFFFFu; }
+                        for (int j = 1; j < EPH - 1; j++) {
+                            const int np = pos[j] + step;
+                            const uint32_t kk = Koth1[np];
+                            pos[j] = (np <= hi && before(kk, own[j])) ? np : pos[j];
+                        }
                     }
-                }
-                // the time step of every place (its half's sorted index array, parked in L2), all loads in flight together
-                uint16_t id[EPM];
+                    if (debug_phase == 12) { int a_ = 0; for (int j = 0; j < EPH; j++) a_ += pos[j] + (int)id[j]; rank[tid + h * NT] = (uint16_t)a_; return; }  // (timing aid)
 #pragma unroll
-                for (int j = 0; j < EPM; j++) {
-                    const uint32_t from = (src[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
-                    const int h = (from >> 15) & 1, pp = (int)(from & 0x7FFFu);
-                    id[j] = load_l2(ts + h * HALF + min(pp, HALF - 1));
-                }
-#pragma unroll
-                for (int j = 0; j < EPM; j++) {
-                    const uint32_t from = (src[j / 2] >> (16 * (j & 1))) & 0xFFFFu;
-                    if (r0 + j < nvalid) rank[(int)id[j] + ((from & 0x8000u) ? T0 : 0)] = (uint16_t)(r0 + j);
-                }
-                // NaN steps (sorted behind the valid keys of their half): never a member
-                for (int h = 0; h < 2; h++) {
-                    const int Th = h ? Ti - T0 : T0, nh = h ? nv1 : nv0;
-                    for (int pp = nh + tid; pp < HALF; pp += NT) {  // (NaN steps and the padding of the half sort share this tail)
-                        const int idn = load_l2(ts + h * HALF + pp);
-                        if (idn < Th) rank[idn + (h ? T0 : 0)] = 0xFFFFu;
+                    for (int j = 0; j < EPH; j++) {
+                        const int r = tid * EPH + j;
+                        if (r < nown) {
+                            const int fin = r + pos[j];
+                            rank[(int)id[j] + toff] = (uint16_t)fin;
+                            if (debug_phase != 13) by_rank[fin] = own[j];
+                        } else if ((int)id[j] < Th) rank[(int)id[j] + toff] = 0xFFFFu;  // NaN steps: never a member
                     }
+                };
+                {
+                    uint32_t kr[EPH], idr[EPH];
+#pragma unroll
+                    for (int j = 0; j < EPH; j++) { kr[j] = K1[tid * EPH + j]; idr[j] = load_l2(ts + HALF + tid * EPH + j); }
+                    place_half(std::integral_constant<int, 1>{}, kr, idr);
+                }
+                {
+                    uint32_t kr[EPH], idr[EPH];
+#pragma unroll
+                    for (int j = 0; j < EPH; j++) { kr[j] = K0[tid * EPH + j]; idr[j] = load_l2(ts + tid * EPH + j); }
+                    place_half(std::integral_constant<int, 0>{}, kr, idr);
                 }
             }
             stores_done();
             __syncthreads();  // rank[] complete, K0 / K1 dead: the vectors take their place
-            if (debug_phase == 2) continue;  // timing aid: sorts + merge
+            if (debug_phase == 2 || debug_phase == 12 || debug_phase == 13) continue;  // timing aid: sorts + merge
             // ---------------- 3. group quantiles ----------------
-            {
-                const GlobalValsL2 vals{x, by_rank};
-                cell_group_quantiles<L, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr,
-                                                           tog_idx, tog64, G, q, Q, kind, mode, arr, c, af, out_hq, scaling,
-                                                           flag_cell, 0, nostamp);
-            }
+            long_phase_c<DQM, TOG64>(x, by_rank, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q, kind, mode,
+                                     arr, c, af, out_hq, scaling, flag_cell);
             __syncthreads();  // everyone is done with rank[] / the vectors before the next sort reuses the LDS
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
