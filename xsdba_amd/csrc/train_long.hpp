@@ -64,6 +64,7 @@ __device__ __attribute__((noinline)) void long_phase_c(const float *x, const uin
                                                        const int *tog_idx, const int *tog64, int G, const float *q, int Q, int kind, int mode,
                                                        int arr, int64_t c, float *af, float *out_hq, float *scaling, bool &flag_cell)
 {
+    auto nostamp = [](int) {};
     const GlobalValsL2 vals{x, by_rank};
     cell_group_quantiles<LongCfg, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q,
                                                      kind, mode, arr, c, af, out_hq, scaling, flag_cell, 0, nostamp);
