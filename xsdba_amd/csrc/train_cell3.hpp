@@ -236,7 +236,8 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
                                                       int arr, int64_t c, typename Vals::value_type *__restrict__ af,
                                                       typename Vals::value_type *out_hq, typename Vals::value_type *scaling,
                                                       bool &flag_cell, const double *gsum = nullptr, const double *guard = nullptr,
-                                                      int n_time = 0, const uint32_t *lut = nullptr)
+                                                      int n_time = 0, const uint32_t *lut = nullptr,
+                                                      typename Vals::value_type *hqk = nullptr)
 {
     using R = typename Vals::value_type;
     using Cfg = CellCfg3<EPT>;
@@ -351,6 +352,16 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     // this cell's tables (the offsets inside them fit 32 bits: G * Q entries)
     R *const hq_c = out_hq + (size_t)c * G * (size_t)Q, *const af_c = af + (mode == 0 ? (size_t)0 : (size_t)c * G * (size_t)Q);
     const bool ref_pass = mode != 0 && arr != 0;
+    // hqk (eight registers of the caller, alive across both passes of a cell): the hist quantiles this lane forms in the first pass,
+    // for the second pass to form af against — a lane meets the same (group, quantile) at the same step of both passes.  Without
+    // them the second pass reads the whole hist_q table back (20 % on top of the kernel's algorithmic bytes).  A queue rather than
+    // an indexed array (that would live in scratch): pushed at [0] in the first pass, moved up so that step 0 stands at [7],
+    // popped from [7] in the second.  More than eight steps per wave (G > 384): the table is read back.
+    const bool keep = hqk != nullptr && mode != 0 && nA <= 8;  // (wave-uniform)
+    auto hqk_up = [&]() {
+#pragma unroll
+        for (int j = 7; j > 0; j--) hqk[j] = hqk[j - 1];
+    };
     // per-lane walk state: the group of this lane's stream moves by gdir per step, its output slot by gdir * Q
     const int gdir = sid == 1 ? -1 : 1, odir = gdir * Q;
     const int nlim = sid == 0 ? nA : (sid == 1 ? nB : (sid == 2 ? nC : 0));  // steps in which this lane's stream has a group
@@ -430,7 +441,10 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         const bool act = vs && k < Q;
         // the ref pass forms af against the hist quantile written by the first pass: requested here, consumed after the select
         R hq_prev = (R)0;
-        if (ref_pass && act) hq_prev = hq_c[o];
+        if (ref_pass) {
+            if (keep) { hq_prev = hqk[7]; hqk_up(); }
+            else if (act) hq_prev = hq_c[o];
+        }
         R mu = (R)0, inv = (R)0;
         if (DQM && PRESUM) {
             const double gs = gsum[vs && sid < 3 ? g : 0];
@@ -619,11 +633,14 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             if (!ref_pass) hq_c[o] = res;
             else af_c[o] = get_corr<R>(hq_prev, res, kind);
         }
+        if (keep && !ref_pass) { hqk_up(); hqk[0] = res; }
         if (DQM && vs && sid < 3 && k == 0) {
             if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced by the factor in the ref pass
             else scaling[(size_t)c * G + g] = get_corr<R>(scaling[(size_t)c * G + g], mu, kind);
         }
     }
+    if (keep && !ref_pass)
+        for (int s_ = nA; s_ < 8; s_++) hqk_up();  // step 0 to the head of the queue
 }
 
 template <int EPT, bool P10, bool DQM, int STOP = 0>
@@ -649,6 +666,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         const int npass_arr = mode == 0 ? 1 : 2;
         bool flag_cell = false;
+        float hqk[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // the hist quantiles of this lane's steps, kept for the ref pass
         for (int arr = 0; arr < npass_arr; arr++) {
             int lane = tid & 63;
             __asm__ volatile("" : "+v"(lane));
@@ -674,6 +692,8 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
                         float &s_ = scaling[(size_t)c * G + g];
                         s_ = arr == 0 ? nanq : get_corr<float>(s_, nanq, kind);
                     }
+#pragma unroll
+                for (int j = 0; j < 8; j++) hqk[j] = nanq;  // (what the walk of a first pass would have kept)
                 __syncthreads();
                 continue;
             }
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             const LdsVals vals{keys, sorted, TPAD};
             cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM, STOP, true>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
-                                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T, lut);
+                                                                     kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T, lut, hqk);
             __syncthreads();
         }
         const int any = __syncthreads_or(flag_cell ? 1 : 0);
