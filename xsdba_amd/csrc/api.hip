@@ -1182,7 +1182,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
                                    (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, use_tog ? pl->d_row_ptr : pl->d_mem_ptr,
                                    use_tog ? pl->d_row_sorted : pl->d_mem_idx, pl->d_mem_ptr, pl->d_mem_idx, pl->d_tog_ptr,
                                    pl->d_tog_idx, pl->d_tog64, use_tog, interp, extrap, (int)kind, (R *)o.kernel_dst,
-                                   (double *)oq.kernel_dst, flag_count, flag_list, pl->max_mem);
+                                   (double *)oq.kernel_dst, flag_count, flag_list, pl->max_mem, pl->d_mem_t32);
                 return check_launch("k_qdm_cell");
             };
             using std::integral_constant;

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, const int *__restrict__ tog64,
     int use_tog,  // consecutive ranking rows differ by the toggle lists; 0: rows are the (disjoint) exact groups
     int interp, int extrap, int kind, R *__restrict__ scen, double *__restrict__ sim_q,
-    int *__restrict__ flag_count, int *__restrict__ flag_list, int max_mem /* most elements any row ranks */)
+    int *__restrict__ flag_count, int *__restrict__ flag_list, int max_mem /* most elements any row ranks */,
+    const int *__restrict__ mem_t32 /* [16][G] member slots, two 16-bit time steps per word (0xFFFF: none), or null */)
 {
     using Cfg = CellCfg<EPT>;
     using QC = QdmCfg<EPT>;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         // and a row ranks at most 30 elements (30 years of a day-of-year window): the second stream's vectors take the place of the
         // keys, which are dead once the tie bits are formed — what still needs a value reads the series itself
         const bool have_tb = (size_t)(TPAD / 8) <= (size_t)(QC::GMAX - G) * 24;
-        const bool two = have_tb && G >= NWAVE && use_tog && tog64 != nullptr && max_mem <= 30;
+        const bool two = have_tb && G >= NWAVE && use_tog && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
         const QdmSeries<R> ser{sim + c * sc, keys, sorted, two}, ser_lds{sim + c * sc, keys, sorted, false};
         // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):
         // first rank in [0, r] whose value equals the one at r ...
@@ -248,9 +249,10 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 if (nA > 1) preA = tog64[(size_t)(gm + 1) * 64 + lane];        // A, it = 1: gm -> gm + 1
                 if (nB > 0) preB = tog64[(size_t)gm * 64 + lane];              // B, it = 0: gm -> gm - 1
                 auto member_of = [&](int g, bool valid) {                      // the element lane l5 ranks in row g (-1: none)
-                    if (!valid) return -1;
-                    const int b = mem_ptr[g], mlen = mem_ptr[g + 1] - b;
-                    return l5 < mlen ? mem_idx[b + l5] : -1;
+                    // (the slot table: one load, no pointer chase through mem_ptr — that one made every step wait for all its loads)
+                    const uint32_t w = (uint32_t)mem_t32[(size_t)(l5 >> 1) * G + (valid ? g : 0)];
+                    const int t = (int)((w >> (16 * (l5 & 1))) & 0xFFFFu);
+                    return (valid && t != 0xFFFF) ? t : -1;
                 };
                 int memN = member_of(half ? gm - 1 : gm, half ? nB > 0 : true);
                 for (int it = 0; it < nA; it++) {
@@ -263,7 +265,10 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     if (rB < nvalid) (void)__hip_atomic_fetch_xor(&bitsB[rB >> 5], 1u << (rB & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (it + 1 < nA) preA = tog64[(size_t)(gA + 1) * 64 + lane];
                     if (it + 1 < nB) preB = tog64[(size_t)gB * 64 + lane];
-                    const int t = memN;
+                    // (an explicit copy: left to itself the compiler loads the next element into a fresh register and moves it over at
+                    //  the loop's end — behind a wait for every load in flight, which undoes the prefetch of all three lists)
+                    int t;
+                    __asm__ volatile("v_mov_b32 %0, %1" : "=v"(t) : "v"(memN));
                     memN = member_of(half ? gB - 1 : gA + 1, half ? it + 1 < nB : it + 1 < nA);
                     lds_wave_fence();
                     // member counts of both vectors, packed (A low, B high 16 bits): one prefix scan; the per-word prefix tables
@@ -278,32 +283,37 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     const int totp = __builtin_amdgcn_readlane(inclp, 63);
                     const int cntA = totp & 0xFFFF, cntB = (int)((unsigned)totp >> 16);
                     int runp = inclp - clp;
-                    // first / last member of each row: every lane its own words' extremes, the first / last lane that holds any is read
-                    int pfA = 0, plA = 0, pfB = 0, plB = 0;
 #pragma unroll
                     for (int j = 0; j < WPL; j++) {
                         pwA[lane * WPL + j] = (uint16_t)(runp & 0xFFFF);
                         pwB[lane * WPL + j] = (uint16_t)((unsigned)runp >> 16);
                         runp += __popc(wa[j]) + (__popc(wb[j]) << 16);
-                        if (wa[j]) plA = (lane * WPL + j) * 32 + 31 - __clz((int)wa[j]);
-                        if (wb[j]) plB = (lane * WPL + j) * 32 + 31 - __clz((int)wb[j]);
                     }
-#pragma unroll
-                    for (int j = WPL - 1; j >= 0; j--) {
-                        if (wa[j]) pfA = (lane * WPL + j) * 32 + __ffs((int)wa[j]) - 1;
-                        if (wb[j]) pfB = (lane * WPL + j) * 32 + __ffs((int)wb[j]) - 1;
-                    }
+                    // first / last member of each row (the extreme tie counts): lanes 30 / 31 of a half read the words of the first /
+                    // last lane of their stream that holds any member (wave-uniform lane numbers off the ballots) back from the
+                    // LDS and scan them — every lane runs the scan, on broadcast reads, instead of every lane scanning its own
+                    // words of both vectors for the sake of two of them (a quarter of the step's vector instructions)
                     const unsigned long long bmA = __ballot((clp & 0xFFFF) != 0), bmB = __ballot(((unsigned)clp >> 16) != 0u);
-                    const int p0A = bmA ? __builtin_amdgcn_readlane(pfA, __ffsll((long long)bmA) - 1) : 0;
-                    const int p1A = bmA ? __builtin_amdgcn_readlane(plA, 63 - __clzll((long long)bmA)) : 0;
-                    const int p0B = bmB ? __builtin_amdgcn_readlane(pfB, __ffsll((long long)bmB) - 1) : 0;
-                    const int p1B = bmB ? __builtin_amdgcn_readlane(plB, 63 - __clzll((long long)bmB)) : 0;
+                    const int LfA = bmA ? __ffsll((long long)bmA) - 1 : 0, LlA = bmA ? 63 - __clzll((long long)bmA) : 0;
+                    const int LfB = bmB ? __ffsll((long long)bmB) - 1 : 0, LlB = bmB ? 63 - __clzll((long long)bmB) : 0;
+                    const int Lx = l5 == 31 ? (half ? LlB : LlA) : (half ? LfB : LfA);
+                    uint32_t wx[WPL];
+#pragma unroll
+                    for (int j = 0; j < WPL; j++) wx[j] = bits_h[Lx * WPL + j];
+                    int pf = 0, pl = 0;
+#pragma unroll
+                    for (int j = 0; j < WPL; j++)
+                        if (wx[j]) pl = j * 32 + 31 - __clz((int)wx[j]);
+#pragma unroll
+                    for (int j = WPL - 1; j >= 0; j--)
+                        if (wx[j]) pf = j * 32 + __ffs((int)wx[j]) - 1;
+                    const int px = Lx * (WPL * 32) + (l5 == 31 ? pl : pf);
                     lds_wave_fence();
                     // this half's stream: its row's count, its element (lanes 0-29) or the row's first / last member (lanes 30 / 31)
                     const int n = half ? cntB : cntA;
                     const bool vh = half ? vB : true;
                     int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
-                    r = l5 == 30 ? (half ? p0B : p0A) : (l5 == 31 ? (half ? p1B : p1A) : r);
+                    r = l5 >= 30 ? px : r;
                     int bl = 0, bh = 0;
                     if (vh && n > 0 && r < nvalid) {
                         int rs, re;
