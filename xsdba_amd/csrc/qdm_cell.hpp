@@ -216,12 +216,18 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             const int gpc = (G + NWAVE - 1) / NWAVE;
             const int g0 = min(G, wid * gpc), g1 = min(G, g0 + gpc);
             const int nB = (g1 - g0) / 2, nA = (g1 - g0) - nB, gm = g0 + nB;  // nA >= nB
-            uint32_t *bitsA = bits, *bitsB = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys) + wid * BITW;
-            uint16_t *pwA = pw, *pwB = reinterpret_cast<uint16_t *>(smem + Cfg::off_keys + (size_t)NWAVE * BITW * 4) + wid * BITW;
-            static_assert((size_t)NWAVE * BITW * 6 <= (size_t)TPAD * 4, "the second stream's vectors fit in the key array");
+            // LDS: A's vectors where the one-stream walk keeps its own; the per-word prefix counts of both streams packed in one
+            // dword (A low, B high 16 bits: one store per word, one bit-field extract to read) in the key array; B's vectors in
+            // the one-stream walk's prefix tables (waves 0-7) and behind the packed table in the key array (waves 8-15)
+            uint32_t *bitsA = bits;
+            uint32_t *pw2 = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys) + wid * BITW;
+            uint32_t *bitsB = wid < NWAVE / 2 ? reinterpret_cast<uint32_t *>(smem + QC::off_pw) + wid * BITW
+                                              : reinterpret_cast<uint32_t *>(smem + Cfg::off_keys + (size_t)NWAVE * BITW * 4) + (wid - NWAVE / 2) * BITW;
+            static_assert((size_t)NWAVE * BITW * 4 + (size_t)(NWAVE / 2) * BITW * 4 <= (size_t)TPAD * 4, "the packed table and half of B's vectors fit in the key array");
+            static_assert((size_t)(NWAVE / 2) * BITW * 4 <= (size_t)NWAVE * BITW * 2, "the other half of B's vectors fit in the one-stream prefix tables");
             const int half = lane >> 5, l5 = lane & 31;
             const uint32_t *bits_h = half ? bitsB : bitsA;
-            const uint16_t *pw_h = half ? pwB : pwA;
+            const unsigned pwsh = 16u * (unsigned)half;
             if (nA > 0) {
                 for (int i = lane; i < BITW; i += 64) bitsA[i] = 0u;
                 lds_wave_fence();
@@ -285,8 +291,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     int runp = inclp - clp;
 #pragma unroll
                     for (int j = 0; j < WPL; j++) {
-                        pwA[lane * WPL + j] = (uint16_t)(runp & 0xFFFF);
-                        pwB[lane * WPL + j] = (uint16_t)((unsigned)runp >> 16);
+                        pw2[lane * WPL + j] = (uint32_t)runp;
                         runp += __popc(wa[j]) + (__popc(wb[j]) << 16);
                     }
                     // first / last member of each row (the extreme tie counts): lanes 30 / 31 of a half read the words of the first /
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                         int rs, re;
                         tie_run(r, rs, re);
                         const int ws = rs >> 5, we = re >> 5;
-                        bl = (int)pw_h[ws] + __popc(bits_h[ws] & ((1u << (rs & 31)) - 1u));
-                        bh = re >= nvalid ? n : (int)pw_h[we] + __popc(bits_h[we] & ((1u << (re & 31)) - 1u));
+                        bl = (int)((pw2[ws] >> pwsh) & 0xFFFFu) + __popc(bits_h[ws] & ((1u << (rs & 31)) - 1u));
+                        bh = re >= nvalid ? n : (int)((pw2[we] >> pwsh) & 0xFFFFu) + __popc(bits_h[we] & ((1u << (re & 31)) - 1u));
                         if (l5 < 30) r2buf[t] = (uint16_t)(bl + bh + 1);
                     }
                     const int nminA = __builtin_amdgcn_readlane(bh, 30), nmaxA = cntA - __builtin_amdgcn_readlane(bl, 31);
