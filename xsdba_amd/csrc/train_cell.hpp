@@ -143,10 +143,15 @@ template <int EPT> struct CellCfg {
 #ifndef XS_SORT_STOP
 #define XS_SORT_STOP 0  // (scripts/ubench/train3_bench.hip builds with 1..6 to time the sort's phases; the library never does)
 #endif
+// fused (with dgl): the load phase has already counted the valid keys into the first pass's histogram — on the low 14 bits of
+// the KEYS, which are the digits of (key - kmin) when kmin is a multiple of 2^14 (cell_load_sort rounds it down) — and kept
+// every element's digit (dgl: the two elements of load round j, 16 bits each; bit 15 = NaN / padding, whose digit is only
+// known with the range).  The pass then starts at its scan, and its scatter deals the elements out in the load's order.
 template <int EPT>
 __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
                                                               uint32_t kmin, uint32_t range, int stop_after, bool hist_zeroed = false,
-                                                              int nan_rank = -1)
+                                                              int nan_rank = -1, bool fused = false,
+                                                              const uint32_t *dgl = nullptr)
 {
     using Cfg = CellCfg<EPT>;
     constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
@@ -172,22 +177,30 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
                 __syncthreads();
             }
             uint32_t dgp[(EPT + 1) / 2];  // the 14-bit digits of this thread's elements, two per register
+            const uint32_t d_nan = (range + 1u) & (NB1 - 1);  // the digit of NaN / padding keys
+            if (!fused) {
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                uint32_t k = keys[tid * EPT + e];
-                uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
-                uint32_t d = r & (NB1 - 1);
-                if (e & 1) dgp[e >> 1] |= d << 16; else dgp[e >> 1] = d;
-                atomicAdd(&hist[d >> 1], 1u << (16 * (d & 1)));
+                for (int e = 0; e < EPT; e++) {
+                    uint32_t k = keys[tid * EPT + e];
+                    uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
+                    uint32_t d = r & (NB1 - 1);
+                    if (e & 1) dgp[e >> 1] |= d << 16; else dgp[e >> 1] = d;
+                    atomicAdd(&hist[d >> 1], 1u << (16 * (d & 1)));
+                }
+                __syncthreads();
             }
-            __syncthreads();
             if constexpr (XS_SORT_STOP == 1) return idx1;
             {
                 constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
                 uint32_t wv[BPT / 2];
                 int run = 0;
 #pragma unroll
-                for (int i = 0; i < BPT / 2; i++) { wv[i] = hist[tid * (BPT / 2) + i]; run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16); }
+                for (int i = 0; i < BPT / 2; i++) {
+                    wv[i] = hist[tid * (BPT / 2) + i];
+                    // fused: the NaN / padding keys were not counted by the load (their digit needs the range): the owner of their bin adds them
+                    if (fused && (int)(d_nan >> 4) == tid && (int)((d_nan & 15u) >> 1) == i) wv[i] += (uint32_t)(TPAD - nvalid) << (16 * (d_nan & 1u));
+                    run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16);
+                }
                 int incl = wave_incl_scan(run);
                 if (lane == 63) red[wid] = (uint32_t)incl;
                 __syncthreads();
@@ -202,12 +215,28 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             }
             __syncthreads();
             if constexpr (XS_SORT_STOP == 2) return idx1;
+            if (fused) {
 #pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                const uint32_t d = (e & 1) ? (dgp[e >> 1] >> 16) : (dgp[e >> 1] & 0xFFFFu);
-                const int sh = 16 * (d & 1);
-                uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
-                idx1[(old >> sh) & 0xFFFFu] = (uint16_t)(tid * EPT + e);
+                for (int j = 0; j < (EPT + 1) / 2; j++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int i = 2 * tid + j * 2 * NT + h;  // the load's element order
+                        if ((j + 1) * 2 * NT <= TPAD || i < TPAD) {
+                            const uint32_t f = (dgl[j] >> (16 * h)) & 0xFFFFu;
+                            const uint32_t d = (f & 0x8000u) ? d_nan : f;
+                            const int sh = 16 * (d & 1);
+                            uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
+                            idx1[(old >> sh) & 0xFFFFu] = (uint16_t)i;
+                        }
+                    }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPT; e++) {
+                    const uint32_t d = (e & 1) ? (dgp[e >> 1] >> 16) : (dgp[e >> 1] & 0xFFFFu);
+                    const int sh = 16 * (d & 1);
+                    uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
+                    idx1[(old >> sh) & 0xFFFFu] = (uint16_t)(tid * EPT + e);
+                }
             }
             __syncthreads();
         }
@@ -349,6 +378,8 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         // ---------------- A. load, keys, range ----------------
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        bool fused = false;                 // the load has counted the histogram of the sort's first pass
+        uint32_t dgl[(EPT + 1) / 2] = {};   // ... and kept the digits of its elements
         const int Ti = (int)T;  // <= TPAD
         if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
             // all the loads of the series are issued before the first one is consumed (one HBM latency per array
@@ -366,7 +397,10 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
             if constexpr (!Hook::uses_sort_scratch) {  // the histogram of the sort's first pass, cleared while the loads are in flight
                 uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
                 for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+                __syncthreads();  // ... and counted into as the loads arrive (see radix_sort_indexes: fused)
+                fused = true;
             }
+            uint32_t *hist1 = reinterpret_cast<uint32_t *>(smem + Cfg::off_cntlo);
             // keys and their statistics in integer arithmetic (to_key() through compares and selects costs three times the
             // instructions, and selects on VCC stall each other: scripts/ubench/issue_rate.hip): `ok` is all ones for a number
             // and 0 for a NaN; a NaN's key is 0xFFFFFFFF — no effect on the minimum — and it enters the maximum as 0
@@ -390,6 +424,14 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                     }
                     const uint32_t k0 = key_of(a), k1 = key_of(b);
                     *reinterpret_cast<uint2 *>(keys + i) = make_uint2(k0, k1);
+                    if constexpr (!Hook::uses_sort_scratch) {
+                        // the first pass of the sort counts its 14-bit digits here: no second walk over the keys, no barrier of its own
+                        const uint32_t d0 = k0 & 0x3FFFu, d1 = k1 & 0x3FFFu;
+                        const bool n0 = k0 == 0xFFFFFFFFu, n1 = k1 == 0xFFFFFFFFu;
+                        if (!n0) atomicAdd(&hist1[d0 >> 1], 1u << (16 * (d0 & 1u)));
+                        if (!n1) atomicAdd(&hist1[d1 >> 1], 1u << (16 * (d1 & 1u)));
+                        dgl[j] = (n0 ? 0x8000u : d0) | ((n1 ? 0x8000u : d1) << 16);
+                    }
                 }
             }
         } else {
@@ -430,6 +472,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         }
         const int nvalid = nv;
         nvalid_out = nv;
+        if (fused) kmin &= ~0x3FFFu;  // the digits counted by the load are those of (key - kmin) only for such a kmin
         const uint32_t range = nvalid ? kmax - kmin : 0u;  // NaN / padding are remapped to range + 1
         // red[] is next written behind the first barrier of the sort, which no wave passes before every wave has read it here:
         // a barrier of its own only when a hook (or the timing aid's early return) comes in between
@@ -441,7 +484,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         // (wave-uniform) and writes its all-NaN results directly.  keys[] is complete; the barrier protects red[].
         if (skip_empty && nvalid == 0) { __syncthreads(); return nullptr; }
         hook(keys, Ti, tid);
-        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank);
+        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank, fused, dgl);
 }
 
 // Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has
