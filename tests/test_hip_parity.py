@@ -78,6 +78,8 @@ GROUPINGS = {
     "month5": lambda T: (_doy_month(T)[1], 12, 5),
     "doy30_even": lambda T: (_doy_month(T)[0], 365, 30),
 }
+# 40 un-windowed groups of ~T / 40 members: neither k_train_sel (more than 32 groups) nor a padded toggle table (lists of ~T / 20 steps)
+LONG_GROUPINGS = dict(GROUPINGS, week40=lambda T: (((np.arange(T) // 7) % 40).astype(np.int32), 40, 1))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -694,13 +696,14 @@ def test_fast_train_fallback_cells(hip, train_kernel):
             assert_close(af, eaf, rtol=2e-6, atol=2e-4, what=f"dqm af {kind}")
 
 
-@pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5")])
+@pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5"), (15001, "week40")])
 def test_long_series_train(hip, T, gname):
-    """11 265 .. 22 528 steps: the split-sort + merge kernel (k_train_long) — both toggle-table forms, an odd length,
-    the maximum length, NaNs, ties across the two halves, an all-NaN cell; EQM bit-exact, DQM within 2 ulp"""
+    """11 265 .. 22 528 steps: the split-sort + merge kernel (k_train_long) — the padded [G][128] toggle table (doy windows) and
+    the CSR lists (week40: 750 steps per list), an odd length, the maximum length, NaNs, ties across the two halves, an all-NaN
+    cell; EQM bit-exact, DQM within 2 ulp"""
     rng = np.random.default_rng(T)
     C = 3
-    gidx, G, W = GROUPINGS[gname](T)
+    gidx, G, W = LONG_GROUPINGS[gname](T)
     q = _nodes(20)
     for kind in "+*":
         ref, hist, _ = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
