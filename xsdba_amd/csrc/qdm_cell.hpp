@@ -165,14 +165,25 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             gstat[3 * g + 1] = (double)nmin;
             gstat[3 * g + 2] = (double)nmax;
         };
-        for (int i = tid; i < TPAD; i += NT) r2buf[i] = 0;
-        if (have_tb)
-            for (int r0 = 0; r0 < TPAD; r0 += NT) {
-                const int r = r0 + tid;
-                const bool eq = r > 0 && r < nvalid && ser_lds.eq_ranks(r - 1, r);
-                const unsigned long long b = __ballot(eq);
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(r2buf);  // (16-byte aligned: both index buffers are)
+            for (int i = tid; i < TPAD / 8; i += NT) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (have_tb) {
+            // all the index -> key reads of a thread's places first (independent), then the ballots and the stores
+            uint32_t eqm = 0u;
+#pragma unroll
+            for (int j = 0; j < TPAD / NT; j++) {
+                const int r = j * NT + tid;
+                eqm |= (uint32_t)(r > 0 && r < nvalid && ser_lds.eq_ranks(r - 1, r)) << j;
+            }
+#pragma unroll
+            for (int j = 0; j < TPAD / NT; j++) {
+                const int r = j * NT + tid;
+                const unsigned long long b = __ballot((eqm >> j) & 1u);
                 if (lane == 0) { tieb[r >> 5] = (uint32_t)b; tieb[(r >> 5) + 1] = (uint32_t)(b >> 32); }
             }
+        }
         if (tid == 0) gstat[3 * (G / 2)] = 0.0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
         if (af && wid == 0) {
