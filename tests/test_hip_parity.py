@@ -696,6 +696,32 @@ def test_fast_train_fallback_cells(hip, train_kernel):
             assert_close(af, eaf, rtol=2e-6, atol=2e-4, what=f"dqm af {kind}")
 
 
+@pytest.mark.parametrize("Q", [21, 22, 30, 42, 43, 50, 63, 64])
+@pytest.mark.parametrize("T", [3650, 10950])
+def test_train_many_quantile_nodes(hip, Q, T):
+    """22 .. 63 nodes on windowed day-of-year groups: the three-stream kernel serves them in two or three rounds of the select per
+    group step (64 and more: the two-stream kernel); EQM bit-exact, DQM within 2 ulp; NaNs, ties, an all-NaN series"""
+    rng = np.random.default_rng(Q * 100003 + T)
+    C = 3
+    gidx, G, W = GROUPINGS["doy31"](T)
+    q = _nodes(Q)
+    for kind in "+*":
+        ref, hist, _ = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+        hist[0] = np.round(hist[0])
+        if kind == "*":
+            ref[1] = np.nan
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+        assert_close(hq, ehq, rtol=0.0, what=f"hist_q {kind} Q={Q}")
+        assert_close(af, eaf, rtol=0.0, what=f"af {kind} Q={Q}")
+    ref, hist, _ = _synth(rng, C, T, "+", np.float32, nan_frac=0.01)
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, "+")
+    assert_close(sc, esc, rtol=2.4e-7, atol=2e-5, what="scaling")
+    assert_close(hq, ehq, rtol=2.4e-7, atol=1e-4, what="hist_q (dqm)")
+    assert_close(af, eaf, rtol=2.4e-7, atol=1e-4, what="af (dqm)")
+
+
 @pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5"), (15001, "week40")])
 def test_long_series_train(hip, T, gname):
     """11 265 .. 22 528 steps: the split-sort + merge kernel (k_train_long) — the padded [G][128] toggle table (doy windows) and

@@ -632,16 +632,16 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             auto pick_dqm = [&](auto cfg) -> int { return mode == 2 ? pick_t64(cfg, true_type{}) : pick_t64(cfg, false_type{}); };
             // three group streams per wave (train_cell3.hpp): plain / EQM quantiles of up to 21 nodes on windowed day-of-year-like
             // groups (padded toggle table, at least three groups per wave).  XSDBA_HIP_TRAIN3=0 pins the two-stream kernel.
-            auto go3 = [&](auto cfg, auto p10, auto dqm) -> int {
-                constexpr int EPT = decltype(cfg)::value;
+            auto go3 = [&](auto cfg, auto p10, auto dqm, auto nr) -> int {
+                constexpr int EPT = decltype(cfg)::value, NR = decltype(nr)::value;
                 constexpr bool P10 = decltype(p10)::value, DQM = decltype(dqm)::value;
                 const size_t lds = xs::CellCfg3<EPT>::lds_bytes + (DQM ? ((size_t)G + 1) * sizeof(double) : 0);  // + the group sums of dqm_train
                 int rc2;
-                if ((rc2 = set_lds(xs::k_train_cell3<EPT, P10, DQM>, lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_cell3<EPT, P10, DQM, 0, NR>, lds, ctx, "the per-cell sort"))) return rc2;
                 const int gm = getenv("XSDBA_HIP_GRID_MULT") ? atoi(getenv("XSDBA_HIP_GRID_MULT")) : 4;
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, (int64_t)std::max(gm, 1) * ctx->n_cu);
                 LaunchScope ls(ctx, "k_train_cell3");
-                hipLaunchKernelGGL((xs::k_train_cell3<EPT, P10, DQM>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_cell3<EPT, P10, DQM, 0, NR>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, G, (const float *)dq, Q, (int)kind, mode,
                                    (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev, flag_count, flag_list, C, pl->d_tog64p,
                                    pl->d_mem_ptr, pl->d_mem_idx, (8 * (int64_t)G <= T) ? pl->d_mem_t32 : (const int *)nullptr, pl->W);
@@ -651,10 +651,15 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             const size_t lds3 = (ept == 4 ? xs::CellCfg3<4>::lds_bytes : ept == 8 ? xs::CellCfg3<8>::lds_bytes : xs::CellCfg3<11>::lds_bytes) +
                                 (mode == 2 ? ((size_t)G + 1) * sizeof(double) : 0);
             // (T < TPAD: the kernel uses time step T, a padding step of the series in LDS, as the "no toggle" entry of its table)
-            const bool three = !dbg && pl->d_tog64p && Q <= 21 && G >= 48 && T < (int64_t)ept * 1024 && lds3 <= (size_t)ctx->lds_limit &&
-                               !(t3 && !strcmp(t3, "0"));
-            auto pick3d = [&](auto cfg, auto p10) -> int { return mode == 2 ? go3(cfg, p10, true_type{}) : go3(cfg, p10, false_type{}); };
-            auto pick3 = [&](auto cfg) -> int { return pl->max_row <= 1023 ? pick3d(cfg, true_type{}) : pick3d(cfg, false_type{}); };
+            // (22 to 63 nodes: two or three rounds of the select per group step, instantiated for the 10-bit packed counts only)
+            const bool three = !dbg && pl->d_tog64p && (Q <= 21 || (Q <= 63 && pl->max_row <= 1023)) && G >= 48 && T < (int64_t)ept * 1024 &&
+                               lds3 <= (size_t)ctx->lds_limit && !(t3 && !strcmp(t3, "0"));
+            auto pick3d = [&](auto cfg, auto p10, auto nr) -> int { return mode == 2 ? go3(cfg, p10, true_type{}, nr) : go3(cfg, p10, false_type{}, nr); };
+            auto pick3 = [&](auto cfg) -> int {
+                if (Q > 42) return pick3d(cfg, true_type{}, integral_constant<int, 3>{});
+                if (Q > 21) return pick3d(cfg, true_type{}, integral_constant<int, 2>{});
+                return pl->max_row <= 1023 ? pick3d(cfg, true_type{}, integral_constant<int, 1>{}) : pick3d(cfg, false_type{}, integral_constant<int, 1>{});
+            };
             if (three)
                 rc = ept == 4 ? pick3(integral_constant<int, 4>{}) : ept == 8 ? pick3(integral_constant<int, 8>{}) : pick3(integral_constant<int, 11>{});
             else if (dbg && ept == 11 && mode != 2 && pl->d_tog64)  // timing aids (XSDBA_HIP_DEBUG_PHASE): diagnostic build

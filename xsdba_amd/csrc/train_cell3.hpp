@@ -228,7 +228,9 @@ template <int EPT> struct GroupSumHook {
 // 3 = the build of the middle group + copies + fast-forward, 4 = run the loop with toggles / recount / scan but no select.
 // PADT: `tog64` is the table padded with time step n_time instead of -1 (float32 kernel, n_time < TPAD) and rank[] holds NAN_RANK
 // for NaN / padding steps.
-template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false>
+// NR: rounds of the select per group step — a stream's 21 lanes serve quantiles k, k + 21, ... (Q <= 21 NR nodes); everything up
+// to the packed counts is done once per step whatever NR.
+template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false, int NR = 1>
 __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
@@ -347,8 +349,10 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         preB = tog64[(size_t)(1 < nB ? gb - 1 : 0) * 64 + lane];
         preC = tog64[(size_t)(1 < nC ? gc3 + 1 : 0) * 64 + lane];
     }
-    int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case = 3, c_lo = 0;
-    R c_gamma = (R)0;
+    int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case[NR], c_lo[NR];
+    R c_gamma[NR];
+#pragma unroll
+    for (int rd = 0; rd < NR; rd++) { c_case[rd] = 3; c_lo[rd] = 0; c_gamma[rd] = (R)0; }
     // this cell's tables (the offsets inside them fit 32 bits: G * Q entries)
     R *const hq_c = out_hq + (size_t)c * G * (size_t)Q, *const af_c = af + (mode == 0 ? (size_t)0 : (size_t)c * G * (size_t)Q);
     const bool ref_pass = mode != 0 && arr != 0;
@@ -357,7 +361,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     // them the second pass reads the whole hist_q table back (20 % on top of the kernel's algorithmic bytes).  A queue rather than
     // an indexed array (that would live in scratch): pushed at [0] in the first pass, moved up so that step 0 stands at [7],
     // popped from [7] in the second.  More than eight steps per wave (G > 384): the table is read back.
-    const bool keep = hqk != nullptr && mode != 0 && nA <= 8;  // (wave-uniform)
+    const bool keep = NR == 1 && hqk != nullptr && mode != 0 && nA <= 8;  // (wave-uniform)
     auto hqk_up = [&]() {
 #pragma unroll
         for (int j = 7; j > 0; j--) hqk[j] = hqk[j - 1];
@@ -368,7 +372,9 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     int g = sid == 0 ? gb : (sid == 1 ? gb - 1 : gc3);
     int o = g * Q + k;
     const int fsh = (P10 ? 10 : 16) * (sid < 3 ? sid : 0);  // where this stream's field sits in the packed counts
-    int Lprev4 = -1;  // (owner lane of the previous step) * 4, the bpermute address
+    int Lprev4[NR];  // (owner lane of the previous step) * 4, the bpermute address, per round
+#pragma unroll
+    for (int rd = 0; rd < NR; rd++) Lprev4[rd] = -1;
     for (int it = 0; it < nA; it++, g += gdir, o += odir) {
         const bool vB = it < nB, vC = it < nC;
         const int tA = preA, tB = preB, tC = preC;
@@ -438,12 +444,15 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         if constexpr (STOP == 4) { if (cntA + exAB + cntB + cntC == 0x7FFFFFF1) out_hq[0] = (R)1; next_flips(); continue; }
         const int ns = P10 ? (int)__builtin_amdgcn_ubfe((unsigned)totAB, (unsigned)fsh, 10u) : (sid == 0 ? cntA : (sid == 1 ? cntB : cntC));
         const bool vs = it < nlim;
-        const bool act = vs && k < Q;
         // the ref pass forms af against the hist quantile written by the first pass: requested here, consumed after the select
-        R hq_prev = (R)0;
-        if (ref_pass) {
-            if (keep) { hq_prev = hqk[7]; hqk_up(); }
-            else if (act) hq_prev = hq_c[o];
+        R hq_prev[NR];
+#pragma unroll
+        for (int rd = 0; rd < NR; rd++) {
+            hq_prev[rd] = (R)0;
+            if (ref_pass) {
+                if (keep) { hq_prev[rd] = hqk[7]; hqk_up(); }
+                else if (vs && k + QL * rd < Q) hq_prev[rd] = hq_c[o + QL * rd];
+            }
         }
         R mu = (R)0, inv = (R)0;
         if (DQM && PRESUM) {
@@ -484,21 +493,26 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             constexpr double LIM = sizeof(R) == 8 ? 200.0 : 1.0e6;
             if (kind == '*' && !(amax <= LIM * gmin)) flag_cell = true;  // see cell_group_quantiles: rounding of the running sums
         }
+        const bool same_counts = cntA == nA_prev && cntB == nB_prev && cntC == nC_prev;
+        nA_prev = cntA; nB_prev = cntB; nC_prev = cntC;
+#pragma unroll
+        for (int rd = 0; rd < NR; rd++) {
+        const int kr = k + QL * rd;  // this round's quantile of the lane
+        const bool act = vs && kr < Q;
         // quantile-index math depends on (n, k) only: cached while the three streams keep their counts
         int casek, lo;  // 0: general lerp, 1: clamp to a[n-1], 2: clamp to a[0], 3: empty
         R gamma;
-        if (cntA == nA_prev && cntB == nB_prev && cntC == nC_prev) { casek = c_case; lo = c_lo; gamma = c_gamma; }
+        if (same_counts) { casek = c_case[rd]; lo = c_lo[rd]; gamma = c_gamma[rd]; }
         else {
-            const double qk = (double)q[k < Q ? k : 0];
+            const double qk = (double)q[kr < Q ? kr : 0];
             const double vi = (double)ns * qk + (1.0 + qk * (1.0 - 1.0 - 1.0)) - 1.0;
             lo = 0; gamma = (R)0;
             if (ns == 0) casek = 3;
             else if (vi != vi || vi >= (double)(ns - 1)) { casek = 1; lo = ns - 1; }
             else if (vi < 0.0) { casek = 2; lo = 0; }
             else { casek = 0; lo = (int)floor(vi); gamma = (R)(vi - (double)lo); }
-            c_case = casek; c_lo = lo; c_gamma = gamma;
+            c_case[rd] = casek; c_lo[rd] = lo; c_gamma[rd] = gamma;
         }
-        nA_prev = cntA; nB_prev = cntB; nC_prev = cntC;
         // owner lane of member `lo`: the last lane whose exclusive count is <= lo.  Consecutive groups share 900 of 930 members, so
         // the owner is nearly always the previous step's lane or a neighbour: four exclusive counts around it are fetched
         // together (ONE cross-lane latency instead of six dependent ones); a wave in which some lane's owner moved further
@@ -510,16 +524,16 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         };
         int L4 = 0, eL = 0;
         bool miss = true;
-        if (Lprev4 >= 0) {  // (wave-uniform: -1 only in the first step)
-            const int a0 = Lprev4 - 4;  // lanes Lprev - 1 .. Lprev + 2 (the address wraps for Lprev == 0: that count is never used)
+        if (Lprev4[rd] >= 0) {  // (wave-uniform: -1 only in the first step)
+            const int a0 = Lprev4[rd] - 4;  // lanes Lprev - 1 .. Lprev + 2 (the address wraps for Lprev == 0: that count is never used)
             const int e_m = field(__builtin_amdgcn_ds_bpermute(a0, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0, exC));
             const int e_0 = field(__builtin_amdgcn_ds_bpermute(a0 + 4, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 4, exC));
             const int e_1 = field(__builtin_amdgcn_ds_bpermute(a0 + 8, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 8, exC));
             const int e_2 = field(__builtin_amdgcn_ds_bpermute(a0 + 12, exAB), P10 ? 0 : __builtin_amdgcn_ds_bpermute(a0 + 12, exC));
             const bool dn = e_0 > lo, st = e_1 > lo;  // the owner is below Lprev / not above it
-            L4 = dn ? a0 : (st ? Lprev4 : Lprev4 + 4);
+            L4 = dn ? a0 : (st ? Lprev4[rd] : Lprev4[rd] + 4);
             eL = dn ? e_m : (st ? e_0 : e_1);
-            miss = dn ? (e_m > lo || Lprev4 == 0) : (!st && e_2 <= lo);
+            miss = dn ? (e_m > lo || Lprev4[rd] == 0) : (!st && e_2 <= lo);
         }
         if (__any(miss)) {
             L4 = 0; eL = 0;
@@ -533,7 +547,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             }
         }
         L4 = min(L4, 4 * (NL - 1));  // (empty streams / idle lanes: stay inside the vector)
-        Lprev4 = L4;
+        Lprev4[rd] = L4;
         const int L = L4 >> 2;
         int rem = lo - eL;
         // the owner lane's words + the two behind them (the next member is nearly always there: one set bit per ~12 places)
@@ -615,7 +629,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             }
             if (need_slow) hrank = hr;
         }
-        next_flips();  // the vectors have been read for the last time in this step
+        if (rd == NR - 1) next_flips();  // the vectors have been read for the last time in this step
         const int rs0 = min(max(lrank, 0), TPAD - 1), rs1 = min(max(casek == 0 ? hrank : lrank, 0), TPAD - 1);
         R v, vhi;
         vals.at_ranks(rs0, rs1, v, vhi);
@@ -630,10 +644,11 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             if (res != res && act) flag_cell = true;  // inf - inf: the generic kernel redoes the cell
         }
         if (act) {
-            if (!ref_pass) hq_c[o] = res;
-            else af_c[o] = get_corr<R>(hq_prev, res, kind);
+            if (!ref_pass) hq_c[o + QL * rd] = res;
+            else af_c[o + QL * rd] = get_corr<R>(hq_prev[rd], res, kind);
         }
         if (keep && !ref_pass) { hqk_up(); hqk[0] = res; }
+        }  // (rounds)
         if (DQM && vs && sid < 3 && k == 0) {
             if (arr == 0) scaling[(size_t)c * G + g] = mu;  // mean(hist), replaced by the factor in the ref pass
             else scaling[(size_t)c * G + g] = get_corr<R>(scaling[(size_t)c * G + g], mu, kind);
@@ -643,7 +658,7 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         for (int s_ = nA; s_ < 8; s_++) hqk_up();  // step 0 to the head of the queue
 }
 
-template <int EPT, bool P10, bool DQM, int STOP = 0>
+template <int EPT, bool P10, bool DQM, int STOP = 0, int NR = 1>
 __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc,
                                                        const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, int G,
                                                        const float *__restrict__ q, int Q, int kind, int mode, float *__restrict__ af,
@@ -700,7 +715,7 @@ __global__ __launch_bounds__(1024) void k_train_cell3(const float *__restrict__ 
             if constexpr (STOP == 2) { if (tid == 0 && sorted[nvalid / 2] == 0xFFFF) out_hq[0] = 1.f; __syncthreads(); continue; }  // (load + sort)
             uint16_t *rank = sorted == idx0 ? idx1 : idx0;  // the buffer the sort left free
             const LdsVals vals{keys, sorted, TPAD};
-            cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM, STOP, true>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
+            cell_group_quantiles3<EPT, P10, DQM, LdsVals, DQM, STOP, true, NR>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q,
                                                                      kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, gsum + G, (int)T, lut, hqk);
             __syncthreads();
         }
