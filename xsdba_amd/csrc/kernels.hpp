@@ -524,7 +524,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     // correction (Markstein) instead of the long IEEE division sequence.  When the series fits CH values per
     // thread the means are held in registers and written back over the series in place (no second array, no
     // global round trip); longer series park them in the trend buffer.
-    constexpr int CH = 24;
+    constexpr int CH = 25;  // (odd: the threads of a wave read their chunks CH dwords apart — 24 put eight lanes on every LDS bank)
     const bool inplace = !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
     auto mean_of = [&](double s, int n) {
         double mv = __builtin_nan("");
