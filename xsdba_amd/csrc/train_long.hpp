@@ -169,7 +169,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
                 // thread cost 13.9 ms per 32 400 cells, and one full bisection per element (6.1 ms): profiles/r03_long_phases.txt.
                 auto place_half = [&](auto hsel, const uint32_t (&own)[EPH], const uint32_t (&id)[EPH]) {
                     constexpr int h = decltype(hsel)::value;
-                    const uint32_t *Koth1 = (h ? K0 : K1) - 1;  // Koth1[n] = the n-th key of the other half, counted from 1
+                    const uint32_t *Koth = h ? K0 : K1;  // (Koth[n - 1] = the n-th key of the other half, counted from 1)
                     const int nown = h ? nv1 : nv0, noth = h ? nv0 : nv1, toff = h ? T0 : 0, Th = h ? Ti - T0 : T0;
                     // before(kk, k): a key kk of the other half sorts in front of the key k of this one
                     auto before = [](uint32_t kk, uint32_t k) { return h ? kk <= k : kk < k; };
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
                     for (int step = 8192; step; step >>= 1) {
                         const int nl = lo + step, nh = hi + step;
                         // (a probe past the other half's valid keys reads some word of the LDS and is discarded)
-                        const uint32_t kl = Koth1[nl], kh = Koth1[nh];
+                        const uint32_t kl = Koth[nl - 1], kh = Koth[nh - 1];
                         lo = (nl <= noth && before(kl, own[0])) ? nl : lo;
                         hi = (nh <= noth && before(kh, own[EPH - 1])) ? nh : hi;
                     }
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
 #pragma unroll
                         for (int j = 1; j < EPH - 1; j++) {
                             const int np = pos[j] + step;
-                            const uint32_t kk = Koth1[np];
+                            const uint32_t kk = Koth[np - 1];
                             pos[j] = (np <= hi && before(kk, own[j])) ? np : pos[j];
                         }
                     }
