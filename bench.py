@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--gather", action="store_true", help="also time (and verify) the final native RCCL gather of scen to rank 0 "
                     "(the default with more than one rank)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL gather of scen")
-    ap.add_argument("--gather-timeout", type=float, default=180.0, help="seconds the gather leg may take before the line is printed without it")
+    ap.add_argument("--gather-timeout", type=float, default=90.0, help="seconds the gather leg may take before the line is printed without it")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)  # rendezvous only, no GPU work (tests/test_bench_spawn.py)
     args = ap.parse_args()
 
