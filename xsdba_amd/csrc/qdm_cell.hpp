@@ -160,10 +160,13 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         // extreme percent ranks of a group (utils.rank :631-635: mn / mx of rank / N with average ties), once per group
         // (phase C parks the three counts of a group; the float64 divisions are done for all groups at once after it, by a
         //  lane per group, instead of once per group step by a whole wave)
+        // (the counts are parked as integers in the low words of the group's three float64 slots: the conversions wait for the
+        //  lane-per-group pass after the walk instead of running, wave-wide, in every group step)
         auto put_stats = [&](int g, int n, int nmin, int nmax) {
-            gstat[3 * g] = (double)n;
-            gstat[3 * g + 1] = (double)nmin;
-            gstat[3 * g + 2] = (double)nmax;
+            int *gi = reinterpret_cast<int *>(gstat + 3 * g);
+            gi[0] = n;
+            gi[2] = nmin;
+            gi[4] = nmax;
         };
         {
             uint4 *z = reinterpret_cast<uint4 *>(r2buf);  // (16-byte aligned: both index buffers are)
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 if (lane == 0) { tieb[r >> 5] = (uint32_t)b; tieb[(r >> 5) + 1] = (uint32_t)(b >> 32); }
             }
         }
-        if (tid == 0) gstat[3 * (G / 2)] = 0.0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
+        if (tid == 0) *reinterpret_cast<int *>(gstat + 3 * (G / 2)) = 0;  // (the middle group seeds the node table of pass D: 0 = no valid value this cell)
         // interpolation table: the nodes (grouped) or the compacted (node, factor) pairs of the only row (1-D)
         if (af && wid == 0) {
             const R xq = lane < Q ? quantiles[lane] : nan_of<R>();
@@ -472,7 +475,9 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         __syncthreads();
         if constexpr (XS_QDM_STOP == 3) { if (r2buf[5] == 0xFFFF && tid == 0) flag_count[1] = 1; __syncthreads(); continue; }
         for (int g = tid; g < G; g += NT) {
-            const double N = gstat[3 * g], nmin = gstat[3 * g + 1], nmax = gstat[3 * g + 2];
+            const int *gi = reinterpret_cast<const int *>(gstat + 3 * g);
+            const double N = (double)gi[0], nmin = (double)gi[2], nmax = (double)gi[4];
+            gstat[3 * g] = N;
             gstat[3 * g + 1] = ((nmin + 1.0) / 2.0) / N;
             gstat[3 * g + 2] = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
         }
@@ -515,7 +520,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             // NB elements per thread and round, every load of a stage in flight together: element by element the pass is a chain of
             // dependent round trips (group index -> group triple -> table byte -> factor -> store) and took 4.7 of the kernel's 18.5 ms;
             // four at a time 4.2 ms; all eleven at once spill (19.3 ms for the kernel)
-            constexpr int NB = 6;
+            constexpr int NB = 8;
             for (int t0 = tid; t0 < (int)T; t0 += NB * NT) {
                 int gg[NB], rr[NB], code[NB];
                 bool in[NB];
