@@ -183,6 +183,31 @@ def test_qm_adjust_bit_exact_vs_oracle(hip, gname, kind):
     assert_close(got_tm, oracle.qm_adjust(sim, af, hq, gidx, "nearest", "constant", kind), rtol=0.0, what="time-major")
 
 
+@pytest.mark.parametrize("Q", [16, 32, 48])
+@pytest.mark.parametrize("gname", ["doy31", "month"])
+def test_qm_adjust_row_lengths_multiple_of_16(hip, gname, Q):
+    """tables whose rows are a multiple of 16 dwords long live padded in LDS (kernels.hpp: tab_row_stride): dense tables, tables with
+    holes (the compaction path), both extrapolations, EQM / DQM / QDM adjustments — bit-exact scen and node indexes"""
+    rng = np.random.default_rng(Q + len(gname))
+    T, C = 3650, 4
+    gidx, G, W = GROUPINGS[gname](T)
+    kind = "+"
+    ref, hist, sim = _synth(rng, C, T, kind, np.float32, nan_frac=0.01)
+    q = _nodes(Q)
+    af, hq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+    af[1, G // 2, 3] = np.nan
+    hq[2, 0, :] = np.nan
+    for extrap in ("constant", "nan"):
+        got, node = hip.qm_adjust(sim, af, hq, gidx, "nearest", extrap, kind, return_nodes=True)
+        exp, enode = oracle.qm_adjust(sim, af, hq, gidx, "nearest", extrap, kind, return_nodes=True)
+        assert_close(got, exp, rtol=0.0, what=f"scen {extrap}")
+        np.testing.assert_array_equal(node, enode)
+    scen, sim_q = hip.qdm_adjust(sim, af, q, gidx, W, True, "nearest", "constant", kind)
+    escen, esim_q = oracle.qdm_adjust(sim, af, q, gidx, W, True, "nearest", "constant", kind)
+    assert_close(sim_q, esim_q, rtol=0.0, what="qdm sim_q")
+    assert_close(scen, escen, rtol=0.0, what="qdm scen")
+
+
 @pytest.mark.parametrize("gname", ["time", "doy31", "month"])
 @pytest.mark.parametrize("kind", ["+", "*"])
 def test_dqm_adjust_vs_oracle(hip, gname, kind):

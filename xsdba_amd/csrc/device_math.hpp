@@ -102,11 +102,13 @@ template <typename R, typename Load> __device__ __forceinline__ R vecquantile_so
 template <typename R> struct CellTab {
     const R *xs;        // [G][xstride] compacted abscissae (hist_q), or ONE row shared by all groups (xstride == 0:
                         // the quantile nodes of QDM when the cell's factors hold no NaN)
-    const R *ys;        // [G][Q] compacted factors
+    const R *ys;        // [G][ystride] compacted factors
     const int *rn;      // [G] valid pairs per row
     const double *xfirst, *xlast;  // [G] first/last non-NaN abscissa (NaN if none) — nbutils.py:380-389
     const R *yfirst, *ylast;       // [G] first/last non-NaN factor
     int G, Q, any_valid, xstride;
+    int ystride = 0;    // row stride of ys (0: Q); tab_stage pads rows whose length is a multiple of 16 (tab_row_stride)
+    __device__ __forceinline__ size_t yrow(int g) const { return (size_t)g * (size_t)(ystride ? ystride : Q); }
     bool dense = false;  // no NaN anywhere in the cell's table: every row holds Q pairs, xfirst / xlast are its end abscissae
     const double *spl = nullptr;  // [n] second derivatives of the not-a-knot cubic spline of row 0 (interp = cubic, one group)
 };
@@ -236,7 +238,7 @@ __device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, 
                 if (n == 0) continue;
                 d2 = row_nearest<R, XF>(x, ct.xs + (size_t)g * ct.xstride, n, &w) + d2r;
             }
-            if (d2 < best) { best = d2; val = ct.ys[(size_t)g * Q + w]; node = rr * Q + w; }
+            if (d2 < best) { best = d2; val = ct.ys[ct.yrow(g) + w]; node = rr * Q + w; }
         }
     }
     return val;
@@ -258,7 +260,7 @@ __device__ __forceinline__ R interp2d_nearest(XF x, int g0, const CellTab<R> &ct
         if (n) {
             int w;
             best = row_nearest<R, XF>(x, ct.xs + (size_t)g0 * ct.xstride, n, &w);
-            val = ct.ys[(size_t)g0 * Q + w];
+            val = ct.ys[ct.yrow(g0) + w];
             node = r * Q + w;
         }
         if (best <= 1.0) return val;
@@ -277,7 +279,7 @@ __device__ __forceinline__ R interp2d_nearest_dense(R x, int g0, const CellTab<R
     node = -1;
     if (x != x) return nan_of<R>();
     const int Q = ct.Q, r = g0 + 1;
-    const R *xr = ct.xs + (size_t)g0 * ct.xstride, *yr = ct.ys + (size_t)g0 * Q;
+    const R *xr = ct.xs + (size_t)g0 * ct.xstride, *yr = ct.ys + ct.yrow(g0);
     if (x < xr[0]) return extrap == 0 ? yr[0] : nan_of<R>();
     if (x > xr[Q - 1]) return extrap == 0 ? yr[Q - 1] : nan_of<R>();
     int lo = 0;

@@ -169,9 +169,14 @@ template <typename R> struct TabLds {
     double *spl;  // [3 Q] cubic-spline second derivatives of row 0 + work space (tab_spline)
 };
 
+// Row stride of a cell's [G][Q] tables in LDS.  The lanes of a wave search the rows of consecutive groups at the same offsets:
+// float rows a multiple of 16 dwords long would put sixteen lanes on every LDS bank (nquantiles = 16: the adjustment 4.3 ms per
+// 64 800 cells against 2.6 ms with 20 nodes) — they get four dwords of padding, which keeps the 16-byte staging.
+template <typename R> __host__ __device__ inline int tab_row_stride(int G, int Q) { return (sizeof(R) == 4 && G > 1 && (Q & 15) == 0) ? Q + 4 : Q; }
+
 template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q, bool shared_x = false)
 {
-    size_t n = (size_t)G * Q;
+    size_t n = (size_t)G * tab_row_stride<R>(G, Q);
     return 2 * sizeof(double) * (size_t)G + 3 * sizeof(double) * (size_t)Q + sizeof(R) * (n + (shared_x ? (size_t)Q : n)) +
            2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16;
 }
@@ -179,7 +184,7 @@ template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int
 template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q, bool shared_x = false)
 {
     TabLds<R> t;
-    size_t n = (size_t)G * Q;
+    size_t n = (size_t)G * tab_row_stride<R>(G, Q);
     t.xstride = shared_x ? 0 : Q;
     t.xfirst = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
     t.xlast = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
@@ -227,6 +232,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         ct.any_valid = 1;
         return ct;
     }
+    const int RS = tab_row_stride<R>(G, Q);  // row stride in LDS: Q, or Q + 4 (tab_row_stride)
     const bool vec16 = xq_row_stride == Q && (n & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(t.xs) |
                          reinterpret_cast<uintptr_t>(t.ys)) & 15) == 0;
@@ -246,7 +252,10 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
 #pragma unroll
             for (int k = 0; k < NB4; k++) {
                 const int i = i0 + k * (int)blockDim.x;
-                if (i < n4) { dx[i] = xv[k]; dy[i] = yv[k]; has_nan |= nan4(xv[k]) || nan4(yv[k]); }
+                if (i < n4) {
+                    const int d = RS == Q ? i : i + i / (Q >> 2);  // (padded rows: Q is a multiple of 16, a vector lies inside one row)
+                    dx[d] = xv[k]; dy[d] = yv[k]; has_nan |= nan4(xv[k]) || nan4(yv[k]);
+                }
             }
         }
     } else if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
@@ -259,34 +268,34 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 const int i = i0 + k * (int)blockDim.x;
-                if (i < n) { t.xs[i] = xv[k]; t.ys[i] = yv[k]; has_nan |= (xv[k] != xv[k]) || (yv[k] != yv[k]); }
+                if (i < n) { const int d = RS == Q ? i : i + (RS - Q) * (i / Q); t.xs[d] = xv[k]; t.ys[d] = yv[k]; has_nan |= (xv[k] != xv[k]) || (yv[k] != yv[k]); }
             }
         }
     } else {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             int g = i / Q, k = i - g * Q;
             const R xv = xq[(size_t)g * xq_row_stride + k], yv = yq[i];
-            t.xs[i] = xv;
-            t.ys[i] = yv;
+            t.xs[(size_t)g * RS + k] = xv;
+            t.ys[(size_t)g * RS + k] = yv;
             has_nan |= (xv != xv) || (yv != yv);
         }
     }
     if (!__syncthreads_or(has_nan ? 1 : 0)) {
         // the usual case, no NaN anywhere in the cell's table: rows are already compact
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
-            const R *xr = t.xs + (size_t)g * Q, *yr = t.ys + (size_t)g * Q;
+            const R *xr = t.xs + (size_t)g * RS, *yr = t.ys + (size_t)g * RS;
             t.rn[g] = Q; t.xfirst[g] = (double)xr[0]; t.xlast[g] = (double)xr[Q - 1]; t.yfirst[g] = yr[0]; t.ylast[g] = yr[Q - 1];
         }
         if (threadIdx.x == 0) *t.any = 1;
         __syncthreads();
         CellTab<R> ct;
         ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
-        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1; ct.xstride = Q;
+        ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1; ct.xstride = RS; ct.ystride = RS;
         ct.dense = true;
         return ct;
     }
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        R *xr = t.xs + (size_t)g * Q, *yr = t.ys + (size_t)g * Q;
+        R *xr = t.xs + (size_t)g * RS, *yr = t.ys + (size_t)g * RS;
         int m = 0;
         bool fx = false, fy = false;
         double xf = __builtin_nan(""), xl = __builtin_nan("");
@@ -303,7 +312,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     __syncthreads();
     CellTab<R> ct;
     ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
-    ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any; ct.xstride = Q;
+    ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any; ct.xstride = RS; ct.ystride = RS;
     return ct;
 }
 
