@@ -177,8 +177,9 @@ template <typename R> __host__ __device__ inline int tab_row_stride(int G, int Q
 template <typename R> __host__ __device__ inline size_t tab_lds_bytes(int G, int Q, bool shared_x = false)
 {
     size_t n = (size_t)G * tab_row_stride<R>(G, Q);
+    // (+ 16 bytes behind xs and ys each: tab_stage may shift a table by up to three elements, see there)
     return 2 * sizeof(double) * (size_t)G + 3 * sizeof(double) * (size_t)Q + sizeof(R) * (n + (shared_x ? (size_t)Q : n)) +
-           2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16;
+           2 * sizeof(R) * (size_t)G + sizeof(int) * ((size_t)G + 2) + 16 + 32;
 }
 
 template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned char *p, int G, int Q, bool shared_x = false)
@@ -189,8 +190,8 @@ template <typename R> __device__ __forceinline__ TabLds<R> tab_carve(unsigned ch
     t.xfirst = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
     t.xlast = reinterpret_cast<double *>(p); p += sizeof(double) * (size_t)G;
     t.spl = reinterpret_cast<double *>(p); p += 3 * sizeof(double) * (size_t)Q;
-    t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * (shared_x ? (size_t)Q : n);
-    t.ys = reinterpret_cast<R *>(p); p += sizeof(R) * n;
+    t.xs = reinterpret_cast<R *>(p); p += sizeof(R) * (shared_x ? (size_t)Q : n) + 16;
+    t.ys = reinterpret_cast<R *>(p); p += sizeof(R) * n + 16;
     t.yfirst = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
     t.ylast = reinterpret_cast<R *>(p); p += sizeof(R) * (size_t)G;
     t.rn = reinterpret_cast<int *>(p); p += sizeof(int) * (size_t)G;
@@ -233,6 +234,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
         return ct;
     }
     const int RS = tab_row_stride<R>(G, Q);  // row stride in LDS: Q, or Q + 4 (tab_row_stride)
+    R *xs_ = t.xs, *ys_ = t.ys;  // where the tables end up (shifted by up to three elements in the unaligned 16-byte staging below)
     const bool vec16 = xq_row_stride == Q && (n & 3) == 0 &&
                        ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq) | reinterpret_cast<uintptr_t>(t.xs) |
                          reinterpret_cast<uintptr_t>(t.ys)) & 15) == 0;
@@ -256,6 +258,42 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
                     const int d = RS == Q ? i : i + i / (Q >> 2);  // (padded rows: Q is a multiple of 16, a vector lies inside one row)
                     dx[d] = xv[k]; dy[d] = yv[k]; has_nan |= nan4(xv[k]) || nan4(yv[k]);
                 }
+            }
+        }
+    } else if (sizeof(R) == 4 && xq_row_stride == Q && RS == Q && n >= 16 &&
+               ((reinterpret_cast<uintptr_t>(xq) | reinterpret_cast<uintptr_t>(yq)) & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(xq) ^ reinterpret_cast<uintptr_t>(yq)) & 15) == 0) {
+        // plain [G][Q] float tables that are NOT 16-byte aligned (15, 19, 21 ... nodes: a cell's table starts anywhere): the LDS
+        // copies are shifted by up to three elements so that their addresses are congruent to the global ones modulo 16 — the
+        // body then moves in 16-byte pieces like the aligned case, the up to three elements in front of the first whole piece
+        // and behind the last one go one by one (the scalar copy of such a table cost 0.5 ms per 64 800 cells)
+        xs_ = t.xs + (((reinterpret_cast<uintptr_t>(xq) - reinterpret_cast<uintptr_t>(t.xs)) & 15) >> 2);
+        ys_ = t.ys + (((reinterpret_cast<uintptr_t>(yq) - reinterpret_cast<uintptr_t>(t.ys)) & 15) >> 2);
+        const int head = (int)(((16 - (reinterpret_cast<uintptr_t>(xq) & 15)) & 15) >> 2), n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+        if ((int)threadIdx.x < head) {
+            const R xv = xq[threadIdx.x], yv = yq[threadIdx.x];
+            xs_[threadIdx.x] = xv; ys_[threadIdx.x] = yv; has_nan |= (xv != xv) || (yv != yv);
+        }
+        if ((int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < n - tail0) {
+            const int i = tail0 + (int)threadIdx.x - 64;
+            const R xv = xq[i], yv = yq[i];
+            xs_[i] = xv; ys_[i] = yv; has_nan |= (xv != xv) || (yv != yv);
+        }
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(xq + head), *y4 = reinterpret_cast<const uint4 *>(yq + head);
+        uint4 *dx = reinterpret_cast<uint4 *>(xs_ + head), *dy = reinterpret_cast<uint4 *>(ys_ + head);
+        auto nan4 = [](const uint4 &v) {
+            auto isn = [](uint32_t b) { return (b & 0x7FFFFFFFu) > 0x7F800000u; };
+            return isn(v.x) || isn(v.y) || isn(v.z) || isn(v.w);
+        };
+        constexpr int NB4 = 3;
+        for (int i0 = threadIdx.x; i0 < n4; i0 += NB4 * blockDim.x) {
+            uint4 xv[NB4], yv[NB4];
+#pragma unroll
+            for (int k = 0; k < NB4; k++) { const int i = min(i0 + k * (int)blockDim.x, n4 - 1); xv[k] = x4[i]; yv[k] = y4[i]; }
+#pragma unroll
+            for (int k = 0; k < NB4; k++) {
+                const int i = i0 + k * (int)blockDim.x;
+                if (i < n4) { dx[i] = xv[k]; dy[i] = yv[k]; has_nan |= nan4(xv[k]) || nan4(yv[k]); }
             }
         }
     } else if (xq_row_stride == Q) {  // both tables are plain [G][Q] arrays: straight copy, no index arithmetic
@@ -283,19 +321,19 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     if (!__syncthreads_or(has_nan ? 1 : 0)) {
         // the usual case, no NaN anywhere in the cell's table: rows are already compact
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
-            const R *xr = t.xs + (size_t)g * RS, *yr = t.ys + (size_t)g * RS;
+            const R *xr = xs_ + (size_t)g * RS, *yr = ys_ + (size_t)g * RS;
             t.rn[g] = Q; t.xfirst[g] = (double)xr[0]; t.xlast[g] = (double)xr[Q - 1]; t.yfirst[g] = yr[0]; t.ylast[g] = yr[Q - 1];
         }
         if (threadIdx.x == 0) *t.any = 1;
         __syncthreads();
         CellTab<R> ct;
-        ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
+        ct.xs = xs_; ct.ys = ys_; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
         ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = 1; ct.xstride = RS; ct.ystride = RS;
         ct.dense = true;
         return ct;
     }
     for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        R *xr = t.xs + (size_t)g * RS, *yr = t.ys + (size_t)g * RS;
+        R *xr = xs_ + (size_t)g * RS, *yr = ys_ + (size_t)g * RS;
         int m = 0;
         bool fx = false, fy = false;
         double xf = __builtin_nan(""), xl = __builtin_nan("");
@@ -311,7 +349,7 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
     }
     __syncthreads();
     CellTab<R> ct;
-    ct.xs = t.xs; ct.ys = t.ys; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
+    ct.xs = xs_; ct.ys = ys_; ct.rn = t.rn; ct.xfirst = t.xfirst; ct.xlast = t.xlast;
     ct.yfirst = t.yfirst; ct.ylast = t.ylast; ct.G = G; ct.Q = Q; ct.any_valid = *t.any; ct.xstride = RS; ct.ystride = RS;
     return ct;
 }
