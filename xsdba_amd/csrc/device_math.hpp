@@ -218,11 +218,46 @@ template <typename R, typename XF> __device__ __forceinline__ double row_nearest
     return best;
 }
 
+// The same with a guess `lo` of the lower bound (the one found in a neighbouring row: the rows of consecutive windowed groups are
+// nearly the same numbers): when the guess brackets x — xs[lo - 1] < x <= xs[lo], which makes it THE first place >= x of a sorted
+// row — the two reads of the test are the two reads the distances need; otherwise the fixed bisection runs.  `lo` is updated.
+template <typename R, typename XF> __device__ __forceinline__ double row_nearest_hint(XF x, const R *xs, int n, int &lo, int *which)
+{
+    const int h = min(max(lo, 0), n);
+    const XF below = h > 0 ? (XF)xs[h - 1] : (XF)0, at = h < n ? (XF)xs[h] : (XF)0;
+    if ((h == 0 || below < x) && (h == n || !(at < x))) {
+        double best = __builtin_inf();
+        int bi = -1;
+        if (h > 0) { double d = (double)x - (double)below; best = d * d; bi = h - 1; }
+        if (h < n) { double d = (double)x - (double)at; if (d * d < best) { best = d * d; bi = h; } }
+        *which = bi;
+        lo = h;
+        return best;
+    }
+    // (the bisection of row_nearest_fixed, keeping its lower bound for the next row)
+    int l2 = 0;
+    for (int m = n; m > 1;) {
+        const int half = m >> 1;
+        l2 = (XF)xs[l2 + half - 1] < x ? l2 + half : l2;
+        m -= half;
+    }
+    l2 += (XF)xs[l2] < x ? 1 : 0;
+    double best = __builtin_inf();
+    int bi = -1;
+    if (l2 > 0) { double d = (double)x - (double)xs[l2 - 1]; best = d * d; bi = l2 - 1; }
+    if (l2 < n) { double d = (double)x - (double)xs[l2]; if (d * d < best) { best = d * d; bi = l2; } }
+    *which = bi;
+    lo = l2;
+    return best;
+}
+
 // rows r-1, r+1, r-2, ... while dr^2 < best (the tail of interp2d_nearest: the element's own row has been searched)
+// lo_hint (dense tables): the lower bound found in the element's own row
 template <typename R, typename XF, bool DENSE = false>
-__device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, double best, R val, int &node)
+__device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, double best, R val, int &node, int lo_hint = -1)
 {
     const int G = ct.G, Q = ct.Q;
+    int lo_dn = lo_hint, lo_up = lo_hint;  // the guesses travel outward with their side
     for (int dr = 1; dr <= G + 1; dr++) {
         double d2r = (double)dr * (double)dr;
         if (d2r >= best) break;
@@ -232,7 +267,8 @@ __device__ __forceinline__ R nearest_outward(XF x, int r, const CellTab<R> &ct, 
             int g = ext_row(rr, G);
             int w;
             double d2;
-            if (DENSE) d2 = row_nearest_fixed<R, XF>(x, ct.xs + (size_t)g * ct.xstride, Q, &w) + d2r;
+            if (DENSE) d2 = (lo_hint >= 0 ? row_nearest_hint<R, XF>(x, ct.xs + (size_t)g * ct.xstride, Q, s ? lo_up : lo_dn, &w)
+                                           : row_nearest_fixed<R, XF>(x, ct.xs + (size_t)g * ct.xstride, Q, &w)) + d2r;
             else {
                 int n = ct.rn[g];
                 if (n == 0) continue;
@@ -300,7 +336,7 @@ __device__ __forceinline__ R interp2d_nearest_dense(R x, int g0, const CellTab<R
     node = r * Q + w;
     const double best = d * d;
     if (best <= 1.0) return val;
-    return nearest_outward<R, R, true>(x, r, ct, best, val, node);
+    return nearest_outward<R, R, true>(x, r, ct, best, val, node, lo);
 }
 
 template <typename R>
