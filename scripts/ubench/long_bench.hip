@@ -75,7 +75,7 @@ int main(int argc, char **argv)
     float *dq = upload(q);
     const unsigned nblk = (unsigned)std::min(C, 512);
     unsigned char *scratch;
-    CK(hipMalloc(&scratch, xs::LongCfg::scratch_bytes * nblk));
+    CK(hipMalloc(&scratch, xs::LongCfg<11>::scratch_bytes * nblk));
     printf("# k_train_long: %d cells x %d days, %d groups, window %d, %d quantiles; max row %d, longest toggle list %zu, iid NaN %.2f\n", C, T, G, W, Q, max_row, maxlen, nan_iid);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -106,7 +106,7 @@ int main(int argc, char **argv)
     {
         const bool wide = !getenv("CSR");
         auto kern = wide ? xs::k_train_long<false, true> : xs::k_train_long<false, false>;
-        const size_t lds = xs::LongCfg::lds_bytes;
+        const size_t lds = xs::LongCfg<11>::lds_bytes;
         CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int phase : {1, 11, 12, 13, 2, 0}) {
             if (only >= 0 && only != phase) continue;
@@ -114,8 +114,8 @@ int main(int argc, char **argv)
             if (getenv("POISON")) {
                 const int pz = atoi(getenv("POISON"));
                 if (pz & 1) { CK(hipMemset(hq, 0xFF, (size_t)C * G * Q * 4)); CK(hipMemset(af, 0xFF, (size_t)C * G * Q * 4)); }
-                if (pz & 2) CK(hipMemset(scratch, 0xFF, xs::LongCfg::scratch_bytes * nblk));
-                if (pz & 4) CK(hipMemset(scratch, 0x00, xs::LongCfg::scratch_bytes * nblk));
+                if (pz & 2) CK(hipMemset(scratch, 0xFF, xs::LongCfg<11>::scratch_bytes * nblk));
+                if (pz & 4) CK(hipMemset(scratch, 0x00, xs::LongCfg<11>::scratch_bytes * nblk));
             }
             auto launch = [&]() {
                 hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), lds, 0, ref, hist, (int64_t)T, (int64_t)T, d_rp, d_rows, d_tp, d_ti, G, dq, Q, (int)'+', 1, af, hq,

@@ -747,7 +747,7 @@ def test_train_many_quantile_nodes(hip, Q, T):
     assert_close(af, eaf, rtol=2.4e-7, atol=1e-4, what="af (dqm)")
 
 
-@pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5"), (15001, "week40")])
+@pytest.mark.parametrize("T,gname", [(21900, "doy31"), (11300, "doy31"), (14600, "doy31"), (16384, "doy31"), (16385, "doy31"), (12001, "month"), (22528, "doy1"), (15000, "month5"), (15001, "week40")])
 def test_long_series_train(hip, T, gname):
     """11 265 .. 22 528 steps: the split-sort + merge kernel (k_train_long) — the padded [G][128] toggle table (doy windows) and
     the CSR lists (week40: 750 steps per list), an odd length, the maximum length, NaNs, ties across the two halves, an all-NaN

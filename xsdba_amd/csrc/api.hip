@@ -350,7 +350,7 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
             }
             if ((rc = upload_ints(ctx, t64p, &pl->d_tog64p))) return rc;
         }
-        if (maxlen <= 128 && T > 11 * 1024 && T <= xs::LongCfg::TPAD) {
+        if (maxlen <= 128 && T > 11 * 1024 && T <= xs::LongCfg<11>::TPAD) {
             // k_train_long's series: 31 to 61 years of daily steps toggle up to ~124 steps per day-of-year group; the padded
             // table is one independent load per 64 entries, a step ahead, where the CSR lists cost a pointer chase per step
             std::vector<int> t128((size_t)G * 128, -1);
@@ -676,7 +676,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     if constexpr (std::is_same<R, float>::value) {
         // 11 265 .. 22 528 time steps (e.g. 60 years daily): split sort + merge, train_long.hpp
         const char *force = getenv("XSDBA_HIP_TRAIN");
-        const bool fast_long = !fast && mode != 3 && pl->simple && T > 11 * 1024 && T <= xs::LongCfg::TPAD && G > 1 &&
+        const bool fast_long = !fast && mode != 3 && pl->simple && T > 11 * 1024 && T <= xs::LongCfg<11>::TPAD && G > 1 &&
                                !(force && !strcmp(force, "rows"));
         if (fast_long) {
             void *flags, *scratch;
@@ -684,14 +684,16 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const unsigned nblk = (unsigned)std::min<int64_t>(C, 2 * ctx->n_cu);
-            if ((rc = ensure(ctx, S_SCR, xs::LongCfg::scratch_bytes * nblk, &scratch))) return rc;
-            auto go = [&](auto dqm, auto t64) -> int {
+            if ((rc = ensure(ctx, S_SCR, xs::LongCfg<11>::scratch_bytes * nblk, &scratch))) return rc;
+            const bool short_halves = T <= xs::LongCfg<8>::TPAD;  // up to 16 384 steps: halves of at most 8 192
+            auto go2 = [&](auto dqm, auto t64, auto ept) -> int {
                 constexpr bool DQM = decltype(dqm)::value, TOG64 = decltype(t64)::value;
-                const size_t lds = xs::LongCfg::lds_bytes;
+                constexpr int EPT = decltype(ept)::value;
+                const size_t lds = xs::LongCfg<EPT>::lds_bytes;
                 int rc2;
-                if ((rc2 = set_lds(xs::k_train_long<DQM, TOG64>, lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_long<DQM, TOG64, EPT>, lds, ctx, "the per-cell sort"))) return rc2;
                 LaunchScope ls(ctx, "k_train_long");
-                hipLaunchKernelGGL((xs::k_train_long<DQM, TOG64>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_long<DQM, TOG64, EPT>), dim3(nblk), dim3(1024), lds, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
                                    flag_count, flag_list, C, pl->d_tog128, (unsigned char *)scratch,
@@ -701,6 +703,9 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                                    0);
 #endif
                 return check_launch("k_train_long");
+            };
+            auto go = [&](auto dqm, auto t64) -> int {
+                return short_halves ? go2(dqm, t64, std::integral_constant<int, 8>{}) : go2(dqm, t64, std::integral_constant<int, 11>{});
             };
             using std::false_type;
             using std::true_type;

@@ -15,8 +15,10 @@
 
 namespace xs {
 
-struct LongCfg {
-    using H = CellCfg<11>;
+// EPT: elements per thread of a half's sort — 11 (series up to 22 528 steps) or 8 (up to 16 384: 31 to 44 years of daily steps pay
+// for 16 384 places instead of 22 528)
+template <int EPT> struct LongCfg {
+    using H = CellCfg<EPT>;
     static constexpr int NT = 1024, HALF = H::TPAD, TPAD = 2 * HALF;
     static constexpr int NWORDS = TPAD / 32, WPL = (NWORDS + 63) / 64, BITW = WPL * 64, NWAVE = NT / 64;
     static constexpr int TOGN = 2;  // the padded toggle table of this geometry: [G][128] (60 years of day-of-year windows: 120 steps)
@@ -58,7 +60,7 @@ struct GlobalValsL2 {
 
 // Phase C behind a call: the walk's register allocation is then its own (inlined, its loops shared the 128 registers of a
 // 1024-thread block with whatever the sorts and the merge keep alive across the cell loop, and spilled in its group loop).
-template <bool DQM, bool TOG64>
+template <bool DQM, bool TOG64, int EPT>
 __device__ __attribute__((noinline)) void long_phase_c(const float *x, const uint32_t *by_rank, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                        int lane, int wid, const int *row_ptr, const int *row_sorted, const int *tog_ptr,
                                                        const int *tog_idx, const int *tog64, int G, const float *q, int Q, int kind, int mode,
@@ -66,11 +68,11 @@ __device__ __attribute__((noinline)) void long_phase_c(const float *x, const uin
 {
     auto nostamp = [](int) {};
     const GlobalValsL2 vals{x, by_rank};
-    cell_group_quantiles<LongCfg, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q,
+    cell_group_quantiles<LongCfg<EPT>, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q,
                                                      kind, mode, arr, c, af, out_hq, scaling, flag_cell, 0, nostamp);
 }
 
-template <bool DQM, bool TOG64>
+template <bool DQM, bool TOG64, int EPT = 11>
 __global__ __launch_bounds__(1024) void k_train_long(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(1024) void k_train_long(
     int *__restrict__ flag_count, int *__restrict__ flag_list, int64_t C, const int *__restrict__ tog64,
     unsigned char *__restrict__ gscratch, int debug_phase)
 {
-    using H = CellCfg<11>;
-    using L = LongCfg;
+    using H = CellCfg<EPT>;
+    using L = LongCfg<EPT>;
     constexpr int NT = L::NT, HALF = L::HALF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t *keys = reinterpret_cast<const uint32_t *>(smem + H::off_keys);  // sort view
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
             int nv[2];
             for (int h = 0; h < 2; h++) {
                 const int Th = h ? Ti - T0 : T0;
-                const uint16_t *sorted = cell_load_sort<11>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h], NoLoadHook(), -1, true);
+                const uint16_t *sorted = cell_load_sort<EPT>(x + (h ? T0 : 0), (int64_t)Th, smem, red, 2, nv[h], NoLoadHook(), -1, true);
                 if (h == 0) {
                     if (sorted) {
                         for (int r = tid; r < HALF; r += NT) {
@@ -225,7 +227,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
             __syncthreads();  // rank[] complete, K0 / K1 dead: the vectors take their place
             if (debug_phase == 2 || debug_phase == 12 || debug_phase == 13) continue;  // timing aid: sorts + merge
             // ---------------- 3. group quantiles ----------------
-            long_phase_c<DQM, TOG64>(x, by_rank, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q, kind, mode,
+            long_phase_c<DQM, TOG64, EPT>(x, by_rank, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q, kind, mode,
                                      arr, c, af, out_hq, scaling, flag_cell);
             __syncthreads();  // everyone is done with rank[] / the vectors before the next sort reuses the LDS
         }
