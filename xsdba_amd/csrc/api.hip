@@ -948,14 +948,15 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     }
     if (tc_out) { tc_out->coef = coef_out; tc_out->tnum = d_tnum; tc_out->affine = tn_affine; tc_out->t0 = tn0; tc_out->dt = tnd; }
     const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
-    const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
+    // the in-register window means hold 24 values per thread: long series take 1024 threads to stay on that path
+    const unsigned nthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();
+    const size_t scratch_d = 2 * (size_t)pl->G <= (size_t)(nthr >> 5) ? (size_t)xs::TREND_SCRATCH_D : 0;  // (k_group_trend: half-waves sharing a group)
+    const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + scratch_d + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
     const bool m_lds = getenv("XSDBA_HIP_TREND_MLDS") != nullptr;  // window means in LDS: measured slower (occupancy)
     int rc;
     // regression layout: a lane per group when there are many short groups (day-of-year), else a half-wave per group
     const int lane_per_group = (pl->G >= 128 && pl->max_mem <= 256) ? 1 : 0;
-    // the in-register window means hold 24 values per thread: long series take 1024 threads to stay on that path
-    const unsigned nthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();
     if (m_lds && lds2 <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_group_trend<R, true>, lds2, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");

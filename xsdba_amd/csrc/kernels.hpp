@@ -477,6 +477,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
 // divided out ('*'), in float64 before the cast.
 // ---------------------------------------------------------------------------------------------
 constexpr int POLY_MAX_DEG = 6;
+constexpr int TREND_SCRATCH_D = 160;  // doubles of block scratch behind k_group_trend's coefficients (5 partial sums x 32 half-waves)
 
 // least squares of degree d from the moments S_k = sum u^k (k <= 2d), B_k = sum u^k y (k <= d): c[0..d] ascending, NaN if singular
 __device__ __forceinline__ void poly_solve(const double *S, const double *B, int d, double *c)
@@ -527,7 +528,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     const bool general = degree >= 2 || preserve_mean;
     const int ncoef = general ? degree + 4 : 3;
     double *coef = reinterpret_cast<double *>(smem);
-    double *rcp = coef + (size_t)ncoef * G;  // [W+1] correctly rounded reciprocals of the possible window counts
+    double *part = coef + (size_t)ncoef * G;  // [TREND_SCRATCH_D] partial sums of the half-waves that share a group
+    // (the scratch exists only when half-waves share groups — 2 G <= half-waves per block, the host sizes the LDS by the same rule —:
+    //  1.3 KB more would cost the day-of-year case its third block per CU)
+    double *rcp = part + (2 * G <= (int)(blockDim.x >> 5) ? TREND_SCRATCH_D : 0);  // [W+1] correctly rounded reciprocals of the possible window counts
     R *xs = reinterpret_cast<R *>(rcp + W + 1);
     const int64_t c = blockIdx.x;
     const R *x = sim + c * sc;
@@ -760,6 +764,44 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
             for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
             return v;
         };
+        const int nsplit = 2 * G <= nhw ? nhw / G : 1;  // half-waves per group
+        if (nsplit > 1) {
+            // fewer groups than half-waves (group="time": one group of T members): the half-waves of a group take its members
+            // 32 * nsplit apart and add their partial sums in a fixed order — one half-wave alone walked all 10 950 members of
+            // a 30-year series twice (4.2 ms per 16 200 cells, more than the training of the same cube)
+            const int g = hw / nsplit, sp = hw - g * nsplit;
+            const bool on = g < G;
+            const int p0 = on ? mem_ptr[g] : 0, p1 = on ? mem_ptr[g + 1] : 0;
+            double sx = 0, sy = 0, cn = 0;
+            for (int p = p0 + sp * 32 + hl; p < p1; p += 32 * nsplit) {
+                int t = mem_idx[p];
+                R v = m[t];
+                if (v == v) { sx += TN(t); sy += (double)v; cn += 1.0; }
+            }
+            sx = hsum(sx); sy = hsum(sy); cn = hsum(cn);
+            if (hl == 0) { part[5 * hw] = sx; part[5 * hw + 1] = sy; part[5 * hw + 2] = cn; }
+            __syncthreads();
+            sx = sy = cn = 0;
+            if (on) for (int k = 0; k < nsplit; k++) { sx += part[5 * (g * nsplit + k)]; sy += part[5 * (g * nsplit + k) + 1]; cn += part[5 * (g * nsplit + k) + 2]; }
+            const int n = (int)cn;
+            const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
+            double sxx = 0, sxy = 0;
+            if (degree >= 1 && n >= 2)
+                for (int p = p0 + sp * 32 + hl; p < p1; p += 32 * nsplit) {
+                    int t = mem_idx[p];
+                    R v = m[t];
+                    if (v == v) { double dx = TN(t) - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                }
+            sxx = hsum(sxx); sxy = hsum(sxy);
+            if (hl == 0) { part[5 * hw + 3] = sxx; part[5 * hw + 4] = sxy; }
+            __syncthreads();
+            if (on && sp == 0 && hl == 0) {
+                double a = 0, b = 0;
+                for (int k = 0; k < nsplit; k++) { a += part[5 * (g * nsplit + k) + 3]; b += part[5 * (g * nsplit + k) + 4]; }
+                const double slope = (degree >= 1 && n >= 2 && a > 0) ? b / a : 0.0;
+                coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
+            }
+        } else
         for (int g = hw; g < G; g += nhw) {
             const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
             double sx = 0, sy = 0, cn = 0;
