@@ -458,15 +458,21 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                         if (lane == 0) put_stats(g, n, nmin, nmax);
                     }
                     // average-tie ranks of the elements this row ranks (the exact group)
-                    for (int i0 = slice * 64; i0 < mlen; i0 += nslice * 64) {
-                        const int i = i0 + lane;
-                        const int t = i < mlen ? ml[i] : -1;
-                        const int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
-                        if (r < nvalid) {
-                            int rs, re;
-                            tie_run(r, rs, re);
-                            r2buf[t] = (uint16_t)(below(rs) + below(re) + 1);
-                        }
+                    // (four rounds of member indexes are requested before the first is used: the list is a gather from global
+                    //  memory, and one round trip per 64 members was most of a long row's walk — monthly groups: 912 members)
+                    for (int i0 = slice * 64; i0 < mlen; i0 += nslice * 64 * 4) {
+                        int ts[4], rr[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) { const int i = i0 + u * nslice * 64 + lane; ts[u] = i < mlen ? ml[i] : -1; }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) rr[u] = ts[u] >= 0 ? (int)rank[ts[u]] : 0x7FFFFFFF;
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (rr[u] < nvalid) {
+                                int rs, re;
+                                tie_run(rr[u], rs, re);
+                                r2buf[ts[u]] = (uint16_t)(below(rs) + below(re) + 1);
+                            }
                     }
                 }
                 lds_wave_fence();  // the next toggles rewrite bits / pw
