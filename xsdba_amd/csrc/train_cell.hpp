@@ -539,7 +539,7 @@ __device__ __forceinline__ void cell_group_quantiles(
         lds_wave_fence();
         const uint32_t *bits_h = half ? bitsB : bitsA;
         double gsumA = 0.0, gsumB = 0.0;
-        double amax = 0.0;  // DQM: largest magnitude that went through the running sums of this wave
+        R amax = (R)0;  // DQM: largest magnitude that went through the running sums of this wave (in the series' own type: exact)
         if (DQM && kind == '+' && wid == 0 && lane == 0 && nvalid > 1) {
             // additive kind: the running sums leave an absolute error of ~2e-16 * (largest |value|) on a group mean.
             // Harmless unless the series holds wild outliers (unmasked fill values, 1e300 ...): compare the extremes
@@ -586,7 +586,7 @@ __device__ __forceinline__ void cell_group_quantiles(
                         uint32_t old = atomicXor(&bits[r >> 5], m);
                         R v = vals.at_time(t);
                         dloc += (old & m) ? -(double)v : (double)v;
-                        amax = fmax(amax, fabs((double)v));
+                        amax = fmax(amax, (R)fabs(v));
                     } else {
                         (void)__hip_atomic_fetch_xor(&bits[r >> 5], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -667,7 +667,7 @@ __device__ __forceinline__ void cell_group_quantiles(
                     // ~1e-17 of the largest value, is far below the data's own resolution whatever the mean is.
                     constexpr double LIM = sizeof(R) == 8 ? 200.0 : 1.0e6;
                     const double gmin = fmin((vA && nA) ? fabs(gsumA) : __builtin_inf(), (vB && nB) ? fabs(gsumB) : __builtin_inf());
-                    if (kind == '*' && !(amax <= LIM * gmin)) flag_cell = true;
+                    if (kind == '*' && !((double)amax <= LIM * gmin)) flag_cell = true;
                 }
             }
             const size_t obase = ((size_t)c * G + (vh ? g : 0)) * (size_t)Q;
