@@ -5,8 +5,9 @@ One "step" = one full train + adjust pass of the workload over the rank's block 
 synthetic (cell, time) cubes already resident in HBM (generated on the device).  Default
 workload = the one BASELINE.json's metric names: EmpiricalQuantileMapping, Grouper("time.dayofyear",
 window=31), kind "+", 30 years of daily data (10950 noleap days), nquantiles 20, interp "nearest", on the
-360x180 grid of configs[1] (64800 cells per GPU; weak scaling: every rank owns its own block of cells, no
-data-path collective).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time | dqm_doy31_nan
+per-GPU shard of north_star's 1440x720 cube over 8 GPUs (129 600 cells per GPU at EVERY N, so that the N = 1, 2, 4, 8
+series is weak scaling of one per-GPU problem; every rank owns its own block of cells, no data-path collective; --cells
+64800 / 259200 give the 360x180 and 720x360 grids of configs[1] / [2]).  Other workloads: --workload eqm_month | dqm_doy31 | qdm_doy31 | eqm_time | dqm_doy31_nan
 (BASELINE configs[4]: use --days 21900).
 
 N > 1: launched by torch.distributed.run, one process per GPU; torch is used only for the rendezvous, the barrier and the
@@ -43,6 +44,8 @@ WORKLOADS = {
     # --days 21900; cells per GPU as memory allows)
     "dqm_doy31_nan": ("dqm", "dayofyear", 31, "+", 0),
 }
+GRID_NAMES = {129600: " (1/8 of the 1440x720 grid)", 64800: " (the 360x180 grid)", 259200: " (the 720x360 grid)"}
+DEFAULT_CELLS_PER_GPU = 1440 * 720 // 8  # 129 600: the per-GPU shard of north_star's 1440x720 cube over 8 GPUs
 NAN_MASK = {"dqm_doy31_nan": (0.30, 0.01)}  # workload -> (fraction of all-NaN cells, i.i.d. NaN fraction elsewhere)
 
 
@@ -75,8 +78,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="eqm_doy31", choices=sorted(WORKLOADS))
-    ap.add_argument("--cells", type=int, default=None, help="grid cells per GPU (default: 64 800, the 360x180 grid; 129 600 at 8 GPUs, "
-                    "an eighth of the 1440x720 grid)")
+    ap.add_argument("--cells", type=int, default=None, help="grid cells per GPU (default at every N: 129 600, an eighth of "
+                    "north_star's 1440x720 grid; 64 800 = the 360x180 grid, 259 200 = the 720x360 one)")
     ap.add_argument("--days", type=int, default=10950)
     ap.add_argument("--nquantiles", type=int, default=20)
     ap.add_argument("--time-major", action="store_true", help="store the cubes as (time, cell) instead of (cell, time)")
@@ -101,12 +104,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.cells is None:
-        # one GPU: the 360x180 grid of configs[1]; eight: the per-GPU shard of north_star's 1440x720 cube (configs[3] / [4])
-        args.cells = 1440 * 720 // 8 if world == 8 else 360 * 180
+        args.cells = DEFAULT_CELLS_PER_GPU  # the same per-GPU problem at every N: the series over N is weak scaling
     if world > 1 and not args.no_gather:
         args.gather = True
     if args.dry_run:
-        return dry_run(world, rank)
+        return dry_run(world, rank, args.cells)
 
     dist = None
     # torch.distributed is rendezvous / barrier / MAX-over-ranks plumbing only, on CPU tensors ("gloo"): the process then
@@ -222,9 +224,10 @@ def main():
         dom_avg_ms = kern[dom]["total_ms"] / kern[dom]["count"]
         dom_bytes = C * (tb if dom.startswith("k_train") else ab)  # algorithmic bytes one launch moves
         achieved = dom_bytes / (dom_avg_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(args.workload, C, T, dom)
         roof = {
             "bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic(args.workload, C, T, dom),
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
             "avg_launch_ms": round(dom_avg_ms, 4), "algorithmic_bytes_per_launch": dom_bytes,
             "kernels": {k: {"count": v["count"], "avg_ms": round(v["total_ms"] / v["count"], 4)} for k, v in kern.items()},
         }
@@ -242,7 +245,8 @@ def main():
             "config": {
                 "workload": f"{args.workload}: {method.upper()} train+adjust{' (rank_window=True)' if rank_window else ''}, group={group}, window={W}, kind='{kind}', "
                             f"nquantiles={Q}, interp=nearest, {C} cells/GPU x {T} days fp32, "
-                            f"{'time-major (time,cell)' if args.time_major else 'cell-major (cell,time)'} cubes resident in HBM",
+                            f"{'time-major (time,cell)' if args.time_major else 'cell-major (cell,time)'} cubes resident in HBM"
+                            f"{GRID_NAMES.get(C, '')}",
                 "cells_per_gpu": C, "days": T, "groups": G, "window": W, "parallelism": f"cells sharded over {world} GPU(s)",
             },
             "roofline": roof,
@@ -269,7 +273,8 @@ def main():
                 a.free()
         if not args.no_cpu_baseline and world == 1:  # (rank 0 at N = 1 only)
             out["cpu_baseline"] = cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T,
-                                               args.cpu_seconds, args.time_major, rank_window)
+                                               args.cpu_seconds, args.time_major, rank_window,
+                                               synth_args=(gen, seed, cell0, ncf, nif))
     else:
         out = None
 
@@ -378,18 +383,22 @@ def spawn_ranks(n: int) -> int:
     return proc.returncode
 
 
-def dry_run(world: int, rank: int) -> None:
+def dry_run(world: int, rank: int, cells: int) -> None:
     """Rendezvous only (gloo), no GPU work: what tests/test_bench_spawn.py runs on a box without a GPU."""
-    import torch
-    import torch.distributed as dist
+    seen = 1
+    if world > 1:
+        import torch
+        import torch.distributed as dist
 
-    dist.init_process_group("gloo")
-    t = torch.ones(1, dtype=torch.int64)
-    dist.all_reduce(t)
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(t)
+        seen = int(t.item())
     if rank == 0:
-        print(json.dumps({"metric": "dry-run", "n_gpus": world, "ranks_seen": int(t.item()), "dry_run": True}), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+        print(json.dumps({"metric": "dry-run", "n_gpus": world, "ranks_seen": seen, "cells_per_gpu": cells, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window):
@@ -438,7 +447,7 @@ def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
     res["device_inputs_cells_per_s"] = round(C * reps / (time.perf_counter() - t0), 1)
     del scen
     n = min(C, 16384)
-    host = [wrap(np.ascontiguousarray(a.download()[:n]), n) for a in (ref, hist, sim)]
+    host = [wrap(first_rows(ctx, a, n, T), n) for a in (ref, hist, sim)]
     run(*host).values  # warm-up
     t0 = time.perf_counter()
     out = run(*host).values  # the download is part of it
@@ -450,10 +459,19 @@ def api_level(ctx, ref, hist, sim, method, group, W, kind, Q, C, T, rank_window)
     return res
 
 
+def first_rows(ctx, dev, n, T):
+    """the first `n` series of a cell-major [cells, T] float32 device cube on the host: a view of those rows is downloaded,
+    never the cube (5.7 GB at the default size)"""
+    from xsdba_amd._lib import DeviceArray
+
+    return DeviceArray.from_ptr(ctx, dev.ptr, (n, T), np.float32).download().reshape(n, T)
+
+
 def pmc_traffic(workload, cells, days, kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this very configuration
-    (profiles/*traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 corrections applied); None when
-    no PMC run matches the workload being benchmarked."""
+    """(HBM bytes per launch of `kernel`, where they come from).  The bytes are NOT measured by this run: they are the
+    rocprofv3 PMC passes of this very configuration committed under profiles/ (*traffic*.json: separate --pmc FETCH_SIZE /
+    WRITE_SIZE runs of this script, gfx950 corrections applied), and `traffic_source` names the file; (None, reason) when
+    no committed PMC run matches the workload, cells and days being benchmarked."""
     # the newest set first: "<round>_final_*", then the versioned sets in descending order (v10 before v9)
     def age(f):
         # "rNN_final*" is the round's last set, "rNN_vK*" an intermediate one, a plain "rNN_*" the first
@@ -469,18 +487,26 @@ def pmc_traffic(workload, cells, days, kernel):
         if d.get("workload") == workload and d.get("cells") == cells and d.get("days") == days:
             k = d.get("kernels", {}).get(kernel.split("(")[0])
             if k:
-                return k["traffic_bytes"]
-    return None
+                return k["traffic_bytes"], f"profiles/{f.name} (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this configuration; not measured in this run)"
+    return None, f"none: no committed PMC pass under profiles/ for workload={workload}, cells={cells}, days={days}, kernel={kernel}"
 
 
-def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major, rank_window=False):
+def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C, T, target_s, time_major, rank_window=False,
+                 synth_args=None):
     """The CPU oracle (a restatement of the reference algorithm, kind="port") timed on this box's host cores
     on a bounded sample of the SAME device-generated cells; reported beside the GPU number, never the target."""
     import oracle
 
-    def fetch(dev, n):
-        full = dev.download()
-        return np.ascontiguousarray(full.T[:n] if time_major else full[:n])
+    def fetch(which, dev, n):
+        # only the rows the sample uses ever cross PCIe: a view of the first n series of a cell-major cube; for a time-major
+        # cube (whose series are columns) the same n cells regenerated cell-major by the counter-based generator
+        if not time_major:
+            return first_rows(ctx, dev, n, T)
+        tmp = ctx.synth((n, T), np.float32, *synth_args[:1], which, *synth_args[1:], time_major=False)
+        try:
+            return tmp.download().reshape(n, T)
+        finally:
+            tmp.free()
 
     def run(r, h, s):
         t0 = time.perf_counter()
@@ -496,7 +522,7 @@ def cpu_baseline(ctx, hip, ref, hist, sim, method, gidx, G, W, q, kind, tnum, C,
         return time.perf_counter() - t0
 
     nmax = min(C, 8192)
-    r, h, s = fetch(ref, nmax), fetch(hist, nmax), fetch(sim, nmax)
+    r, h, s = fetch(0, ref, nmax), fetch(1, hist, nmax), fetch(2, sim, nmax)
     # thread scaling first: the box may expose far more logical CPUs than this job's share of cores, and OpenMP over all of
     # them then measures oversubscription, not the algorithm.  Short probes (a few cells per thread) at 1, 4, 16, ... threads;
     # the count with the best rate runs the bounded sample.

@@ -153,3 +153,47 @@ def test_results_are_released_with_their_arrays():
             before = ptr
     # the allocator hands the same block out again once it has been returned
     assert ptr == before or i > 0
+
+
+def test_device_resident_ref_and_hist_with_swapped_cell_order(monkeypatch):
+    """ref stored (lat, lon, time), hist stored (lon, lat, time), both on the device: the cells are paired by label
+    (`hist.transpose(*ref.dims)` is a lazy relabel of a device buffer — the training must not pair them by buffer position)."""
+    import warnings
+
+    ref_v, hist_v, sim_v = _data("+", shape=(4, 6, 3650))
+    monkeypatch.setenv("XSDBA_AMD_DEVICE_MIN_MB", "0")
+    from xsdba_amd._lib import default_context
+
+    ctx = default_context()
+    ref = _cube(ref_v, ("lat", "lon", "time"), "K")
+    hist_h = _cube(np.ascontiguousarray(hist_v.transpose(1, 0, 2)), ("lon", "lat", "time"), "K")
+    hist_d = DataArray(ctx.to_device(hist_h.values), hist_h.dims, hist_h.coords, hist_h.attrs)
+    ref_d = DataArray(ctx.to_device(ref.values), ref.dims, ref.coords, ref.attrs)
+    sim = _cube(sim_v, ("lat", "lon", "time"), "K")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = xs.EmpiricalQuantileMapping.train(ref, _cube(hist_v, ("lat", "lon", "time"), "K"),
+                                                 group=xs.Grouper("time.dayofyear", window=31), nquantiles=20, kind="+")
+        got = xs.EmpiricalQuantileMapping.train(ref_d, hist_d, group=xs.Grouper("time.dayofyear", window=31), nquantiles=20, kind="+")
+        s_want, s_got = want.adjust(sim), got.adjust(sim)
+    for name in ("af", "hist_q"):
+        np.testing.assert_array_equal(got.ds[name].transpose(*want.ds[name].dims).values, want.ds[name].values, err_msg=name)
+    np.testing.assert_array_equal(s_got.transpose(*s_want.dims).values, s_want.values)
+
+
+@pytest.mark.parametrize("nq", [15, 19, 21])
+def test_adjust_with_one_wave_blocks_and_unaligned_tables(monkeypatch, nq):
+    """kernels.hpp tab_stage: tables that start off a 16-byte boundary (15, 19, 21 nodes) are staged in shifted 16-byte
+    pieces; the elements behind the last whole piece must be copied whatever the block size (XSDBA_HIP_ADJ_THREADS=64)."""
+    rng = np.random.default_rng(5)
+    C, T = 7, 3650
+    doy = (np.arange(T) % 365).astype(np.int32)
+    ref = (280 - 20 * np.cos(2 * np.pi * (doy + 1) / 365) + 2 * rng.random((C, T))).astype(np.float32)
+    hist = (ref + 1 + rng.random((C, T))).astype(np.float32)
+    sim = (hist + 1).astype(np.float32)
+    q = ((np.arange(nq) + 0.5) / nq).astype(np.float32)
+    af, hq = hip.eqm_train(ref, hist, doy, 365, 31, q, "+")
+    want = hip.qm_adjust(sim, af, hq, doy, "nearest", "constant", "+")
+    monkeypatch.setenv("XSDBA_HIP_ADJ_THREADS", "64")
+    got = hip.qm_adjust(sim, af, hq, doy, "nearest", "constant", "+")
+    np.testing.assert_array_equal(got, want)

@@ -20,6 +20,16 @@ def test_gpus_2_spawns_two_ranks_and_relays_rank0_line():
     assert len(lines) == 1, p.stdout  # ONE JSON line on stdout, whatever the ranks printed
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["cells_per_gpu"] == 129600  # the same per-GPU problem at every N (weak scaling)
+
+
+def test_one_rank_has_the_same_per_gpu_size():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29611")
+    p = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--dry-run"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["cells_per_gpu"] == 129600
 
 
 def test_world_size_mismatch_is_refused():

@@ -64,3 +64,35 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
         capture_output=True, text=True, env=env, timeout=300)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "GATHER_OK (11, 5)" in proc.stdout
+
+
+def test_token_file_rendezvous_ignores_clocks_and_other_jobs(tmp_path):
+    """xsdba_amd.sharding._token_through_file: a rank that arrives long after rank 0 wrote still gets the token (no mtime
+    test), and a complete file left by ANOTHER job is never taken for this one's."""
+    import os
+    import threading
+    import time
+
+    from xsdba_amd import sharding as sh
+
+    f = str(tmp_path / "tok")
+    tok = bytes(range(sh.COMM_ID_BYTES % 256)) * 1 + bytes(sh.COMM_ID_BYTES - (sh.COMM_ID_BYTES % 256))
+    tok = tok[:sh.COMM_ID_BYTES]
+    n_a, n_b = sh._job_nonce("job-a"), sh._job_nonce("job-b")
+    assert n_a != n_b and len(n_a) == 16
+    # rank 0 of job a wrote long ago (mtime far in the past): a late rank still accepts it
+    assert sh._token_through_file(tok, 0, f, n_a, 5.0) == tok
+    os.utime(f, (time.time() - 3600, time.time() - 3600))
+    assert sh._token_through_file(b"", 1, f, n_a, 5.0) == tok
+    # a rank of job b waits past job a's leftover until its own rank 0 has written
+    other = bytes(reversed(tok))
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault("t", sh._token_through_file(b"", 1, f, n_b, 10.0)))
+    th.start()
+    time.sleep(0.3)
+    assert th.is_alive()
+    sh._token_through_file(other, 0, f, n_b, 5.0)
+    th.join(10)
+    assert got["t"] == other
+    with pytest.raises(TimeoutError):
+        sh._token_through_file(b"", 1, f, sh._job_nonce("job-c"), 0.2)

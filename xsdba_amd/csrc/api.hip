@@ -948,8 +948,8 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     }
     if (tc_out) { tc_out->coef = coef_out; tc_out->tnum = d_tnum; tc_out->affine = tn_affine; tc_out->t0 = tn0; tc_out->dt = tnd; }
     const size_t ncoef = (degree >= 2 || preserve_mean) ? (size_t)degree + 4 : 3;
-    // the in-register window means hold 24 values per thread: long series take 1024 threads to stay on that path
-    const unsigned nthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();
+    // the in-register window means hold TREND_CH values per thread: long series take 1024 threads to stay on that path
+    const unsigned nthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > xs::TREND_CH * 512 && T <= xs::TREND_CH * 1024) ? 1024u : trend_threads();
     const size_t scratch_d = 2 * (size_t)pl->G <= (size_t)(nthr >> 5) ? (size_t)xs::TREND_SCRATCH_D : 0;  // (k_group_trend: half-waves sharing a group)
     const size_t lds1 = sizeof(double) * (ncoef * (size_t)pl->G + scratch_d + (size_t)pl->W + 1) + (size_t)T * sizeof(R);
     const size_t lds2 = lds1 + (size_t)T * sizeof(R);
@@ -1010,7 +1010,7 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         // kernel evaluates them per element — no [cell][time] array written and read back
         const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double) + (((size_t)G * sizeof(float) + 15) & ~(size_t)15);
         // (series long enough for the trend kernel to park its window means in the trend buffer keep the array)
-        const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > 24 * 512 && T <= 24 * 1024) ? 1024u : trend_threads();  // as launch_trend
+        const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > xs::TREND_CH * 512 && T <= xs::TREND_CH * 1024) ? 1024u : trend_threads();  // as launch_trend
         const bool means_in_regs = pl->W == 1 || T <= (int64_t)24 * tthr;
         if (!trend && degree <= 1 && means_in_regs && tab_c <= (size_t)ctx->lds_limit && !getenv("XSDBA_HIP_TREND_ARRAY")) {
             void *cbuf;

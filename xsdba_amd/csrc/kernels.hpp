@@ -274,8 +274,8 @@ __device__ __forceinline__ CellTab<R> tab_stage(const TabLds<R> &t, const R *__r
             const R xv = xq[threadIdx.x], yv = yq[threadIdx.x];
             xs_[threadIdx.x] = xv; ys_[threadIdx.x] = yv; has_nan |= (xv != xv) || (yv != yv);
         }
-        if ((int)threadIdx.x >= 64 && (int)threadIdx.x - 64 < n - tail0) {
-            const int i = tail0 + (int)threadIdx.x - 64;
+        if ((int)threadIdx.x >= 4 && (int)threadIdx.x - 4 < n - tail0) {  // (lanes 4..6: present in every block size)
+            const int i = tail0 + (int)threadIdx.x - 4;
             const R xv = xq[i], yv = yq[i];
             xs_[i] = xv; ys_[i] = yv; has_nan |= (xv != xv) || (yv != yv);
         }
@@ -477,6 +477,7 @@ __global__ void k_qm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int
 // divided out ('*'), in float64 before the cast.
 // ---------------------------------------------------------------------------------------------
 constexpr int POLY_MAX_DEG = 6;
+constexpr int TREND_CH = 25;  // time steps per thread of k_group_trend's in-register window means (the host picks the block size from it)
 constexpr int TREND_SCRATCH_D = 160;  // doubles of block scratch behind k_group_trend's coefficients (5 partial sums x 32 half-waves)
 
 // least squares of degree d from the moments S_k = sum u^k (k <= 2d), B_k = sum u^k y (k <= d): c[0..d] ascending, NaN if singular
@@ -575,7 +576,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     // correction (Markstein) instead of the long IEEE division sequence.  When the series fits CH values per
     // thread the means are held in registers and written back over the series in place (no second array, no
     // global round trip); longer series park them in the trend buffer.
-    constexpr int CH = 25;  // (odd: the threads of a wave read their chunks CH dwords apart — 24 put eight lanes on every LDS bank)
+    constexpr int CH = TREND_CH;  // (odd: the threads of a wave read their chunks CH dwords apart — 24 put eight lanes on every LDS bank)
     const bool inplace = !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
     auto mean_of = [&](double s, int n) {
         double mv = __builtin_nan("");

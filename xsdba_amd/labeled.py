@@ -283,7 +283,10 @@ class DataArray:
         if isinstance(name, dict):
             dims = tuple(name.get(d, d) for d in self.dims)
             coords = OrderedDict((name.get(k, k), Coordinate(name.get(k, k), c.values, c.attrs)) for k, c in self.coords.items())
-            return self._like(dims=dims, coords=coords)
+            out = self._like(dims=dims, coords=coords)
+            if out._dev_dims is not None:  # a lazily transposed device view: the buffer's dimension names follow
+                out._dev_dims = tuple(name.get(d, d) for d in out._dev_dims)
+            return out
         out = self._like()
         out.name = name
         return out

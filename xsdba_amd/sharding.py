@@ -49,10 +49,55 @@ def shard_cells(x: np.ndarray, world: int, rank: int, cell_axis: int = 0) -> np.
     return x[tuple(idx)]
 
 
-def init_comm(ctx, rank: int, world: int, token_file: str | None = None) -> None:
+def _job_nonce(job_id) -> bytes:
+    """16 bytes every rank of ONE job derives alike and another job does not: from `job_id`, else from what the launcher
+    shares with all its ranks (XSDBA_AMD_JOB_ID, torchrun's run id, MASTER_ADDR:MASTER_PORT); zeros when nothing is shared"""
+    import hashlib
+
+    if job_id is None:
+        env = os.environ
+        job_id = env.get("XSDBA_AMD_JOB_ID") or env.get("TORCHELASTIC_RUN_ID")
+        if job_id is None and env.get("MASTER_PORT"):
+            job_id = f"{env.get('MASTER_ADDR', '')}:{env['MASTER_PORT']}"
+    if job_id is None:
+        return bytes(16)
+    return hashlib.sha256(str(job_id).encode()).digest()[:16]
+
+
+def _token_through_file(token: bytes, rank: int, token_file: str, nonce: bytes, timeout: float) -> bytes:
+    """Rank 0 publishes `token`, the others return rank 0's.  The file holds the 16-byte job nonce + the token.  Freshness is
+    never judged by clocks (ranks start seconds apart, file-system and local clocks differ): rank 0 removes whatever is there
+    before it writes (atomically) and again once every rank has joined; the others take the first complete file that carries
+    this job's nonce — a leftover of another job is ignored, however recent."""
+    if rank == 0:
+        try:
+            os.unlink(token_file)
+        except FileNotFoundError:
+            pass
+        tmp = f"{token_file}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(nonce + token)
+        os.replace(tmp, token_file)
+        return token
+    t0 = time.monotonic()
+    while True:
+        try:
+            with open(token_file, "rb") as f:
+                raw = f.read(16 + COMM_ID_BYTES + 1)
+            if len(raw) == 16 + COMM_ID_BYTES and raw[:16] == nonce:
+                return raw[16:]
+        except FileNotFoundError:
+            pass
+        if time.monotonic() - t0 > timeout:
+            raise TimeoutError(f"no RCCL token of this job at {token_file} after {timeout:.0f} s")
+        time.sleep(0.01)
+
+
+def init_comm(ctx, rank: int, world: int, token_file: str | None = None, job_id=None, timeout: float = 600.0) -> None:
     """Collective: set up the RCCL communicator of `ctx`.  Rank 0 creates the token; it travels through
     torch.distributed when a process group is initialised, else through `token_file` (written atomically by rank 0, polled by
-    the others — any shared path works: the ranks of one node share /tmp)."""
+    the others — any shared path works: the ranks of one node share /tmp).  `job_id` (or XSDBA_AMD_JOB_ID / the launcher's
+    run id in the environment) tells this job's token from one a crashed earlier job left at the same path."""
     from ._lib import check, load
 
     buf = (C.c_char * COMM_ID_BYTES)()
@@ -74,34 +119,7 @@ def init_comm(ctx, rank: int, world: int, token_file: str | None = None) -> None
         else:
             if not token_file:
                 raise ValueError("init_comm needs torch.distributed to be initialised or a token_file shared by the ranks")
-            # A token left by an earlier job (or an earlier init_comm of this one) must never be taken for this one's: rank 0
-            # removes whatever is there before it writes, the others accept only a complete file written after they started
-            # waiting, and rank 0 removes the file once every rank has had time to join (comm_init returns when all have).
-            if rank == 0:
-                try:
-                    os.unlink(token_file)
-                except FileNotFoundError:
-                    pass
-                tmp = f"{token_file}.{os.getpid()}.tmp"
-                with open(tmp, "wb") as f:
-                    f.write(bytes(buf.raw))
-                os.replace(tmp, token_file)
-            else:
-                t0 = time.time()
-                while True:
-                    try:
-                        st = os.stat(token_file)
-                        if st.st_size == COMM_ID_BYTES and st.st_mtime >= t0 - 1.0:
-                            with open(token_file, "rb") as f:
-                                raw = f.read(COMM_ID_BYTES)
-                            if len(raw) == COMM_ID_BYTES:
-                                buf.raw = raw
-                                break
-                    except FileNotFoundError:
-                        pass
-                    if time.time() - t0 > 120:
-                        raise TimeoutError(f"no fresh RCCL token at {token_file} (a file older than this call is ignored)")
-                    time.sleep(0.01)
+            buf.raw = _token_through_file(bytes(buf.raw), rank, token_file, _job_nonce(job_id), timeout)
     check(load().xsdba_hip_comm_init(ctx.handle, buf, C.c_int(rank), C.c_int(world)), "comm_init")
     if world > 1 and dist is None and rank == 0:
         try:

@@ -81,23 +81,25 @@ def cell_time_view(da: DataArray, dim: str = "time"):
     cell_dims = tuple(d for d in da.dims if d != dim)
     dev = getattr(da, "device_data", None)
     if dev is not None and getattr(da, "_host", None) is None:
-        # device-resident data: (cells..., time) is a reshape of the buffer, (time, cells...) the time-major view of it
-        # (the buffer's own dimension order counts: `da` may be a relabelled — lazily transposed — view of it)
+        # device-resident data: (cells..., time) is a reshape of the buffer, (time, cells...) the time-major view of it.
+        # The buffer's own dimension order counts (`da` may be a relabelled — lazily transposed — view of it): the views are
+        # only handed out when the buffer orders the cells the way the labels do, because callers pair the cells of several
+        # arrays by position after `x.transpose(*other.dims)`; anything else takes the labelled-order host path below.
         pdims = tuple(da.device_dims)
-        ax = pdims.index(dim)
-        cell_dims = tuple(d for d in pdims if d != dim)
-        shape = tuple(dev.shape)
-        cell_shape = shape[:ax] + shape[ax + 1:]
-        n_cell, n_time = int(np.prod(cell_shape, dtype=np.int64)), shape[ax]
-        if ax == len(shape) - 1:
-            return dev.reshape(n_cell, n_time), cell_dims, cell_shape
-        if ax == 0 and getattr(dev, "cell_time_strides", None) is None:
-            from ._lib import DeviceArray
+        pax = pdims.index(dim)
+        if tuple(d for d in pdims if d != dim) == cell_dims:
+            shape = tuple(dev.shape)
+            cell_shape = shape[:pax] + shape[pax + 1:]
+            n_cell, n_time = int(np.prod(cell_shape, dtype=np.int64)), shape[pax]
+            if pax == len(shape) - 1:
+                return dev.reshape(n_cell, n_time), cell_dims, cell_shape
+            if pax == 0 and getattr(dev, "cell_time_strides", None) is None:
+                from ._lib import DeviceArray
 
-            v = DeviceArray.from_ptr(dev.ctx, dev.ptr, (n_time, n_cell), dev.dtype)
-            v._base = dev
-            v.logical_shape, v.cell_time_strides = (n_cell, n_time), (1, n_cell)
-            return v, cell_dims, cell_shape
+                v = DeviceArray.from_ptr(dev.ctx, dev.ptr, (n_time, n_cell), dev.dtype)
+                v._base = dev
+                v.logical_shape, v.cell_time_strides = (n_cell, n_time), (1, n_cell)
+                return v, cell_dims, cell_shape
     v = np.moveaxis(da.values, ax, -1)
     cell_shape = v.shape[:-1]
     return v.reshape(-1, v.shape[-1]), cell_dims, cell_shape
