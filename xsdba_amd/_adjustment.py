@@ -29,7 +29,7 @@ from . import utils as u
 from .base import Grouper, map_blocks, map_groups
 from .detrending import BaseDetrend, MeanDetrend, NoDetrend, PolyDetrend, RollingMeanDetrend
 from .labeled import Coordinate, DataArray, Dataset, as_dataarray, full_like
-from .utils import cell_time_view, table_view
+from .utils import cell_time_pair, cell_time_view, table_view
 
 
 def _unsupported(**opts):
@@ -160,9 +160,8 @@ def _prep_train(ds, group):
     gidx, G = group.group_index(ref)
     tb = _TrainBlock()
     if not group.add_dims:
-        hist = hist.transpose(*ref.dims)
-        tb.r2, cell_dims, cell_shape = cell_time_view(ref.astype(dt) if ref.dtype != dt else ref, group.dim)
-        tb.h2, _, _ = cell_time_view(hist.astype(dt) if hist.dtype != dt else hist, group.dim)
+        tb.r2, tb.h2, cell_dims, cell_shape = cell_time_pair(ref.astype(dt) if ref.dtype != dt else ref,
+                                                             hist.astype(dt) if hist.dtype != dt else hist, group.dim)
         tb.gidx_r = tb.gidx_h = gidx
         tb.same = True
         return ref, tb, gidx, G, cell_dims, cell_shape, dt

@@ -115,18 +115,16 @@ template <int EPT> struct CellCfg {
     static constexpr int WPL = (NWORDS + 63) / 64;  // bit-vector words per lane
     static constexpr int BITW = WPL * 64;
     static constexpr int NWAVE = NT / 64;
-    static constexpr int CNTN = NT + 2 * (NT / 16);  // padded per-thread counter arrays: 18 dwords per 16 threads (8-byte
-                                                     // aligned chunks, conflict-free as ds_read_b64 at a lane stride of 72 bytes)
-    static constexpr int BS = NT + 8 * (NT / 16);    // padded base row (u16 units): 24 per 16 threads (16-byte aligned chunks)
+    static constexpr int WROW = 256 + 8;             // dwords per wave-private counter row of the sort's stable passes (<= 256
+                                                     // digits; + 8: the scan's reads across the rows spread over the banks)
     static constexpr size_t off_keys = 0;
     static constexpr size_t off_idx0 = off_keys + (size_t)TPAD * 4;
     static constexpr size_t off_idx1 = off_idx0 + (size_t)TPAD * 2;
     static constexpr size_t off_union = off_idx1 + (size_t)TPAD * 2;
-    // sort view of the union
-    static constexpr size_t off_cntlo = off_union;
-    static constexpr size_t off_cnthi = off_cntlo + (size_t)CNTN * 4;
-    static constexpr size_t off_base = off_cnthi + (size_t)CNTN * 4;
-    static constexpr size_t sort_end = off_base + (size_t)16 * BS * 2;
+    // sort view of the union: the first pass's histogram (2^14 u16 bins), behind it the stable passes' counter rows
+    static constexpr size_t off_hist = off_union;
+    static constexpr size_t off_wcnt = off_hist + (size_t)(1 << 14) * 2;
+    static constexpr size_t sort_end = off_wcnt + (size_t)NWAVE * WROW * 4;
     // select view of the union
     static constexpr size_t off_rank = off_union;
     static constexpr size_t off_bits = off_rank + (size_t)TPAD * 2;
@@ -136,218 +134,200 @@ template <int EPT> struct CellCfg {
 };
 
 // Phase B: LSD radix sort of the time indexes by the keys in LDS (valid keys lie in [kmin, kmin + range], NaN / padding
-// are 0xFFFFFFFF), then rank[t] = position of t.  Returns the sorted index array (one of the two u16 buffers; the other
-// one is free afterwards).  stop_after == 2: return before building rank[]; 3: rank[] goes into that other buffer
-// (written by the last stable pass), with `nan_rank` (when >= 0) in place of the positions >= nvalid: the three-stream
-// kernel points NaN / padding steps at a scratch word of its bit-vectors and toggles without looking at nvalid.
+// are 0xFFFFFFFF), then rank[t] = position of t.  Returns the sorted index array (the upper u16 half of the handle buffer;
+// the lower half is free afterwards).  stop_after == 2: no rank[]; 3: rank[] goes into that lower half, with `nan_rank`
+// (when >= 0) in place of the positions >= nvalid: the three-stream kernel points NaN / padding steps at a scratch word of
+// its bit-vectors and toggles without looking at nvalid; else rank[] goes to off_rank.
+//
+// What is sorted are 32-bit HANDLES, (r >> 14) << 14 | time index with r = key - kmin (NaN / padding: range + 1): the time
+// index needs 14 bits (TPAD <= 16384), the 18 bits above it hold every key bit the first pass has not consumed — so the
+// passes after the first never go back to keys[] (eleven random LDS reads per thread and pass in round 3's sort) and read
+// their input as consecutive dwords.
+//   pass 1: the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no information): a
+//           counting sort with LDS atomics — 16384 u16 bins packed two per dword, histogram by ds_add (fused into the
+//           series' load by cell_load_sort), exclusive scan (16 bins per thread), slots by returning ds_add;
+//   then:   the remaining R = nbits - 14 bits in ceil(R / 8) STABLE counting passes of up to 8 bits.  Wave w owns the 64 EPT
+//           consecutive places [w 64 EPT, (w + 1) 64 EPT) and takes them in EPT rounds of 64 consecutive places, one per lane;
+//           a returning ds_add on a counter row PRIVATE to the wave gives every element the number of equal digits in front
+//           of it inside the wave's range — the LDS serves the lanes of one instruction that hit the same word in ascending
+//           lane order, and the instructions of a wave in program order (scripts/ubench/atomic_order.hip: 1.4e11 returning
+//           atomics over every kind of lane -> address map, 16 waves at once, not one out of order), which is exactly
+//           stability.  A scan over (digit, wave) turns the rows into base slots; slot = base + that number.
+//           Round 3's stable passes took 4 bits each with per-thread packed-nibble counts (410 VALU instructions per thread
+//           and pass, two passes for the 7 bits left of a temperature series); one 7-bit pass now, the handles in registers
+//           across it, so that it sorts in place.
 #ifndef XS_SORT_STOP
 #define XS_SORT_STOP 0  // (scripts/ubench/train3_bench.hip builds with 1..6 to time the sort's phases; the library never does)
 #endif
-// fused (with dgl): the load phase has already counted the valid keys into the first pass's histogram — on the low 14 bits of
-// the KEYS, which are the digits of (key - kmin) when kmin is a multiple of 2^14 (cell_load_sort rounds it down) — and kept
-// every element's digit (dgl: the two elements of load round j, 16 bits each; bit 15 = NaN / padding, whose digit is only
-// known with the range).  The pass then starts at its scan, and its scatter deals the elements out in the load's order.
+// fused: the load phase has already counted the valid keys into the first pass's histogram — on the low 14 bits of the KEYS,
+// which are the digits of (key - kmin) when kmin is a multiple of 2^14 (cell_load_sort rounds it down).
 template <int EPT>
 __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *smem, uint32_t *red, int tid, int nvalid,
                                                               uint32_t kmin, uint32_t range, int stop_after, bool hist_zeroed = false,
-                                                              int nan_rank = -1, bool fused = false,
-                                                              const uint32_t *dgl = nullptr)
+                                                              int nan_rank = -1, bool fused = false)
 {
     using Cfg = CellCfg<EPT>;
-    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD, BS = Cfg::BS;
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem + Cfg::off_keys);
+    constexpr int NT = Cfg::NT, TPAD = Cfg::TPAD;
+    static_assert(TPAD <= (1 << 14), "a handle keeps the time index in 14 bits");
+    const uint32_t *keys = reinterpret_cast<const uint32_t *>(smem + Cfg::off_keys);
+    uint32_t *H = reinterpret_cast<uint32_t *>(smem + Cfg::off_idx0);       // [TPAD] handles (the two u16 buffers' space)
     uint16_t *idx0 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx0);
     uint16_t *idx1 = reinterpret_cast<uint16_t *>(smem + Cfg::off_idx1);
-    uint32_t *cntlo = reinterpret_cast<uint32_t *>(smem + Cfg::off_cntlo);
-    uint32_t *cnthi = reinterpret_cast<uint32_t *>(smem + Cfg::off_cnthi);
-    uint16_t *base = reinterpret_cast<uint16_t *>(smem + Cfg::off_base);
-    uint16_t *rank = reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + Cfg::off_hist);    // pass 1: 16384 u16 bins
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + Cfg::off_wcnt);    // later passes: [16][WROW] per-wave counters
+    uint16_t *rank = stop_after == 3 ? idx0 : reinterpret_cast<uint16_t *>(smem + Cfg::off_rank);
+    uint16_t *sorted = idx1;
     const int lane = tid & 63, wid = tid >> 6;
     static_assert(Cfg::NWAVE == 16, "waves_before() scans one DPP row of per-wave totals");
+    constexpr int D1 = 14, NB1 = 1 << D1, WROW = Cfg::WROW;
     const int nbits = 32 - __clz((int)(range + 1u) | 0);
-        // ---------------- B. LSD radix sort of the time indexes ----------------
-        // Pass 1 takes the 14 LOW bits in one go.  The first LSD pass need not be stable (its input order carries no
-        // information), so it is a counting sort with LDS atomics: 16384 u16 bins packed two per dword, histogram by
-        // ds_add, exclusive scan (16 bins per thread), slots by returning ds_add.  It replaces 3.5 nibble passes.
-        constexpr int D1 = 14, NB1 = 1 << D1;
-        {
-            uint32_t *hist = cntlo;  // NB1/2 dwords = 32 KB inside the sort scratch (cntlo/cnthi/base region)
-            if (!hist_zeroed) {  // (cell_load_sort clears it under the series' global loads, in front of a barrier it has anyway)
-                for (int i = tid; i < NB1 / 2; i += NT) hist[i] = 0u;
-                __syncthreads();
-            }
-            uint32_t dgp[(EPT + 1) / 2];  // the 14-bit digits of this thread's elements, two per register
-            const uint32_t d_nan = (range + 1u) & (NB1 - 1);  // the digit of NaN / padding keys
-            if (!fused) {
-#pragma unroll
-                for (int e = 0; e < EPT; e++) {
-                    uint32_t k = keys[tid * EPT + e];
-                    uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
-                    uint32_t d = r & (NB1 - 1);
-                    if (e & 1) dgp[e >> 1] |= d << 16; else dgp[e >> 1] = d;
-                    atomicAdd(&hist[d >> 1], 1u << (16 * (d & 1)));
-                }
-                __syncthreads();
-            }
-            if constexpr (XS_SORT_STOP == 1) return idx1;
-            {
-                constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
-                uint32_t wv[BPT / 2];
-                int run = 0;
-#pragma unroll
-                for (int i = 0; i < BPT / 2; i++) {
-                    wv[i] = hist[tid * (BPT / 2) + i];
-                    // fused: the NaN / padding keys were not counted by the load (their digit needs the range): the owner of their bin adds them
-                    if (fused && (int)(d_nan >> 4) == tid && (int)((d_nan & 15u) >> 1) == i) wv[i] += (uint32_t)(TPAD - nvalid) << (16 * (d_nan & 1u));
-                    run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16);
-                }
-                int incl = wave_incl_scan(run);
-                if (lane == 63) red[wid] = (uint32_t)incl;
-                __syncthreads();
-                const int woff = waves_before(red, lane, wid);
-                int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
-#pragma unroll
-                for (int i = 0; i < BPT / 2; i++) {
-                    int c0 = (int)(wv[i] & 0xFFFFu), c1 = (int)(wv[i] >> 16);
-                    hist[tid * (BPT / 2) + i] = (uint32_t)pre | ((uint32_t)(pre + c0) << 16);
-                    pre += c0 + c1;
-                }
-            }
+    const int R = nbits > D1 ? nbits - D1 : 0;           // key bits left after pass 1 (<= 18)
+    const int npass_rest = (R + 7) >> 3;                 // 0..3
+    const int db = npass_rest ? (R + npass_rest - 1) / npass_rest : 0;  // digit bits of the stable passes (<= 8)
+    const int ND = 1 << db;
+    uint32_t *wrow = wcnt + wid * WROW;                  // this wave's counter row
+    if (npass_rest)
+        for (int i = lane; i < ND; i += 64) wrow[i] = 0u;  // (only this wave touches the row before the first scan)
+    // ---------------- pass 1 ----------------
+    const uint32_t d_nan = (range + 1u) & (NB1 - 1);  // the digit of NaN / padding keys
+    constexpr int NL = (EPT + 1) / 2;                 // elements in the load's order: the pair 2 tid + j 2 NT, j < NL
+    if (!fused) {
+        if (!hist_zeroed) {
+            uint4 *hz = reinterpret_cast<uint4 *>(hist);
+            for (int i = tid; i < NB1 / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
             __syncthreads();
-            if constexpr (XS_SORT_STOP == 2) return idx1;
-            if (fused) {
+        }
 #pragma unroll
-                for (int j = 0; j < (EPT + 1) / 2; j++)
+        for (int j = 0; j < NL; j++) {
+            const int i = 2 * tid + j * 2 * NT;
+            if ((j + 1) * 2 * NT <= TPAD || i < TPAD) {
+                const uint2 kk = *reinterpret_cast<const uint2 *>(keys + i);
+                const uint32_t d0 = (kk.x == 0xFFFFFFFFu) ? d_nan : ((kk.x - kmin) & (NB1 - 1));
+                const uint32_t d1 = (kk.y == 0xFFFFFFFFu) ? d_nan : ((kk.y - kmin) & (NB1 - 1));
+                atomicAdd(&hist[d0 >> 1], 1u << (16 * (d0 & 1u)));
+                atomicAdd(&hist[d1 >> 1], 1u << (16 * (d1 & 1u)));
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (XS_SORT_STOP == 1) return idx1;
+    {
+        constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
+        uint32_t wv[BPT / 2];
+        int run = 0;
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int i = 2 * tid + j * 2 * NT + h;  // the load's element order
-                        if ((j + 1) * 2 * NT <= TPAD || i < TPAD) {
-                            const uint32_t f = (dgl[j] >> (16 * h)) & 0xFFFFu;
-                            const uint32_t d = (f & 0x8000u) ? d_nan : f;
-                            const int sh = 16 * (d & 1);
-                            uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
-                            idx1[(old >> sh) & 0xFFFFu] = (uint16_t)i;
-                        }
-                    }
-            } else {
+        for (int i = 0; i < BPT / 2; i++) {
+            wv[i] = hist[tid * (BPT / 2) + i];
+            // fused: the NaN / padding keys were not counted by the load (their digit needs the range): the owner of their bin adds them
+            if (fused && (int)(d_nan >> 4) == tid && (int)((d_nan & 15u) >> 1) == i) wv[i] += (uint32_t)(TPAD - nvalid) << (16 * (d_nan & 1u));
+            run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16);
+        }
+        int incl = wave_incl_scan(run);
+        if (lane == 63) red[wid] = (uint32_t)incl;
+        __syncthreads();
+        const int woff = waves_before(red, lane, wid);
+        int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
 #pragma unroll
-                for (int e = 0; e < EPT; e++) {
-                    const uint32_t d = (e & 1) ? (dgp[e >> 1] >> 16) : (dgp[e >> 1] & 0xFFFFu);
+        for (int i = 0; i < BPT / 2; i++) {
+            int c0 = (int)(wv[i] & 0xFFFFu), c1 = (int)(wv[i] >> 16);
+            hist[tid * (BPT / 2) + i] = (uint32_t)pre | ((uint32_t)(pre + c0) << 16);
+            pre += c0 + c1;
+        }
+    }
+    __syncthreads();
+    if constexpr (XS_SORT_STOP == 2) return idx1;
+    {
+        // slots by returning atomics; what is stored: the handle, or — narrow keys, no further pass — the final arrays
+        const bool last = npass_rest == 0;
+        const bool rank_here = last && stop_after == 3;   // (rank[] elsewhere overlays the histogram: a pass of its own below)
+#pragma unroll
+        for (int j = 0; j < NL; j++) {
+            const int i = 2 * tid + j * 2 * NT;
+            if ((j + 1) * 2 * NT <= TPAD || i < TPAD) {
+                const uint2 kk = *reinterpret_cast<const uint2 *>(keys + i);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t k = h ? kk.y : kk.x;
+                    const uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
+                    const uint32_t d = r & (NB1 - 1);
                     const int sh = 16 * (d & 1);
-                    uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
-                    idx1[(old >> sh) & 0xFFFFu] = (uint16_t)(tid * EPT + e);
-                }
-            }
-            __syncthreads();
-        }
-        if constexpr (XS_SORT_STOP == 3) return idx1;
-        int cur = 1;
-        const int npass_rest = nbits > D1 ? (nbits - D1 + 3) / 4 : 0;
-        for (int p = 0; p < npass_rest; p++) {
-            const uint16_t *src = cur ? idx1 : idx0;
-            uint16_t *dst = cur ? idx0 : idx1;
-            const int shift = D1 + 4 * p;
-            uint64_t cnt = 0;
-            uint16_t ids[EPT];
-            uint64_t dgs = 0, lrs = 0;
-#pragma unroll
-            for (int e = 0; e < EPT; e++) {
-                uint16_t id = src[tid * EPT + e];
-                uint32_t k = keys[id];
-                uint32_t r = (k == 0xFFFFFFFFu) ? range + 1u : k - kmin;
-                uint32_t d = (r >> shift) & 15u;
-                ids[e] = id;
-                dgs |= (uint64_t)d << (4 * e);
-                lrs |= ((cnt >> (4 * d)) & 15ull) << (4 * e);  // rank among this thread's earlier equal digits
-                cnt += 1ull << (4 * d);
-            }
-            const int pi = tid + 2 * (tid >> 4);
-            cntlo[pi] = (uint32_t)cnt;
-            cnthi[pi] = (uint32_t)(cnt >> 32);
-            __syncthreads();
-            if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
-            {   // transposed scan: wave w owns the digits 2w and 2w + 1 (the two nibbles of one byte of the counter words), lane
-                // `chunk` the threads 16*chunk .. 16*chunk+15: both running counts ride in one register, 16 bits each
-                // (a count is at most TPAD < 2^16).  Eight waves do the reading for sixteen digits — every counter word is read by
-                // four threads instead of eight —, and a last pass over fewer than four bits keeps still fewer waves busy: the
-                // waves of digits that cannot occur neither read the counters nor write base rows nobody will look at.
-                const int w2 = tid >> 6, chunk = tid & 63;
-                const int bits_here = min(4, nbits - shift), nd = 1 << bits_here;
-                const bool live = 2 * w2 < nd;  // (wave-uniform; nd is even)
-                const uint32_t *arrp = w2 < 4 ? cntlo : cnthi;
-                const int sh = 8 * (w2 & 3);
-                uint32_t run = 0u;  // digit 2w in the low half, 2w + 1 in the high half
-                uint32_t pre[16];
-                if (live) {
-                    // the chunk's 16 counter words in eight 8-byte reads (left to itself the compiler emits ds_read2_b32)
-                    uint32_t cw[16];
-                    lds_read_words64<16>(arrp + 18 * chunk, cw);
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        const uint32_t b = cw[k] >> sh;
-                        pre[k] = run;
-                        run += (b & 15u) | ((b & 0xF0u) << 12);
+                    const uint32_t old = atomicAdd(&hist[d >> 1], 1u << sh);
+                    const int pos = (int)((old >> sh) & 0xFFFFu);
+                    if (!last) H[pos] = ((r >> D1) << D1) | (uint32_t)(i + h);
+                    else {
+                        sorted[pos] = (uint16_t)(i + h);
+                        if (rank_here) rank[i + h] = (uint16_t)((nan_rank >= 0 && pos >= nvalid) ? nan_rank : pos);
                     }
                 }
-                const uint32_t incl = (uint32_t)wave_incl_scan((int)run);
-                if (lane == 63) red[wid] = incl;
-                __syncthreads();
-                // digits before 2w: both halves of the packed totals of the waves before this one; before 2w + 1: + this wave's 2w
-                const uint32_t wb = (uint32_t)waves_before(red, lane, wid);
-                const uint32_t tot_here = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t off0 = (wb & 0xFFFFu) + (wb >> 16), off1 = off0 + (tot_here & 0xFFFFu);
-                const uint32_t ex = incl - run;
-                const uint32_t b0 = off0 + (ex & 0xFFFFu), b1 = off1 + (ex >> 16);
-                if (live) {
-                    // the chunk's 16 bases of either digit: 32 contiguous bytes, 16-byte aligned -> two 16-byte stores each
-                    uint32_t pk0[8], pk1[8];
+            }
+        }
+        __syncthreads();
+    }
+    if constexpr (XS_SORT_STOP == 3) return idx1;
+    // ---------------- the stable passes ----------------
+    for (int p = 0; p < npass_rest; p++) {
+        const int shift = D1 + db * p;
+        const bool last = p == npass_rest - 1;
+        uint32_t hd[EPT], od[EPT];  // handles and, per element, the number of equal digits in front of it in this wave's range
+        {
+            const uint32_t *src = H + wid * (64 * EPT) + lane;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const uint32_t a = pre[2 * k], c = pre[2 * k + 1];
-                        pk0[k] = ((b0 + (a & 0xFFFFu)) & 0xFFFFu) | ((b0 + (c & 0xFFFFu)) << 16);
-                        pk1[k] = ((b1 + (a >> 16)) & 0xFFFFu) | ((b1 + (c >> 16)) << 16);
-                    }
-                    uint4 *d0 = reinterpret_cast<uint4 *>(base + (2 * w2) * BS + 24 * chunk), *d1 = reinterpret_cast<uint4 *>(base + (2 * w2 + 1) * BS + 24 * chunk);
-                    d0[0] = make_uint4(pk0[0], pk0[1], pk0[2], pk0[3]);
-                    d0[1] = make_uint4(pk0[4], pk0[5], pk0[6], pk0[7]);
-                    d1[0] = make_uint4(pk1[0], pk1[1], pk1[2], pk1[3]);
-                    d1[1] = make_uint4(pk1[4], pk1[5], pk1[6], pk1[7]);
+            for (int j = 0; j < EPT; j++) hd[j] = src[64 * j];
+#pragma unroll
+            for (int j = 0; j < EPT; j++) od[j] = atomicAdd(&wrow[(hd[j] >> shift) & (uint32_t)(ND - 1)], 1u);
+        }
+        __syncthreads();
+        if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
+        {   // scan over the counters in digit-major order (digit d of wave w at d 16 + w): thread t owns `per` consecutive ones
+            const int NDW = ND << 4, per = NDW > NT ? NDW >> 10 : 1;  // (1, 2 or 4)
+            uint32_t c[4];
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = tid * per + k;
+                c[k] = (k < per && i < NDW) ? wcnt[(i & 15) * WROW + (i >> 4)] : 0u;
+                run += (int)c[k];
+            }
+            const int incl = wave_incl_scan(run);
+            if (lane == 63) red[wid] = (uint32_t)incl;
+            __syncthreads();
+            int pre = waves_before(red, lane, wid) + incl - run;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = tid * per + k;
+                if (k < per && i < NDW) wcnt[(i & 15) * WROW + (i >> 4)] = (uint32_t)pre;
+                pre += (int)c[k];
+            }
+        }
+        __syncthreads();
+        if constexpr (XS_SORT_STOP == 5) { if (p == 0) return idx1; }
+        {
+            uint32_t bs[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; j++) bs[j] = wrow[(hd[j] >> shift) & (uint32_t)(ND - 1)];
+            if (!last) {
+#pragma unroll
+                for (int j = 0; j < EPT; j++) H[bs[j] + od[j]] = hd[j];  // in place: every handle sits in a register
+                for (int i = lane; i < ND; i += 64) wrow[i] = 0u;         // (this wave's row, behind its own reads: the next pass)
+            } else {
+                // the last pass leaves the final arrays where the handles were (nobody reads those any more)
+#pragma unroll
+                for (int j = 0; j < EPT; j++) {
+                    const int pos = (int)(bs[j] + od[j]);
+                    const uint32_t t = hd[j] & (uint32_t)((1 << D1) - 1);
+                    sorted[pos] = (uint16_t)t;
+                    if (stop_after != 2) rank[t] = (uint16_t)((nan_rank >= 0 && pos >= nvalid) ? nan_rank : pos);
                 }
             }
-            __syncthreads();
-            if constexpr (XS_SORT_STOP == 5) { if (p == 0) return idx1; }
-            {
-                const int pb = tid + 8 * (tid >> 4);
-                // stop_after == 3: the last pass also leaves rank[time step] in the buffer it read from (every thread took its
-                // indexes out of it before the first barrier of the pass) — no separate pass over the sorted order afterwards
-                const bool fuse_rank = stop_after == 3 && p == npass_rest - 1;
-                uint16_t *rk = const_cast<uint16_t *>(src);
-#pragma unroll
-                for (int e = 0; e < EPT; e++) {
-                    int d = (int)((dgs >> (4 * e)) & 15u);
-                    int pos = (int)base[d * BS + pb] + (int)((lrs >> (4 * e)) & 15u);  // no read-modify-write chain
-                    dst[pos] = ids[e];
-                    if (fuse_rank) rk[ids[e]] = (uint16_t)((nan_rank >= 0 && pos >= nvalid) ? nan_rank : pos);
-                }
-            }
-            __syncthreads();
-            if constexpr (XS_SORT_STOP == 6) { if (p == 0) return idx1; }
-            cur ^= 1;
         }
-        const uint16_t *sorted = cur ? idx1 : idx0;
-        if (stop_after == 2) return sorted;
-        if (stop_after == 3) {
-            if (npass_rest == 0) {  // narrow keys: no stable pass to ride on
-                uint16_t *rk = cur ? idx0 : idx1;
-                for (int r = tid; r < TPAD; r += NT) rk[sorted[r]] = (uint16_t)((nan_rank >= 0 && r >= nvalid) ? nan_rank : r);
-                __syncthreads();
-            }
-            return sorted;
-        }
+        __syncthreads();
+        if constexpr (XS_SORT_STOP == 6) { if (p == 0) return idx1; }
+    }
+    if (npass_rest == 0 && stop_after != 2 && stop_after != 3) {  // narrow keys, rank[] behind the histogram's space
         for (int r = tid; r < TPAD; r += NT) rank[sorted[r]] = (uint16_t)r;
         __syncthreads();
-
-        return sorted;
+    }
+    return sorted;
 }
 
 // Phases A + B, shared by k_train_cell and k_qdm_cell: the cell's series -> order-preserving keys in LDS, the time
@@ -379,7 +359,6 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         int nv = 0;
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
         bool fused = false;                 // the load has counted the histogram of the sort's first pass
-        uint32_t dgl[(EPT + 1) / 2] = {};   // ... and kept the digits of its elements
         const int Ti = (int)T;  // <= TPAD
         if ((reinterpret_cast<uintptr_t>(x) & 7) == 0) {  // 8-byte aligned rows: two elements per load
             // all the loads of the series are issued before the first one is consumed (one HBM latency per array
@@ -395,12 +374,12 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 v2[j] = *reinterpret_cast<const float2 *>(x + min(i, Te - 2));
             }
             if constexpr (!Hook::uses_sort_scratch) {  // the histogram of the sort's first pass, cleared while the loads are in flight
-                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
+                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_hist);
                 for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
                 __syncthreads();  // ... and counted into as the loads arrive (see radix_sort_indexes: fused)
                 fused = true;
             }
-            uint32_t *hist1 = reinterpret_cast<uint32_t *>(smem + Cfg::off_cntlo);
+            uint32_t *hist1 = reinterpret_cast<uint32_t *>(smem + Cfg::off_hist);
             // keys and their statistics in integer arithmetic (to_key() through compares and selects costs three times the
             // instructions, and selects on VCC stall each other: scripts/ubench/issue_rate.hip): `ok` is all ones for a number
             // and 0 for a NaN; a NaN's key is 0xFFFFFFFF — no effect on the minimum — and it enters the maximum as 0
@@ -427,10 +406,8 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                     if constexpr (!Hook::uses_sort_scratch) {
                         // the first pass of the sort counts its 14-bit digits here: no second walk over the keys, no barrier of its own
                         const uint32_t d0 = k0 & 0x3FFFu, d1 = k1 & 0x3FFFu;
-                        const bool n0 = k0 == 0xFFFFFFFFu, n1 = k1 == 0xFFFFFFFFu;
-                        if (!n0) atomicAdd(&hist1[d0 >> 1], 1u << (16 * (d0 & 1u)));
-                        if (!n1) atomicAdd(&hist1[d1 >> 1], 1u << (16 * (d1 & 1u)));
-                        dgl[j] = (n0 ? 0x8000u : d0) | ((n1 ? 0x8000u : d1) << 16);
+                        if (k0 != 0xFFFFFFFFu) atomicAdd(&hist1[d0 >> 1], 1u << (16 * (d0 & 1u)));
+                        if (k1 != 0xFFFFFFFFu) atomicAdd(&hist1[d1 >> 1], 1u << (16 * (d1 & 1u)));
                     }
                 }
             }
@@ -441,7 +418,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
                 if (k != 0xFFFFFFFFu) { nv++; kmin = min(kmin, k); kmax = max(kmax, k); }
             }
             if constexpr (!Hook::uses_sort_scratch) {
-                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_cntlo);
+                uint4 *hz = reinterpret_cast<uint4 *>(smem + Cfg::off_hist);
                 for (int i = tid; i < (1 << 14) / 8; i += NT) hz[i] = make_uint4(0u, 0u, 0u, 0u);
             }
         }
@@ -484,7 +461,7 @@ __device__ __forceinline__ const uint16_t *cell_load_sort(const float *__restric
         // (wave-uniform) and writes its all-NaN results directly.  keys[] is complete; the barrier protects red[].
         if (skip_empty && nvalid == 0) { __syncthreads(); return nullptr; }
         hook(keys, Ti, tid);
-        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank, fused, dgl);
+        return radix_sort_indexes<EPT>(smem, red, tid, nvalid, kmin, range, stop_after, !Hook::uses_sort_scratch, nan_rank, fused);
 }
 
 // Where phase C finds values: the series' keys and the sorted index array in LDS (k_train_cell); train_long.hpp has

@@ -58,6 +58,9 @@ class BaseDetrend(ParametrizableWithDataset):
             if missing:
                 raise ValueError(f"trend lacks dimension(s) {missing} of the data")
             f2, _, _ = cell_time_view(trend.transpose(*cell_dims, dim), dim)
+            if type(f2).__name__ == "DeviceArray":  # (the factor of series_correction is a host array, [cell, time])
+                h = f2.download().reshape(f2.shape)
+                f2 = h.T if getattr(f2, "cell_time_strides", None) is not None else h
         out = hip.series_correction(x2.astype(dt, copy=False), f2.astype(dt, copy=False), self.kind, inverted, skip_zeros)
         coords = {k: c for k, c in da.coords.items() if k in cell_dims or k == dim}
         return DataArray(out.reshape(cell_shape + (out.shape[-1],)), cell_dims + (dim,), coords, dict(da.attrs), da.name).transpose(*da.dims)

@@ -11,7 +11,7 @@ import numpy as np
 from . import hip
 from .base import Grouper, parse_group
 from .labeled import Coordinate, DataArray, as_dataarray
-from .utils import cell_time_view
+from .utils import cell_time_pair, cell_time_view
 
 __all__ = ["adapt_freq", "jitter", "jitter_over_thresh", "jitter_under_thresh"]
 
@@ -81,8 +81,8 @@ def adapt_freq(ref, sim, *, group: Grouper | str, thresh="0 mm d-1"):
         raise NotImplementedError("Grouper(add_dims=...) is not implemented on the HIP path yet")
     th = quantity_to_float(thresh, ref, "thresh")
     dt = np.result_type(ref.dtype, sim.dtype, np.float32)
-    s2, cell_dims, cell_shape = cell_time_view(sim.astype(dt) if sim.dtype != dt else sim, group.dim)
-    r2, _, _ = cell_time_view((ref.astype(dt) if ref.dtype != dt else ref).transpose(*sim.dims), group.dim)
+    s2, r2, cell_dims, cell_shape = cell_time_pair(sim.astype(dt) if sim.dtype != dt else sim,
+                                                   ref.astype(dt) if ref.dtype != dt else ref, group.dim)
     gidx, G = group.group_index(sim)
     sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
     attrs = dict(sim.attrs)

@@ -105,6 +105,44 @@ def cell_time_view(da: DataArray, dim: str = "time"):
     return v.reshape(-1, v.shape[-1]), cell_dims, cell_shape
 
 
+def _is_dev(v) -> bool:
+    return type(v).__name__ == "DeviceArray"
+
+
+def _upload_like(host2d, like):
+    """the host ``[cell, time]`` block on the device, laid out like the device view `like` (cell-major, or the time-major view
+    `cell_time_view` hands out): the library takes the series of one call from ONE kind of memory in ONE layout"""
+    from ._lib import DeviceArray
+
+    strides = getattr(like, "cell_time_strides", None)
+    if strides is None:
+        return like.ctx.to_device(np.ascontiguousarray(host2d, like.dtype))
+    n_cell, n_time = host2d.shape
+    buf = like.ctx.to_device(np.ascontiguousarray(np.asarray(host2d, like.dtype).T))
+    v = DeviceArray.from_ptr(buf.ctx, buf.ptr, (n_time, n_cell), buf.dtype)
+    v._base = buf
+    v.logical_shape, v.cell_time_strides = (n_cell, n_time), (1, n_cell)
+    return v
+
+
+def cell_time_pair(a: DataArray, b: DataArray, dim: str = "time"):
+    """``[cell, time]`` views of `a` and of `b` with b's cells in a's (labelled) order, both in the same memory and layout:
+    (a2, b2, cell_dims, cell_shape).  The arrays whose cells are paired by position (ref / hist at training, sim / ref in
+    adapt_freq) come through here: a device-resident array stored in another cell order, or one array on the device and one
+    on the host, is brought to the layout of the other instead of being paired by buffer position."""
+    a2, cell_dims, cell_shape = cell_time_view(a, dim)
+    b2, _, _ = cell_time_view(b.transpose(*a.dims), dim)
+    da, db = _is_dev(a2), _is_dev(b2)
+    if da and db and getattr(a2, "cell_time_strides", None) != getattr(b2, "cell_time_strides", None):
+        h = b2.download().reshape(b2.shape)
+        b2, db = (h.T if getattr(b2, "cell_time_strides", None) is not None else h), False
+    if da and not db:
+        b2 = _upload_like(b2, a2)
+    elif db and not da:
+        a2 = _upload_like(a2, b2)
+    return a2, b2, cell_dims, cell_shape
+
+
 def table_view(tab: DataArray, cell_dims, prop: str, last: str | None = "quantiles", cell_shape=None):
     """[cell, group(, quantile)] contiguous view of a trained table with the cells ordered like `cell_dims`.
     Cell dimensions the table does not have (the members pooled by ``Grouper(add_dims=...)`` at training) are broadcast,
