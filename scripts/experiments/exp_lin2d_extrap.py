@@ -3,7 +3,7 @@
 np_interp_at evaluations per element cost."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from bench import group_index  # noqa: E402
 from xsdba_amd import hip  # noqa: E402
 ctx = hip.Context(0)

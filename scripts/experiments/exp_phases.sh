@@ -1,6 +1,6 @@
 #!/bin/bash
 # Phase timing of a kernel from experiment builds (run on the GPU box through gpurun):
-#   scripts/exp_phases.sh <workload> <lib1.so> <lib2.so> ...   (libraries under build_exp/, built with -DXS_*_STOP=n)
+#   scripts/experiments/exp_phases.sh <workload> <lib1.so> <lib2.so> ...   (libraries under build_exp/, built with -DXS_*_STOP=n)
 # Each library is copied over the in-tree one (on the box's scratch copy only) and the bench line's kernel table printed.
 W=$1; shift
 cp xsdba_amd/lib/libxsdba_hip.so /tmp/libxsdba_release.so

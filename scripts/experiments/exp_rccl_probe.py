@@ -1,6 +1,6 @@
 """probe: does RCCL initialise on this box — torch's bundled copy and the system copy through our C ABI"""
 import os, sys, ctypes
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 which = sys.argv[1]
 if which == "torch":
     import torch, torch.distributed as dist

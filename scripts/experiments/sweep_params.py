@@ -1,5 +1,5 @@
 """Train + adjust timings over the options a user is likely to vary (window, nodes, series length, kind) — looks for settings that
-fall off the fast kernels.   python scripts/sweep_params.py [cells]"""
+fall off the fast kernels.   python scripts/experiments/sweep_params.py [cells]"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from xsdba_amd import hip

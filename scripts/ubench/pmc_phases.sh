@@ -3,7 +3,7 @@
 # so one rocprofv3 --pmc pass over the binary yields a counter row per phase; differences of consecutive rows attribute the
 # counters to load / sort / build / toggles+recount+scan / select.   scripts/ubench/pmc_phases.sh <tag> [cells]
 TAG=${1:-phases}; CELLS=${2:-64800}
-REPO=$(pwd); OUT=$REPO/gpurun_out/r03; mkdir -p $OUT
+REPO=$(pwd); OUT=$REPO/gpurun_out/r04; mkdir -p $OUT
 BIN=$REPO/scripts/ubench/build/train3_bench
 cd /tmp && export TMPDIR=/tmp
 P1="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY"

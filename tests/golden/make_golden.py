@@ -900,6 +900,53 @@ def gen_window_handcase_nonreducing():
     return 1
 
 
+def gen_week_season_handcase():
+    """Hand-checkable vectors for the two groupings that had none: `time.season` and `time.week` (base.py:196-198, 312-327).
+    x = arange(731) on 2000-01-01 .. 2001-12-31 (standard calendar).  Everything comes from python's own `datetime` — the
+    ISO week of `date.isocalendar()`, the season of the month — with explicit loops, independent of xsdba_amd.calendar, of
+    the oracle's row gathering and of rolling_construct above: winter 2000 without a window is the mean over January,
+    February and December 2000 plus January, February and December 2001."""
+    import datetime
+
+    start = datetime.date(2000, 1, 1)
+    n = 731
+    dates = [start + datetime.timedelta(days=k) for k in range(n)]
+    assert dates[-1] == datetime.date(2001, 12, 31)
+    x = np.arange(n, dtype=np.float64)
+    season0 = np.array([dt.month % 12 // 3 for dt in dates], np.int32)          # DJF = 0, MAM = 1, JJA = 2, SON = 3
+    week0 = np.array([dt.isocalendar()[1] - 1 for dt in dates], np.int32)        # ISO week 1..53 -> 0..52
+    assert week0[0] == 51 and week0[2] == 0          # Saturday 2000-01-01 is in ISO week 52 of 1999; Monday 2000-01-03 opens week 1
+    assert season0[0] == 0 and season0[59] == 0 and season0[60] == 1   # 2000-02-29 is winter, 2000-03-01 spring
+
+    def means(gidx, G, W):
+        out = np.full(G, np.nan)
+        h = W // 2
+        for g in range(G):
+            vals = [x[k + o] for k in range(n) if gidx[k] == g for o in range(-h, W - h) if 0 <= k + o < n]
+            if vals:
+                out[g] = sum(vals) / len(vals)
+        return out
+
+    d = dict(x=x, season_gidx=season0, week_gidx=week0, season_plain=means(season0, 4, 1), season_win5=means(season0, 4, 5),
+             week_plain=means(week0, 53, 1), week_win3=means(week0, 53, 3))
+    djf = [k for k in range(n) if dates[k].month in (12, 1, 2)]
+    assert d["season_plain"][0] == sum(djf) / len(djf) and len(djf) == 31 + 29 + 31 + 31 + 28 + 31
+    # ISO week 53 does not occur in 2000 / 2001 (2004 and 2009 have one): its group stays empty -> NaN
+    assert np.isnan(d["week_plain"][52]) and not np.isnan(d["week_plain"][51])
+    # the median of a season's row of arange, by hand: the middle of its sorted members
+    med = np.full(4, np.nan)
+    for g in range(4):
+        m = sorted(k for k in range(n) if season0[k] == g)
+        med[g] = (m[(len(m) - 1) // 2] + m[len(m) // 2]) / 2.0
+    d["season_median"] = med
+    np.savez_compressed(OUT / "week_season_handcase.npz", **d)
+    return 1
+
+
+def main_round4():
+    print("week / season handcase:", gen_week_season_handcase())
+
+
 def main_round3():
     rng = np.random.default_rng(20260303)
     print("pre-processing, deterministic half:", gen_preproc_deterministic(rng))
@@ -925,11 +972,13 @@ def main():
 
 
 if __name__ == "__main__":
-    # `make_golden.py` regenerates the round-1 files, `make_golden.py round2` / `round3` the files added in those rounds (own seeds, so that
+    # `make_golden.py` regenerates the round-1 files, `make_golden.py round2` / `round3` / `round4` the files added in those rounds (own seeds, so that
     # neither run disturbs the other's vectors)
     if len(sys.argv) > 1 and sys.argv[1] == "round2":
         main_round2()
     elif len(sys.argv) > 1 and sys.argv[1] == "round3":
         main_round3()
+    elif len(sys.argv) > 1 and sys.argv[1] == "round4":
+        main_round4()
     else:
         main()

@@ -43,3 +43,20 @@ def test_window_group_bookkeeping_hand_case_nonreducing(hip, golden):
     np.testing.assert_allclose(r32[0], d["rank_pct"], rtol=1e-14, atol=1e-15)  # (x holds quarters: exact in float32, same ranks)
     tr32 = np.asarray(hip.polydetrend_trend(x32, d["gidx"], 12, W, d["time_ns"], 1))
     np.testing.assert_allclose(tr32[0], d["trend"], rtol=2e-7)
+
+
+def test_week_and_season_bookkeeping_hand_case(hip, golden):
+    """round 4: seasonal / weekly rows on the device against the python-datetime hand case (make_golden.py round4)"""
+    d = golden("week_season_handcase")
+    x = d["x"][None, :]
+    gs, gw = d["season_gidx"], d["week_gidx"]
+    np.testing.assert_allclose(hip.group_means(x, gs, 4, 1)[0], d["season_plain"], rtol=1e-14)
+    np.testing.assert_allclose(hip.group_means(x, gs, 4, 5)[0], d["season_win5"], rtol=1e-14)
+    np.testing.assert_allclose(hip.group_means(x, gw, 53, 1)[0], d["week_plain"], rtol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(hip.group_means(x, gw, 53, 3)[0], d["week_win3"], rtol=1e-14, equal_nan=True)
+    x32 = x.astype(np.float32)
+    med = hip.quantile_groups(x32, gs, 4, 1, np.array([0.5], np.float32))[0, :, 0]
+    np.testing.assert_allclose(med, d["season_median"], rtol=1e-6)
+    # the weekly medians through the training kernel too (53 groups, one of them empty -> NaN)
+    medw = hip.quantile_groups(x32, gw, 53, 1, np.array([0.5], np.float32))[0, :, 0]
+    assert np.isnan(medw[52]) and not np.isnan(medw[:52]).any()

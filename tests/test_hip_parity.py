@@ -590,8 +590,10 @@ def test_golden_qdm_dqm_pipeline(hip, golden, name):
         else:
             assert_close(scen, d[key], rtol=1e-5, what=key)
     if "dqm_af" in d.files:
+        # The golden group means are numpy's float32 means, ours float64 sums rounded once: the normalised values (x - mean, or
+        # x / mean of order 1) may differ by a few float32 ulps OF THE MEAN — 4 are allowed, on top of the 1e-5 relative.
         scale = float(np.nanmax(np.abs(d["ref"])))
-        atol = 2e-6 * scale if kind == "+" else 2e-6
+        atol = 4 * float(np.spacing(np.float32(scale if kind == "+" else 1.0)))
         af, hq, sc = hip.dqm_train(d["ref"], d["hist"], gidx, G, W, d["q"], kind)
         assert_close(sc, d["dqm_scaling"], rtol=1e-5, atol=atol, what="scaling")
         assert_close(hq, d["dqm_hist_q"], rtol=1e-5, atol=atol, what="dqm hist_q")

@@ -379,3 +379,28 @@ def test_window_group_bookkeeping_hand_case_nonreducing(golden):
     np.testing.assert_allclose(r[0], d["rank_pct"], rtol=1e-14, atol=1e-15)
     tr = oracle.polydetrend_trend(x, d["gidx"], 12, W, d["time_ns"], 1)
     np.testing.assert_allclose(tr[0], d["trend"], rtol=1e-12)
+
+
+# ---- round 4: hand cases for the groupings that had none (make_golden.py round4: python datetime + explicit loops)
+def test_week_and_season_bookkeeping_hand_case(golden):
+    """`time.season` / `time.week` group indexes of the host mirror (base.py:196-198, 312-327 of the reference) against
+    python's own datetime, and the oracle's row gathering on them: seasonal / weekly means with and without a window."""
+    import xsdba_amd as xs
+    from xsdba_amd.labeled import DataArray
+
+    d = golden("week_season_handcase")
+    x = d["x"]
+    da = DataArray(x, dims=("time",), coords={"time": xs.date_range("2000-01-01", x.size, "standard").values})
+    gs, G = xs.Grouper("time.season").group_index(da)
+    assert G == 4
+    np.testing.assert_array_equal(gs, d["season_gidx"])
+    gw, G = xs.Grouper("time.week").group_index(da)
+    assert G == 53
+    np.testing.assert_array_equal(gw, d["week_gidx"])
+    x2 = x[None, :]
+    np.testing.assert_allclose(oracle.group_means(x2, gs, 4, 1)[0], d["season_plain"], rtol=1e-14)
+    np.testing.assert_allclose(oracle.group_means(x2, gs, 4, 5)[0], d["season_win5"], rtol=1e-14)
+    np.testing.assert_allclose(oracle.group_means(x2, gw, 53, 1)[0], d["week_plain"], rtol=1e-14, equal_nan=True)
+    np.testing.assert_allclose(oracle.group_means(x2, gw, 53, 3)[0], d["week_win3"], rtol=1e-14, equal_nan=True)
+    med = oracle.quantile_groups(x2, gs, 4, 1, np.array([0.5]))[0, :, 0]
+    np.testing.assert_allclose(med, d["season_median"], rtol=1e-14)

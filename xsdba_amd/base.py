@@ -517,30 +517,29 @@ def map_groups(reduces=None, main_only: bool = False, fused=None, **out_vars):
     that produces the result for ALL groups at once — the functions of the accelerated path pass their HIP
     implementation here; without it the wrapper falls back on ``group.apply(func, ...)`` like the reference.
     """
-    def_reduces = [Grouper.DIM]
-    if not main_only:
-        def_reduces.append(Grouper.ADD_DIMS)
-    reduces = reduces or def_reduces
+    if not reduces:
+        reduces = [Grouper.DIM] if main_only else [Grouper.DIM, Grouper.ADD_DIMS]
+
+    def _run_all_groups(func, dsblock, group, kwargs):
+        """the block's result for every group: the device implementation when the function has one, else the host loop"""
+        if fused is None:
+            return group.apply(func, dsblock, main_only=main_only, **kwargs)
+        out = fused(dsblock, group=group, **kwargs)
+        out.attrs.update(group=group.name, group_window=group.window,
+                         group_compute_dims=[group.dim, "window"] if group.window > 1 else [group.dim])
+        return out
 
     def _decorator(func):
-        decorator = map_blocks(reduces=reduces, **out_vars)
+        name = getattr(func, "__name__", "func")
 
-        def _apply_on_group(dsblock, **kwargs):
-            group = kwargs.pop("group")
-            if fused is not None:
-                out = fused(dsblock, group=group, **kwargs)
-                out.attrs["group"] = group.name
-                out.attrs["group_compute_dims"] = [group.dim] + (["window"] if group.window > 1 else [])
-                out.attrs["group_window"] = group.window
-                return out
-            return group.apply(func, dsblock, main_only=main_only, **kwargs)
+        def per_block(dsblock, group, **kwargs):
+            return _run_all_groups(func, dsblock, group, kwargs)
 
-        _apply_on_group.__name__ = f"group_{func.__name__}"
-        wrapper = decorator(_apply_on_group)
-        wrapper.__name__ = func.__name__
-        wrapper.__doc__ = func.__doc__
-        wrapper.__dict__["func"] = func
-        return wrapper
+        per_block.__name__ = f"group_{name}"  # (the name the failure message of map_blocks reports, as the reference's does)
+        mapped = map_blocks(reduces=reduces, **out_vars)(per_block)
+        mapped.__name__, mapped.__doc__ = name, func.__doc__
+        mapped.__dict__["func"] = func  # the raw per-group body stays reachable (base.py:776)
+        return mapped
 
     return _decorator
 

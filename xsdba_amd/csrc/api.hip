@@ -1011,7 +1011,7 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double) + (((size_t)G * sizeof(float) + 15) & ~(size_t)15);
         // (series long enough for the trend kernel to park its window means in the trend buffer keep the array)
         const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > xs::TREND_CH * 512 && T <= xs::TREND_CH * 1024) ? 1024u : trend_threads();  // as launch_trend
-        const bool means_in_regs = pl->W == 1 || T <= (int64_t)24 * tthr;
+        const bool means_in_regs = pl->W == 1 || T <= (int64_t)xs::TREND_CH * tthr;
         if (!trend && degree <= 1 && means_in_regs && tab_c <= (size_t)ctx->lds_limit && !getenv("XSDBA_HIP_TREND_ARRAY")) {
             void *cbuf;
             if ((rc = ensure(ctx, S_CM2, (size_t)C * G * 3 * sizeof(double), &cbuf))) return rc;
