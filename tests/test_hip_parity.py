@@ -590,10 +590,13 @@ def test_golden_qdm_dqm_pipeline(hip, golden, name):
         else:
             assert_close(scen, d[key], rtol=1e-5, what=key)
     if "dqm_af" in d.files:
-        # The golden group means are numpy's float32 means, ours float64 sums rounded once: the normalised values (x - mean, or
-        # x / mean of order 1) may differ by a few float32 ulps OF THE MEAN — 4 are allowed, on top of the 1e-5 relative.
-        scale = float(np.nanmax(np.abs(d["ref"])))
-        atol = 4 * float(np.spacing(np.float32(scale if kind == "+" else 1.0)))
+        # The golden group means are numpy's float32 means (pairwise summation: error up to log2(n) eps of the mean for a row of n
+        # values), ours float64 sums rounded once; the scaling is the difference of two such means.  Bound: 2 log2(n) eps32 x scale
+        # (n = the longest group row).  Measured: 10 ulps of the mean on the 10 950-value rows of group="time" (3.05e-4 at 300 K) —
+        # the 4 ulps round 3's review suggested do not hold there; round 3 allowed a flat 2e-6 x scale (20 ulps).
+        scale = float(np.nanmax(np.abs(d["ref"]))) if kind == "+" else 1.0
+        n_row = int(np.bincount(gidx[gidx >= 0]).max()) * W if gidx is not None and G > 1 else d["ref"].shape[-1]
+        atol = 2 * np.log2(max(n_row, 2)) * float(np.finfo(np.float32).eps) / 2 * scale
         af, hq, sc = hip.dqm_train(d["ref"], d["hist"], gidx, G, W, d["q"], kind)
         assert_close(sc, d["dqm_scaling"], rtol=1e-5, atol=atol, what="scaling")
         assert_close(hq, d["dqm_hist_q"], rtol=1e-5, atol=atol, what="dqm hist_q")
@@ -774,6 +777,38 @@ def test_long_series_train(hip, T, gname):
     assert_close(sc, esc, rtol=2.4e-7, atol=2e-5, what="scaling")
     assert_close(hq, ehq, rtol=2.4e-7, atol=1e-4, what="hist_q (dqm)")
     assert_close(af, eaf, rtol=2.4e-7, atol=1e-4, what="af (dqm)")
+
+
+@pytest.mark.parametrize("T", [21900, 13001])
+def test_long_series_key_ranges(hip, T):
+    """k_train_long's handle sort over the shapes a key range can take: a series that spans zero (the order-preserving keys of
+    negative and positive floats lie 2^31 apart: 32 significant bits — bit 31 travels beside the handles), 28-bit keys (two
+    stable passes), a handful of distinct values (no stable pass at all: narrow keys), a constant series, +-inf, a huge
+    dynamic range; rows that are only 4-byte aligned (odd T); bit-exact against the oracle"""
+    rng = np.random.default_rng(T + 5)
+    gidx, G, W = LONG_GROUPINGS["doy31"](T)
+    q = _nodes(20)
+    doy = np.arange(T) % 365
+    C = 7
+    x = np.empty((2, C, T), np.float32)
+    for a in range(2):
+        x[a, 0] = -2 + 15 * np.cos(2 * np.pi * doy / 365) + 4 * rng.standard_normal(T)          # degrees Celsius around zero
+        x[a, 1] = rng.gamma(0.6, 5.0, T) * (rng.random(T) < 0.6)                                    # precipitation with dry days
+        x[a, 2] = rng.integers(0, 7, T)                                                              # seven distinct values
+        x[a, 3] = 3.25                                                                               # one value
+        x[a, 4] = 280 + 10 * rng.standard_normal(T)
+        x[a, 4, rng.integers(0, T, 5)] = np.inf
+        x[a, 4, rng.integers(0, T, 5)] = -np.inf
+        x[a, 5] = np.sign(rng.standard_normal(T)) * 10.0 ** rng.uniform(-30, 30, T)                  # every exponent, both signs
+        x[a, 6] = -np.abs(100 + 30 * rng.standard_normal(T))                                        # negative only
+    x[:, :, rng.integers(0, T, 40)] = np.nan
+    ref, hist = x[0], x[1]
+    af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, "+")
+    assert_close(hq, ehq, rtol=0.0, what="hist_q")
+    assert_close(af, eaf, rtol=0.0, what="af")
+    got = hip.quantile_groups(hist, gidx, G, W, q)
+    assert_close(got, oracle.quantile_groups(hist, gidx, G, W, q), rtol=0.0, what="quantile_groups")
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -223,9 +223,11 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16);
         }
         int incl = wave_incl_scan(run);
-        if (lane == 63) red[wid] = (uint32_t)incl;
+        // (words 64.. of the scratch: with the histogram fused into the load no barrier lies between the all-reduce of
+        //  cell_load_sort, which reads words 0 .. 47, and this store — a slow wave may still be reading them)
+        if (lane == 63) red[64 + wid] = (uint32_t)incl;
         __syncthreads();
-        const int woff = waves_before(red, lane, wid);
+        const int woff = waves_before(red + 64, lane, wid);
         int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
 #pragma unroll
         for (int i = 0; i < BPT / 2; i++) {
