@@ -56,25 +56,28 @@ struct GlobalValsIdx {
     using value_type = float;
     const float *x;              // the series (read-only for the whole launch: plain cached loads)
     const uint16_t *sorted;      // time steps in rank order, written by this block's sort: read past the L1
+    int tlast;                   // the last time step of the series (ranks past the valid ones hold padding steps beyond it)
     __device__ __forceinline__ float at_time(int t) const { return x[t]; }
+    __device__ __forceinline__ int idx_load(int r) const { return (int)load_l2(sorted + r); }
+    __device__ __forceinline__ float val_load(int t) const { return x[min(t, tlast)]; }  // (lanes without a quantile look up anything)
     __device__ __forceinline__ void at_ranks(int r0, int r1, float &v0, float &v1) const
     {
-        const int t0 = (int)load_l2(sorted + r0), t1 = (int)load_l2(sorted + r1);
-        v0 = x[t0];
-        v1 = x[t1];
+        const int t0 = idx_load(r0), t1 = idx_load(r1);
+        v0 = val_load(t0);
+        v1 = val_load(t1);
     }
 };
 
 // Phase C behind a call: the walk's register allocation is then its own (inlined, its loops shared the 128 registers of a
 // 1024-thread block with whatever the sorts and the merge keep alive across the cell loop, and spilled in its group loop).
 template <bool DQM, bool TOG64, int EPT>
-__device__ __attribute__((noinline)) void long_phase_c(const float *x, const uint16_t *sorted_g, const uint16_t *rank, uint32_t *bits_all, int nvalid,
+__device__ __attribute__((noinline)) void long_phase_c(const float *x, int n_time, const uint16_t *sorted_g, const uint16_t *rank, uint32_t *bits_all, int nvalid,
                                                        int lane, int wid, const int *row_ptr, const int *row_sorted, const int *tog_ptr,
                                                        const int *tog_idx, const int *tog64, int G, const float *q, int Q, int kind, int mode,
                                                        int arr, int64_t c, float *af, float *out_hq, float *scaling, bool &flag_cell)
 {
     auto nostamp = [](int) {};
-    const GlobalValsIdx vals{x, sorted_g};
+    const GlobalValsIdx vals{x, sorted_g, n_time - 1};
     cell_group_quantiles<LongCfg<EPT>, false, DQM, TOG64>(vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q,
                                                      kind, mode, arr, c, af, out_hq, scaling, flag_cell, 0, nostamp);
 }
@@ -89,6 +92,7 @@ __device__ __forceinline__ int long_load_sort(const float *__restrict__ x, int T
     using L = LongCfg<EPT>;
     constexpr int NT = L::NT, TPAD = L::TPAD, NE = 2 * EPT, D1 = 14, NB1 = 1 << D1, WROW = L::WROW, RND = TPAD / NT;  // RND = NE
     uint32_t *H = reinterpret_cast<uint32_t *>(smem + L::off_h);
+    uint16_t *sorted_l = reinterpret_cast<uint16_t *>(smem + L::off_h);  // the final order, staged where the handles were
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem + L::off_hist);
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(smem + L::off_wcnt);
     uint32_t *b31 = reinterpret_cast<uint32_t *>(smem + L::off_b31);
@@ -221,7 +225,7 @@ __device__ __forceinline__ int long_load_sort(const float *__restrict__ x, int T
             if (!last) {
                 H[pos] = (((r >> D1) & 0x1FFFFu) << 15) | (uint32_t)i;
                 if (wide && (r >> 31)) atomicOr(&b31[i >> 5], 1u << (i & 31));
-            } else sorted_g[pos] = (uint16_t)i;  // narrow keys: the order is final (rank[] below: it overlays the histogram)
+            } else sorted_l[pos] = (uint16_t)i;  // narrow keys: the order is final (rank[] below: it overlays the histogram)
         }
     }
     __syncthreads();
@@ -282,18 +286,22 @@ __device__ __forceinline__ int long_load_sort(const float *__restrict__ x, int T
                 for (int j = 0; j < RND; j++) {
                     const int pos = (int)(bs[j] + od[j]);
                     const uint32_t t = hd[j] & 0x7FFFu;
-                    sorted_g[pos] = (uint16_t)t;
-                    rank[t] = (uint16_t)pos;   // (NaN / padding steps: pos >= nvalid, never a member)
+                    sorted_l[pos] = (uint16_t)t;  // (where the handles were: every handle sits in a register)
+                    rank[t] = (uint16_t)pos;      // (NaN / padding steps: pos >= nvalid, never a member)
                 }
             }
         }
         __syncthreads();
     }
     if (npass_rest == 0) {
-        stores_done();
-        __syncthreads();
-        for (int r = tid; r < TPAD; r += NT) rank[load_l2(sorted_g + r)] = (uint16_t)r;
-        __syncthreads();
+        for (int r = tid; r < TPAD; r += NT) rank[sorted_l[r]] = (uint16_t)r;
+    }
+    // the time steps in rank order leave the LDS (the walk's vectors take their place) in 16-byte pieces: scattered straight
+    // to global memory they were 22 stores of 64 two-byte pieces per thread — a third of the sort's time
+    {
+        const uint4 *sl = reinterpret_cast<const uint4 *>(sorted_l);
+        uint4 *sg = reinterpret_cast<uint4 *>(sorted_g);
+        for (int i = tid; i < TPAD / 8; i += NT) sg[i] = sl[i];
     }
     return nvalid;
 }
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(1024) void k_train_long(
             stores_done();
             __syncthreads();  // rank[] and the rank-ordered time steps are complete; the handles are dead: the vectors take their place
             // ---------------- 2. group quantiles ----------------
-            long_phase_c<DQM, TOG64, EPT>(x, sorted_g, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q, kind, mode,
+            long_phase_c<DQM, TOG64, EPT>(x, Ti, sorted_g, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog_ptr, tog_idx, tog64, G, q, Q, kind, mode,
                                      arr, c, af, out_hq, scaling, flag_cell);
             __syncthreads();  // everyone is done with rank[] / the vectors before the next sort reuses the LDS
         }
