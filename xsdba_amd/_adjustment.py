@@ -382,6 +382,12 @@ def qm_adjust(ds, *, group, interp, extrapolation, kind, adapt_freq_thresh=None,
         # cell's table nodes, "cubic" = the Clough-Tocher interpolant on the same triangulation (csrc/lin2d.hpp)
         gcoord, newg = _linear_group_coords(group, sim)
         scen = hip.qm_adjust_linear2d(s2, af, hq, gcoord, newg, extrapolation, kind, cubic=interp == "cubic")
+    elif G > 1 and max_tail_factor is None and getattr(s2, "cell_time_strides", None) is not None:
+        # a (time, cells...) series resident on the device: mapped in place by the lane-per-cell kernel (csrc/adjust_tm.hpp) and
+        # handed back in the same layout — what the reference returns for a (time, lat, lon) sim, without a layout pass
+        scen = hip.qm_adjust(s2, af, hq, gidx, interp, extrapolation, kind, out_time_major=True)  # [time, cell]
+        coords = {k: c for k, c in sim.coords.items() if k in cell_dims or k == group.dim}
+        return DataArray(scen.reshape((scen.shape[0],) + tuple(cell_shape)), (group.dim,) + tuple(cell_dims), coords, {}, "scen").to_dataset()
     else:
         scen = hip.qm_adjust(s2, af, hq, gidx if G > 1 else None, interp, extrapolation, kind)
     scen = _tail_mask(ds, s2, scen, gidx, G, cell_dims, group, dt, max_tail_factor, cell_shape, sim=sim, interp=interp)

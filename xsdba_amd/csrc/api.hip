@@ -23,6 +23,7 @@
 #include "qdm_cell.hpp"
 #include "qdm_lanes.hpp"
 #include "train_long.hpp"
+#include "adjust_tm.hpp"
 #include "train_cell_f64.hpp"
 #include "train_select.hpp"
 #include "preproc.hpp"
@@ -854,9 +855,35 @@ int qm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, in
     int rc;
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, 1, &pl))) return rc;
+    size_t tab = (size_t)C * G * Q * sizeof(R);
+    if constexpr (std::is_same<R, float>::value) {
+        // (time, cell) series in and out, both on the device: mapped in place, a lane per cell (adjust_tm.hpp) — no layout pass
+        const bool tm = C > 1 && st == C && sc == 1 && ost == C && osc == 1 && is_device_ptr(sim) && is_device_ptr(scen) && G > 1 && !node &&
+                        !pl->has_ungrouped && Q <= 64 && xs::tm_lds_bytes(Q) <= (size_t)ctx->lds_limit && !getenv("XSDBA_HIP_NO_TM_ADJUST");
+        if (tm) {
+            const void *daf, *dhq;
+            if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq))) return rc;
+            const int gpw = std::max(1, std::min(8, G / 16));
+            const int n_runs = (G + gpw * xs::TM_WAVES - 1) / (gpw * xs::TM_WAVES);
+            const int64_t ntile = (C + 63) / 64;
+            const size_t lds = xs::tm_lds_bytes(Q);
+            auto launch = [&](auto kernel) -> int {
+                int rc2;
+                if ((rc2 = set_lds(kernel, lds, ctx, "the lanes' table rows"))) return rc2;
+                LaunchScope ls(ctx, "k_qm_adjust_tm");
+                hipLaunchKernelGGL(kernel, dim3((unsigned)(ntile * n_runs)), dim3(xs::TM_WAVES * 64), lds, ctx->stream, (const float *)sim, T, C,
+                                   (const float *)daf, (const float *)dhq, G, Q, pl->d_mem_ptr, pl->d_mem_idx, gpw, n_runs, extrap, (int)kind,
+                                   (float *)scen);
+                return check_launch("k_qm_adjust_tm");
+            };
+            // (load instructions per table and group: ceil(64 / (64 / (Q / 4))), see the kernel)
+            rc = Q <= 20 ? launch(xs::k_qm_adjust_tm<6>) : (Q <= 32 ? launch(xs::k_qm_adjust_tm<8>) : launch(xs::k_qm_adjust_tm<16>));
+            if (rc) return rc;
+            return sync_if(ctx, false);
+        }
+    }
     SeriesIn s;
     if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
-    size_t tab = (size_t)C * G * Q * sizeof(R);
     const void *daf, *dhq;
     if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq))) return rc;
     SeriesOut o;

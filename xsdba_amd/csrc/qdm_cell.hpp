@@ -571,7 +571,9 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                         flag_cell |= a != a;
                         if ((code[u] & 0xC0) && extrap != 0) a = nan_of<R>();
                     }
-                    if (in[u]) scen[(size_t)c * T + (t0 + u * NT)] = apply_corr<R>(vv[u], a, kind);
+                    // (streaming store: the result must not push this CU's series out of the L2 before pass D has read it again —
+                    //  the keys have left the LDS in the two-stream walk)
+                    if (in[u]) __builtin_nontemporal_store(apply_corr<R>(vv[u], a, kind), &scen[(size_t)c * T + (t0 + u * NT)]);
                 }
             }
         } else  // (sim_q wanted, a single group, or no room for the table: element by element)
