@@ -1,7 +1,8 @@
 """k_qm_adjust_tm (time-major sim in, time-major scen out) against k_qm_adjust on the bench's EQM doy/31 tables: per-kernel ms."""
 import sys
 import numpy as np
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from xsdba_amd import hip
 
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 64800

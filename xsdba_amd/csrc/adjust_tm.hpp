@@ -17,7 +17,8 @@
 
 namespace xs {
 
-constexpr int TM_WAVES = 4;     // waves per block
+constexpr int TM_WAVES = 2;     // waves per block: 21.5 KB of strips, seven blocks per CU (measured, ms per 64 800 cells x 10 950 days: four waves
+                                // per block and three waves per SIMD 3.02, eight 4.44 — one block per CU —, two waves and four per SIMD 2.67)
 constexpr int TM_CHUNK = 16;    // member time steps in flight per lane
 
 __host__ __device__ inline int tm_row_stride(int Q) { return Q | 1; }  // odd: the lanes' strips start on different banks
@@ -90,13 +91,17 @@ __device__ __attribute__((noinline)) float interp2d_nearest_global(float x, int 
     return val;
 }
 
-// grid: (tiles of 64 cells) x (runs of `gpw * TM_WAVES` groups); wave w of a block takes the groups [g_first + w gpw, + gpw)
+// grid: (runs of `gpw` groups) x (quadruples of neighbouring 64-cell tiles); wave w of a block takes tile 4 b + w
 // NI: load instructions per table and group.  A lane's row is 4 Q contiguous bytes, the rows of neighbouring lanes 4 G Q bytes
 // apart: fetched by its own lane in 16-byte pieces, every piece is a memory request of its own that uses a quarter of what it
 // brings in (measured: 3.8 ms per 64 800 cells against 2.6 for the cell-major kernel).  Instead consecutive LANES take the
 // consecutive pieces of a row — P = Q / 4 lanes per cell, 64 / P cells per instruction — and drop them into the owner's strip.
+// four waves per SIMD (128 VGPRs: the rows requested ahead take 48 of them; a dozen spill around the out-of-line slow path)
+#ifndef XS_TM_WPE
+#define XS_TM_WPE 4
+#endif
 template <int NI>
-__global__ __launch_bounds__(TM_WAVES * 64) void k_qm_adjust_tm(const float *__restrict__ sim, int64_t T, int64_t C, const float *__restrict__ af,
+__global__ __launch_bounds__(TM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(XS_TM_WPE, XS_TM_WPE))) void k_qm_adjust_tm(const float *__restrict__ sim, int64_t T, int64_t C, const float *__restrict__ af,
                                                                 const float *__restrict__ hist_q, int G, int Q,
                                                                 const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx, int gpw,
                                                                 int n_runs, int extrap, int kind, float *__restrict__ scen)
@@ -107,16 +112,21 @@ __global__ __launch_bounds__(TM_WAVES * 64) void k_qm_adjust_tm(const float *__r
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)wv * tm_wave_floats(Q);  // this wave's strips, then its 64 row flags
     float *xrow = wbase + ((size_t)lane * 2) * RS, *yrow = xrow + RS;                  // this lane's strips
     int *rowflag = reinterpret_cast<int *>(wbase + (size_t)64 * 2 * RS);
-    const int64_t tile = blockIdx.x / n_runs;
-    const int run = (int)(blockIdx.x - tile * n_runs);
-    const int g_lo = (run * TM_WAVES + wv) * gpw, g_hi = min(G, g_lo + gpw);
-    if (g_lo >= g_hi) return;
+    // the waves of a block take NEIGHBOURING tiles and the same run of groups: they walk the same time steps at about the same
+    // time, so the block's loads of a (time, cell) row are TM_WAVES * 256 contiguous bytes, and neighbouring blocks continue the
+    // row (a wave's 30 member rows lie 365 rows apart: locality inside DRAM pages only comes from the neighbours)
+    const int64_t ntile = (C + 63) / 64, nt4 = (ntile + TM_WAVES - 1) / TM_WAVES;
+    const int run = (int)(blockIdx.x / nt4);
+    const int64_t tile = (blockIdx.x - (int64_t)run * nt4) * TM_WAVES + wv;
+    const int g_lo = run * gpw, g_hi = min(G, g_lo + gpw);
+    if (g_lo >= g_hi || tile >= ntile) return;
     const int64_t c = tile * 64 + lane;
     const bool live = c < C;
     const int64_t cc = live ? c : C - 1;  // (lanes past the last cell load the last cell's data and store nothing)
     const float *xq = hist_q + (size_t)cc * G * Q, *yq = af + (size_t)cc * G * Q;
-    const float *xin = sim + cc;
-    float *yout = scen + cc;
+    const int cc32 = (int)(cc - tile * 64);  // the lane's offset in the tile: row addresses are a scalar base + this
+    const float *xin = sim + tile * 64;
+    float *yout = scen + tile * 64;
     int any_valid = -1;
     // 16-byte pieces when the rows are 16-byte aligned (Q a multiple of 4), else every lane copies its own row
     const bool vec = (Q & 3) == 0 && ((reinterpret_cast<uintptr_t>(hist_q) | reinterpret_cast<uintptr_t>(af)) & 15) == 0;
@@ -168,10 +178,14 @@ __global__ __launch_bounds__(TM_WAVES * 64) void k_qm_adjust_tm(const float *__r
         }
         return !has_nan;
     };
-    request(g_lo);
+#ifndef XS_TM_PREFETCH
+#define XS_TM_PREFETCH 1
+#endif
+    if (XS_TM_PREFETCH) request(g_lo);
     for (int g = g_lo; g < g_hi; g++) {
+        if (!XS_TM_PREFETCH) request(g);
         const bool dense = stage(g);
-        if (g + 1 < g_hi) request(g + 1);  // under the mapping of this group
+        if (XS_TM_PREFETCH && g + 1 < g_hi) request(g + 1);  // under the mapping of this group
         const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
         for (int m0 = p0; m0 < p1; m0 += TM_CHUNK) {
             float v[TM_CHUNK];
@@ -179,13 +193,14 @@ __global__ __launch_bounds__(TM_WAVES * 64) void k_qm_adjust_tm(const float *__r
 #pragma unroll
             for (int u = 0; u < TM_CHUNK; u++) {
                 tt[u] = mem_idx[min(m0 + u, p1 - 1)];  // (uniform: scalar loads)
-                v[u] = xin[(int64_t)tt[u] * C];
+                v[u] = (xin + (int64_t)tt[u] * C)[cc32];
             }
+            uint32_t slowmask = 0u;  // elements that need the search beyond the lane's own row: done after the others, out of line
 #pragma unroll
             for (int u = 0; u < TM_CHUNK; u++) {
                 if (m0 + u < p1) {  // (uniform)
                     const float x = v[u];
-                    float a;
+                    float a = nan_of<float>();
                     bool slow = !dense;
                     if (!slow) {
                         // interp2d_nearest_dense on the lane's own row
@@ -211,9 +226,19 @@ __global__ __launch_bounds__(TM_WAVES * 64) void k_qm_adjust_tm(const float *__r
                             slow = d * d > 1.0;  // another row may hold the nearest node
                         }
                     }
-                    if (slow) a = interp2d_nearest_global(x, g, xq, yq, G, Q, extrap, any_valid);
-                    const float y = kind ? apply_corr<float>(x, a, kind) : a;
-                    if (live) yout[(int64_t)tt[u] * C] = y;
+                    if (slow) slowmask |= 1u << u;
+                    else if (live) (yout + (int64_t)tt[u] * C)[cc32] = kind ? apply_corr<float>(x, a, kind) : a;
+                }
+            }
+            if (__any(slowmask != 0u)) {
+                // (rare; the values are read again rather than kept alive across the call)
+                for (int u = 0; u < TM_CHUNK && m0 + u < p1; u++) {
+                    if ((slowmask >> u) & 1u) {
+                        const int64_t t = mem_idx[m0 + u];
+                        const float x = (xin + t * C)[cc32];
+                        const float a = interp2d_nearest_global(x, g, xq, yq, G, Q, extrap, any_valid);
+                        if (live) (yout + t * C)[cc32] = kind ? apply_corr<float>(x, a, kind) : a;
+                    }
                 }
             }
         }

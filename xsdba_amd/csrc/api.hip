@@ -864,8 +864,8 @@ int qm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, in
             const void *daf, *dhq;
             if ((rc = stage_in(ctx, S_TAB0, af, tab, &daf)) || (rc = stage_in(ctx, S_TAB1, hq, tab, &dhq))) return rc;
             const int gpw = std::max(1, std::min(8, G / 16));
-            const int n_runs = (G + gpw * xs::TM_WAVES - 1) / (gpw * xs::TM_WAVES);
-            const int64_t ntile = (C + 63) / 64;
+            const int n_runs = (G + gpw - 1) / gpw;
+            const int64_t ntile = ((C + 63) / 64 + xs::TM_WAVES - 1) / xs::TM_WAVES;  // quadruples of tiles: a block each
             const size_t lds = xs::tm_lds_bytes(Q);
             auto launch = [&](auto kernel) -> int {
                 int rc2;
