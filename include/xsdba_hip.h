@@ -72,8 +72,8 @@ int xsdba_hip_synchronize(xsdba_hip_ctx *ctx);
 /* the hipStream_t every kernel of this context is launched on (for event timing / stream ordering) */
 int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream);
 /* Device buffers owned by the context.  A buffer of >= 1 MiB given back with xsdba_hip_free is parked in a per-context pool
- * (at most XSDBA_HIP_POOL_MB MiB, default 16384; 0 = hipFree at once) and serves the next xsdba_hip_malloc of exactly that
- * size without a hipMalloc / stream synchronisation: a train + adjust loop asks for the same tables and series every pass.
+ * (at most XSDBA_HIP_POOL_MB MiB — default: a quarter of the device's memory, at least 16384 —; 0 = hipFree at once) and serves
+ * the next xsdba_hip_malloc of exactly that size without a hipMalloc / stream synchronisation: a train + adjust loop asks for the same tables and series every pass.
  * Reuse is ordered on the context's stream, like everything else the library does with the buffer; work that OTHER streams
  * queued on it must have been waited for before the free (that was already so when free synchronised this stream only).
  * The pool is emptied when a hipMalloc fails and at xsdba_hip_destroy. */

@@ -1637,14 +1637,27 @@ API int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream)
     return 0;
 }
 
-// Buffers of 1 MB and more that are given back stay in a per-context pool (XSDBA_HIP_POOL_MB, default 16384) and serve the
+// Buffers of 1 MB and more that are given back stay in a per-context pool (XSDBA_HIP_POOL_MB; default: a quarter of the device's
+// memory) and serve the
 // next request of exactly that size: a train / adjust loop allocates the same tables and series every pass, and hipFree costs a
 // stream synchronisation each time.  Everything the library does with a buffer is ordered on the context's stream, so a pooled
 // buffer may be handed out again while earlier kernels that used it are still queued.
 static size_t pool_cap_bytes()
 {
     const char *e = getenv("XSDBA_HIP_POOL_MB");
-    double mb = e ? atof(e) : 16384.0;
+    if (!e) {
+        // default: a quarter of the device's memory, at least 16 GiB — two passes of a 129 600-cell shard keep 26 GB of tables
+        // and series alive at once; with a fixed 16 GiB every pass fell back to hipMalloc / hipFree (the API leg of the bench
+        // at a third of the kernel rate)
+        static size_t dflt = 0;
+        if (!dflt) {
+            size_t fr = 0, tot = 0;
+            dflt = (size_t)16384 << 20;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 4 > dflt) dflt = tot / 4;
+        }
+        return dflt;
+    }
+    double mb = atof(e);
     if (!(mb >= 0.0)) mb = 0.0;            // negative or unparsable: no pool
     if (mb > 1.0e9) mb = 1.0e9;
     return (size_t)mb << 20;
