@@ -281,9 +281,12 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
         if (!(fmax(fabs((double)lo), fabs((double)hi)) <= LIM_ADD * ((double)q3 - (double)q1))) flag_cell = true;
     }
     // ---- the vector of group gb from its row list, copied to B and C
+    bool early = false;
+    int tf[8] = {0, 0, 0, 0, 0, 0, 0, 0}, e0B = 0, e1A = 0, e1B = 0, e1C = 0;
     {
         const int *l = row_sorted + row_ptr[gb];
         const int len = row_ptr[gb + 1] - row_ptr[gb];
+        early = PADT && len <= 1024 && nA <= 8;  // (wave-uniform)
         // 1024 entries per round (all of a day-of-year window's row): their reads are in flight together — one L2 round trip
         // where every wave of the block waits at the same time
         for (int i0 = 0; i0 < len; i0 += 1024) {
@@ -293,6 +296,16 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
                 // out (masked off: as flips of the scratch word they would all hit one address and be serialised)
 #pragma unroll
                 for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; ts[u] = l[min(i, len - 1)]; }
+                if (early) {
+                    // the toggle lists of the fast-forward and of the first two steps are requested behind the row: the three L2
+                    // round trips of the start-up — row, fast-forward lists, first lists — become one (sixteen waves wait here at once)
+#pragma unroll
+                    for (int u = 0; u < 8; u++) tf[u] = tog64[(size_t)(1 + u <= nA ? gb + 1 + u : 0) * 64 + lane];
+                    e0B = tog64[(size_t)(nB > 0 ? gb : 0) * 64 + lane];
+                    e1A = tog64[(size_t)(1 < nA ? gb + 1 : 0) * 64 + lane];
+                    e1B = tog64[(size_t)(1 < nB ? gb - 1 : 0) * 64 + lane];
+                    e1C = tog64[(size_t)(1 < nC ? gc3 + 1 : 0) * 64 + lane];
+                }
                 int rs[16];
 #pragma unroll
                 for (int u = 0; u < 16; u++) rs[u] = (int)rank[ts[u]];
@@ -317,8 +330,13 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
             // eight lists in flight (XOR commutes); rows past the last list read row 0, the table's all-padding row
             for (int s0 = 1; s0 <= nA; s0 += 8) {
                 int ts[8], rs[8];
+                if (early) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) ts[u] = tog64[(size_t)(s0 + u <= nA ? gb + s0 + u : 0) * 64 + lane];
+                    for (int u = 0; u < 8; u++) ts[u] = tf[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) ts[u] = tog64[(size_t)(s0 + u <= nA ? gb + s0 + u : 0) * 64 + lane];
+                }
 #pragma unroll
                 for (int u = 0; u < 8; u++) rs[u] = (int)rank[ts[u]];
 #pragma unroll
@@ -341,13 +359,16 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     // there is no list 0): a stream with nothing to toggle reads that row, so that the loads need no branches
     const int nolist = PADT ? n_time : -1;  // an entry that is no toggle
     int preA = nolist, preB = nolist, preC = nolist;  // A and C stand on their first group: only B starts with a step (gb -> gb - 1)
-    if (nB > 0) preB = tog64[(size_t)gb * 64 + lane];
+    if (nB > 0) preB = early ? e0B : tog64[(size_t)gb * 64 + lane];
     if constexpr (PADT) {
         // step 0's flips (B only) now, then the lists of step 1
         if (nB > 0) { const int r = (int)rank[preB]; (void)__hip_atomic_fetch_xor(&bB[r >> 5], 1u << (r & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-        preA = tog64[(size_t)(1 < nA ? gb + 1 : 0) * 64 + lane];
-        preB = tog64[(size_t)(1 < nB ? gb - 1 : 0) * 64 + lane];
-        preC = tog64[(size_t)(1 < nC ? gc3 + 1 : 0) * 64 + lane];
+        if (early) { preA = e1A; preB = e1B; preC = e1C; }
+        else {
+            preA = tog64[(size_t)(1 < nA ? gb + 1 : 0) * 64 + lane];
+            preB = tog64[(size_t)(1 < nB ? gb - 1 : 0) * 64 + lane];
+            preC = tog64[(size_t)(1 < nC ? gc3 + 1 : 0) * 64 + lane];
+        }
     }
     int nA_prev = -1, nB_prev = -1, nC_prev = -1, c_case[NR], c_lo[NR];
     R c_gamma[NR];
