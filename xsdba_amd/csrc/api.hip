@@ -72,6 +72,7 @@ struct Plan {
     int *d_tog64p = nullptr;  // the same table for k_train_cell3: no -1 entries (see get_plan)
     int *d_tog128 = nullptr;  // [G][128] padded toggle table of the long series (k_train_long) when every list has <= 128 entries
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
+    int *d_mem_t64 = nullptr;  // [32][G] the same for groups of 33 .. 64 members (the regression of k_group_trend on 60-year series)
     bool has_ungrouped = false;  // some time step belongs to no group
 };
 
@@ -242,6 +243,7 @@ void free_plan(Plan *p)
     if (p->d_tog64p) (void)hipFree(p->d_tog64p);
     if (p->d_tog128) (void)hipFree(p->d_tog128);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
+    if (p->d_mem_t64) (void)hipFree(p->d_mem_t64);
 }
 
 // base.py:232-272 — rolling(center=True, window).construct puts x[t' + j - window/2] in slot j of centre t';
@@ -359,6 +361,17 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
                 std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t128.begin() + (size_t)(i + 1) * 128);
             if ((rc = upload_ints(ctx, t128, &pl->d_tog128))) return rc;
         }
+    }
+    if (G > 1 && pl->max_mem > 32 && pl->max_mem <= 64 && T < 65535) {
+        std::vector<int> mt((size_t)32 * G, -1);
+        for (int i = 0; i < G; i++)
+            for (int y = 0; y < pl->mem_ptr[i + 1] - pl->mem_ptr[i]; y++) {
+                const uint32_t t = (uint32_t)pl->mem_idx[(size_t)pl->mem_ptr[i] + y];
+                uint32_t w = (uint32_t)mt[(size_t)(y / 2) * G + i];
+                w = (y & 1) ? ((w & 0x0000FFFFu) | (t << 16)) : ((w & 0xFFFF0000u) | t);
+                mt[(size_t)(y / 2) * G + i] = (int)w;
+            }
+        if ((rc = upload_ints(ctx, mt, &pl->d_mem_t64))) return rc;
     }
     if (G > 1 && pl->max_mem <= 32 && T < 65535) {
         // member slots of the short exact groups for k_qdm_lanes, slot-pair-major: word [y / 2][g] holds the time indexes of
@@ -989,13 +1002,15 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32, coef_out);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32 ? pl->d_mem_t32 : pl->d_mem_t64, coef_out,
+                           pl->d_mem_t32 ? 16 : 32);
     } else {
         if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32, coef_out);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32 ? pl->d_mem_t32 : pl->d_mem_t64, coef_out,
+                           pl->d_mem_t32 ? 16 : 32);
     }
     return check_launch("k_group_trend");
 }

@@ -515,11 +515,12 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
                               int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd,
-                              const int *__restrict__ mem_t16, double *__restrict__ coef_out)
+                              const int *__restrict__ mem_t16, double *__restrict__ coef_out, int mem_tw = 16)
 {
     // coef_out ([cell][G][3], degree <= 1 without preserve_mean): leave the regression coefficients instead of the trend —
     // the DQM adjust kernel evaluates it per element (no [cell][time] array written and read back)
-    // mem_t16: the plan's packed member table ([16][G] words of two 16-bit time indexes; groups of <= 32 members) or null
+    // mem_t16: the plan's packed member table ([mem_tw][G] words of two 16-bit time indexes; mem_tw = 16: groups of <= 32 members,
+    // 32: <= 64 members) or null
     // tn_affine: the time axis is tnum[t] == tn0 + tnd * t exactly for every t (host-checked: daily steps in ns since an
     // epoch are): the coordinate is computed instead of gathered from L2 in the regression and in the trend evaluation
     auto TN = [&](int64_t t) { return tn_affine ? tn0 + tnd * (double)t : tnum[t]; };
@@ -689,34 +690,40 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     // per-group least squares.  Many short groups (day-of-year: 365 groups of ~30 members): one LANE per group, a
     // serial loop over its members and no cross-lane reduction at all.
     if (lane_per_group && mem_t16 && tn_affine) {
-        // groups of <= 32 members on an affine time axis: the member indexes arrive as 16 coalesced words and nothing else is
-        // gathered from global memory — both passes of the regression read the window means from LDS, in member order
-        for (int g = threadIdx.x; g < G; g += blockDim.x) {
-            uint32_t w[16];
+        // groups of <= 32 (mem_tw = 16 words per group) or <= 64 members (32 words: 60 years of a day of the year) on an affine
+        // time axis: the member indexes arrive as coalesced words and nothing else is gathered from global memory — both passes
+        // of the regression read the window means from LDS, in member order
+        auto regress = [&](auto nwc) {
+            constexpr int NW = decltype(nwc)::value;
+            for (int g = threadIdx.x; g < G; g += blockDim.x) {
+                uint32_t w[NW];
 #pragma unroll
-            for (int u = 0; u < 16; u++) w[u] = (uint32_t)mem_t16[(size_t)u * G + g];
-            double sx = 0, sy = 0;
-            int n = 0;
+                for (int u = 0; u < NW; u++) w[u] = (uint32_t)mem_t16[(size_t)u * G + g];
+                double sx = 0, sy = 0;
+                int n = 0;
 #pragma unroll
-            for (int y = 0; y < 32; y++) {
-                const uint32_t t = (w[y / 2] >> (16 * (y & 1))) & 0xFFFFu;
-                const R v = t != 0xFFFFu ? m[t] : nan_of<R>();
-                if (v == v) { sx += TN(t); sy += (double)v; n++; }
-            }
-            const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
-            double slope = 0.0;
-            if (degree >= 1 && n >= 2) {
-                double sxx = 0, sxy = 0;
-#pragma unroll
-                for (int y = 0; y < 32; y++) {
+                for (int y = 0; y < 2 * NW; y++) {
                     const uint32_t t = (w[y / 2] >> (16 * (y & 1))) & 0xFFFFu;
                     const R v = t != 0xFFFFu ? m[t] : nan_of<R>();
-                    if (v == v) { const double dx = TN(t) - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                    if (v == v) { sx += TN(t); sy += (double)v; n++; }
                 }
-                slope = sxx > 0 ? sxy / sxx : 0.0;
+                const double xb = n ? sx / n : 0.0, yb = n ? sy / n : __builtin_nan("");
+                double slope = 0.0;
+                if (degree >= 1 && n >= 2) {
+                    double sxx = 0, sxy = 0;
+#pragma unroll
+                    for (int y = 0; y < 2 * NW; y++) {
+                        const uint32_t t = (w[y / 2] >> (16 * (y & 1))) & 0xFFFFu;
+                        const R v = t != 0xFFFFu ? m[t] : nan_of<R>();
+                        if (v == v) { const double dx = TN(t) - xb; sxx += dx * dx; sxy += dx * ((double)v - yb); }
+                    }
+                    slope = sxx > 0 ? sxy / sxx : 0.0;
+                }
+                coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
             }
-            coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
-        }
+        };
+        if (mem_tw > 16) regress(std::integral_constant<int, 32>{});
+        else regress(std::integral_constant<int, 16>{});
     } else if (lane_per_group) {
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
             const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
