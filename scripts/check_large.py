@@ -36,4 +36,16 @@ for name, got, exp, tol in (("dqm af", rows(af, 0), eaf, 1e-5), ("dqm scen", row
     err = np.nanmax(np.abs(got.astype(np.float64) - exp) / np.maximum(1e-30, np.abs(exp)))
     print(name, "max rel err", err)
     ok &= bool(err <= tol) and np.array_equal(np.isnan(got), np.isnan(exp))
+# round 4: the (time, cell) adjustment in place (k_qm_adjust_tm) on a cube of > 2^31 elements: selected cells against the oracle
+for d in (scen, trend, scen2, simq, scen3, scen4, af, hq, sc):
+    if hasattr(d, "free"):
+        d.free()
+sim_tm = ctx.synth((C, T), np.float32, 0, 2, 1, 0, time_major=True)
+scen_tm = hip.qm_adjust(sim_tm, af2, hq2, doy, "nearest", "constant", "+", ctx=ctx, out_time_major=True)
+ctx.synchronize()
+from xsdba_amd._lib import DeviceArray
+cols = np.stack([np.concatenate([DeviceArray.from_ptr(ctx, scen_tm.ptr + (t * C + c) * 4, (1,), np.float32).download() for t in range(0, T, 97)]) for c in pick])
+escen_tm = oracle.qm_adjust(S, eaf2, ehq2, doy, "nearest", "constant", "+")[:, ::97]
+print("eqm scen (time-major, every 97th step)", "equal" if np.array_equal(cols, escen_tm, equal_nan=True) else "MISMATCH")
+ok &= np.array_equal(cols, escen_tm, equal_nan=True)
 print("OK" if ok else "MISMATCH")
