@@ -171,7 +171,11 @@ int xsdba_hip_dqm_train(xsdba_hip_ctx *ctx, const void *ref, const void *hist, i
  * true 2-D nearest neighbour and nbutils._extrapolate_on_quantiles (nbutils.py:397-416); interp must be
  * NEAREST there.  kind == 0 returns the interpolated factor itself.  node_index (nullable, int32
  * [cell][time]): flat index r*nq+k of the chosen node on the (n_groups+2)-row extended table, -1 when
- * the value came from extrapolation / NaN (parity instrumentation). */
+ * the value came from extrapolation / NaN (parity instrumentation).
+ * Layouts: float32 (time, cell) series on the device for BOTH sim and scen (stride_t = out_stride_t = n_cell, stride_c =
+ * out_stride_c = 1: a (time, lat, lon) array as xarray holds it, base.py:653-656) are mapped in place, without a layout pass
+ * (k_qm_adjust_tm, csrc/adjust_tm.hpp; grouped tables, every time step in a group, no node_index); other combinations of
+ * strides go through the tiled layout kernel. */
 int xsdba_hip_qm_adjust(xsdba_hip_ctx *ctx, const void *sim, int dtype, int64_t n_time, int64_t n_cell,
                         int64_t stride_t, int64_t stride_c, const void *af, const void *hist_q, int32_t n_groups,
                         int32_t nq, const int32_t *group_of_time, int interp, int extrap, char kind, void *scen,
