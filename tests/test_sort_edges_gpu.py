@@ -1,8 +1,10 @@
-"""The per-cell sort behind the windowed training kernels (train_cell.hpp: one 14-bit counting pass + as many stable nibble
-passes as the occupied key range needs; the last stable pass also leaves rank[]): series whose keys span fewer than 14 bits (no
-stable pass at all: rank[] comes from the fallback loop), exactly 14 + 4k bits, every bit of a float32, one value only, one
-valid value only — EQM / DQM tables and QDM ranks bit for bit against the oracle, float32 and the sizes of all three EPT
-instantiations."""
+"""The per-cell sort behind the windowed training kernels (train_cell.hpp: one 14-bit counting pass on packed LDS bins, then
+ceil(R / 8) stable counting passes on wave-private counter rows for the R key bits left — round 4; the last stable pass also
+leaves rank[]): series whose keys span fewer than 14 bits (no stable pass at all: rank[] comes from the fallback loop), EVERY
+width from 13 to 32 bits (one, two and three stable passes of every digit width, the 32-bit case of a series that spans zero),
+one value only, one valid value only — EQM / DQM tables and QDM ranks bit for bit against the oracle, float32, the sizes of all
+three EPT instantiations of the short kernel and the long-series kernel (keys in registers, 15-bit time steps, bit 31 beside
+the handles)."""
 from __future__ import annotations
 
 import numpy as np
@@ -95,3 +97,41 @@ def test_dqm_tables_on_edge_key_ranges(hip, kind):
     assert_close(sc, esc, rtol=2.4e-7, atol=atol, what="scaling")
     assert_close(hq, ehq, rtol=2.4e-7, atol=atol, what="hist_q")
     assert_close(af, eaf, rtol=5e-7, atol=2 * atol, what="af")
+
+
+def _width_series(rng, bits, C, T):
+    """float32 values whose order-preserving keys span exactly `bits` bits: integers scaled by a power of two at a base whose ulp
+    is known (<= 23 bits), else several binades (24 .. 31) and both signs (32)"""
+    if bits <= 23:
+        base = np.float32(512.0)  # ulp 2^-14 up to 1024: 2^23 steps stay inside the binade
+        k = rng.integers(0, 1 << bits, (C, T))
+        k[:, 0], k[:, 1] = 0, (1 << bits) - 1  # the full width is present in every series
+        return (base + np.spacing(base) * k.astype(np.float64)).astype(np.float32)
+    if bits <= 31:
+        # positive floats over 2^(bits - 23) binades: keys of positive floats are their bit patterns | 0x80000000
+        lo = np.float32(1.0).view(np.uint32).astype(np.int64)
+        k = lo + rng.integers(0, (1 << bits) - 1, (C, T))
+        k[:, 0], k[:, 1] = lo, lo + (1 << bits) - 2
+        return k.astype(np.uint32).view(np.float32)
+    x = (rng.standard_normal((C, T)) * np.exp2(rng.integers(-20, 20, (C, T)))).astype(np.float32)
+    x[:, 0], x[:, 1] = -1e30, 1e30
+    return x
+
+
+@pytest.mark.parametrize("bits", list(range(13, 33)))
+def test_every_key_width_short_and_long(hip, bits):
+    """one 14-bit pass + 0 .. 3 stable passes of 1 .. 8 bits (short kernel, T = 4 000: EPT 4) and the long-series kernel
+    (T = 12 000: 12 keys per thread in registers); ties across passes (5 % of the values repeated), NaNs"""
+    rng = np.random.default_rng(bits)
+    q = ((np.arange(20) + 0.5) / 20).astype(np.float32)
+    for T in (4000, 12000):
+        C = 2
+        ref, hist = _width_series(rng, bits, C, T), _width_series(rng, bits, C, T)
+        rep = rng.random(T) < 0.05
+        hist[:, rep] = hist[:, 2:3]
+        ref[1, rng.random(T) < 0.03] = np.nan
+        gidx = _doy(T)
+        af, hq = hip.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+        assert_close(hq, ehq, rtol=0.0, what=f"hist_q bits={bits} T={T}")
+        assert_close(af, eaf, rtol=0.0, what=f"af bits={bits} T={T}")
