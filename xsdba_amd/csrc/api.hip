@@ -1002,15 +1002,20 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
                            (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32 ? pl->d_mem_t32 : pl->d_mem_t64, coef_out,
-                           pl->d_mem_t32 ? 16 : 32);
+                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32, coef_out);
     } else {
-        if ((rc = set_lds(xs::k_group_trend<R, false>, lds1, ctx, "the detrending series"))) return rc;
-        LaunchScope ls(ctx, "k_group_trend");
-        hipLaunchKernelGGL((xs::k_group_trend<R, false>), dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
-                           (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
-                           pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd, pl->d_mem_t32 ? pl->d_mem_t32 : pl->d_mem_t64, coef_out,
-                           pl->d_mem_t32 ? 16 : 32);
+        const bool mt64 = !pl->d_mem_t32 && pl->d_mem_t64;
+        auto launch = [&](auto kernel) -> int {
+            int rc2;
+            if ((rc2 = set_lds(kernel, lds1, ctx, "the detrending series"))) return rc2;
+            LaunchScope ls(ctx, "k_group_trend");
+            hipLaunchKernelGGL(kernel, dim3((unsigned)C), dim3(nthr), lds1, ctx->stream,
+                               (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
+                               pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd,
+                               mt64 ? pl->d_mem_t64 : pl->d_mem_t32, coef_out);
+            return 0;
+        };
+        if ((rc = mt64 ? launch(xs::k_group_trend<R, false, true>) : launch(xs::k_group_trend<R, false, false>))) return rc;
     }
     return check_launch("k_group_trend");
 }

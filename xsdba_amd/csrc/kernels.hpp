@@ -509,18 +509,20 @@ __device__ __forceinline__ void poly_solve(const double *S, const double *B, int
 
 // M_LDS: the window means live in a second LDS array (T * sizeof(R) more) instead of the trend buffer — the
 // normal case for float32; float64 series that do not fit keep them in global memory.
-template <typename R, bool M_LDS>
+// MT64: the packed member table has 32 words per group (groups of 33 .. 64 members: 60 years of a day of the year) instead of 16 —
+// an instantiation of its own, so that its 32 more registers do not cost the usual one (<= 32 members) its third block per CU
+template <typename R, bool M_LDS, bool MT64 = false>
 __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
                               const double *__restrict__ tnum, int degree, R *__restrict__ trend_cm, int lane_per_group,
                               int preserve_mean, int min_periods, int tn_affine, double tn0, double tnd,
-                              const int *__restrict__ mem_t16, double *__restrict__ coef_out, int mem_tw = 16)
+                              const int *__restrict__ mem_t16, double *__restrict__ coef_out)
 {
     // coef_out ([cell][G][3], degree <= 1 without preserve_mean): leave the regression coefficients instead of the trend —
     // the DQM adjust kernel evaluates it per element (no [cell][time] array written and read back)
-    // mem_t16: the plan's packed member table ([mem_tw][G] words of two 16-bit time indexes; mem_tw = 16: groups of <= 32 members,
-    // 32: <= 64 members) or null
+    // mem_t16: the plan's packed member table ([16][G] words of two 16-bit time indexes: groups of <= 32 members; MT64: [32][G],
+    // <= 64 members) or null
     // tn_affine: the time axis is tnum[t] == tn0 + tnd * t exactly for every t (host-checked: daily steps in ns since an
     // epoch are): the coordinate is computed instead of gathered from L2 in the regression and in the trend evaluation
     auto TN = [&](int64_t t) { return tn_affine ? tn0 + tnd * (double)t : tnum[t]; };
@@ -722,8 +724,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                 coef[3 * g] = xb; coef[3 * g + 1] = yb; coef[3 * g + 2] = slope;
             }
         };
-        if (mem_tw > 16) regress(std::integral_constant<int, 32>{});
-        else regress(std::integral_constant<int, 16>{});
+        regress(std::integral_constant<int, MT64 ? 32 : 16>{});
     } else if (lane_per_group) {
         for (int g = threadIdx.x; g < G; g += blockDim.x) {
             const int p0 = mem_ptr[g], p1 = mem_ptr[g + 1];
