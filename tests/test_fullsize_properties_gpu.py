@@ -1,5 +1,5 @@
-"""The bench workload at its FULL size (64 800 cells x 10 950 days, EQM doy/31; BASELINE configs[1]'s grid with the metric's
-grouping) checked through size-independent properties — the oracle would take minutes there:
+"""The bench workload at its FULL size (129 600 cells x 10 950 days, EQM doy/31: the per-GPU shard of north_star's 1440 x 720 cube,
+what `bench.py` runs by default) checked through size-independent properties — the oracle would take minutes there:
   * position independence (a checksum of checksums in its strongest form): any block of cells regenerated on its own
     (counter-based generator, `cell_offset`) and run alone gives bit for bit the rows of the big run, at the start, in the
     middle and at the very end of the cube (32-bit index overflow would show there), and those rows equal the oracle's;
@@ -27,7 +27,7 @@ def ctx():
 
 
 def test_eqm_doy31_full_bench_size(ctx):
-    C, B = 360 * 180, 32
+    C, B = 1440 * 720 // 8, 32
     ref, hist, sim = (ctx.synth((C, T), np.float32, 0, i, 1) for i in range(3))
     af, hq = hip.eqm_train(ref, hist, DOY, G, W, NODES, "+", ctx=ctx)
     scen = hip.qm_adjust(sim, af, hq, DOY, "nearest", "constant", "+", ctx=ctx)
@@ -50,6 +50,17 @@ def test_eqm_doy31_full_bench_size(ctx):
         np.testing.assert_array_equal(AF[c0:c0 + 4], eaf)
         np.testing.assert_array_equal(HQ[c0:c0 + 4], ehq)
         np.testing.assert_array_equal(SCEN[c0:c0 + 4], oracle.qm_adjust(s[:4], eaf, ehq, DOY, "nearest", "constant", "+"))
+    # the (time, cell) adjustment in place (k_qm_adjust_tm) on the same cube: the same values, transposed — at both ends and in the middle
+    from xsdba_amd._lib import DeviceArray
+
+    sim_tm = ctx.synth((C, T), np.float32, 0, 2, 1, time_major=True)
+    scen_tm = hip.qm_adjust(sim_tm, af, hq, DOY, "nearest", "constant", "+", ctx=ctx, out_time_major=True)
+    ctx.synchronize()
+    for c0 in (0, C // 2, C - B):
+        for t in (0, 1, T // 2, T - 1):
+            row = DeviceArray.from_ptr(ctx, scen_tm.ptr + (t * C + c0) * 4, (B,), np.float32).download()
+            np.testing.assert_array_equal(row, SCEN[c0:c0 + B, t])
+    sim_tm.free(); scen_tm.free()
     # quantiles lie inside the range of the series they come from
     H = hist.download()
     assert (HQ.min(axis=(1, 2)) >= H.min(axis=1)).all() and (HQ.max(axis=(1, 2)) <= H.max(axis=1)).all()
