@@ -23,6 +23,7 @@
 #include "qdm_cell.hpp"
 #include "qdm_lanes.hpp"
 #include "train_long.hpp"
+#include "train_xlong.hpp"
 #include "adjust_tm.hpp"
 #include "train_cell_f64.hpp"
 #include "train_select.hpp"
@@ -71,6 +72,7 @@ struct Plan {
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
     int *d_tog64p = nullptr;  // the same table for k_train_cell3: no -1 entries (see get_plan)
     int *d_tog128 = nullptr;  // [G][128] padded toggle table of the long series (k_train_long) when every list has <= 128 entries
+    int *d_tog256 = nullptr;  // [G][256]: the same for k_train_xlong (series beyond 22 528 steps)
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     int *d_mem_t64 = nullptr;  // [32][G] the same for groups of 33 .. 64 members (the regression of k_group_trend on 60-year series)
     bool has_ungrouped = false;  // some time step belongs to no group
@@ -241,6 +243,7 @@ void free_plan(Plan *p)
     (void)hipFree(p->d_row_sorted); (void)hipFree(p->d_tog_ptr); (void)hipFree(p->d_tog_idx);
     if (p->d_tog64) (void)hipFree(p->d_tog64);
     if (p->d_tog64p) (void)hipFree(p->d_tog64p);
+    if (p->d_tog256) (void)hipFree(p->d_tog256);
     if (p->d_tog128) (void)hipFree(p->d_tog128);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
     if (p->d_mem_t64) (void)hipFree(p->d_mem_t64);
@@ -360,6 +363,12 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
             for (int i = 0; i + 1 < G; i++)
                 std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t128.begin() + (size_t)(i + 1) * 128);
             if ((rc = upload_ints(ctx, t128, &pl->d_tog128))) return rc;
+        }
+        if (maxlen <= 256 && T > xs::LongCfg<11>::TPAD && T <= 65535) {
+            std::vector<int> t256((size_t)G * 256, -1);
+            for (int i = 0; i + 1 < G; i++)
+                std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t256.begin() + (size_t)(i + 1) * 256);
+            if ((rc = upload_ints(ctx, t256, &pl->d_tog256))) return rc;
         }
     }
     if (G > 1 && pl->max_mem > 32 && pl->max_mem <= 64 && T < 65535) {
@@ -729,6 +738,46 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
             fast = true;
         }
+        // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
+        const bool fast_xlong = !fast && mode != 3 && pl->simple && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
+                                !(force && !strcmp(force, "rows"));
+        if (fast_xlong) {
+            void *flags, *scratch;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, ctx->n_cu);  // one block per CU (155 KB of LDS), cells walked grid-stride
+            auto go = [&](auto dqm, auto togp, auto wpl) -> int {
+                constexpr bool DQM = decltype(dqm)::value, TOGP = decltype(togp)::value;
+                constexpr int WPL = decltype(wpl)::value;
+                using X = xs::XLongGeo<WPL>;
+                int rc2;
+                if ((rc2 = ensure(ctx, S_SCR, X::scratch_bytes * nblk, &scratch))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
+                LaunchScope ls(ctx, "k_train_xlong");
+                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
+                                   (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
+                                   flag_count, flag_list, C, pl->d_tog256, (unsigned char *)scratch,
+#ifdef XSDBA_DIAG
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
+#else
+                                   0);
+#endif
+                return check_launch("k_train_xlong");
+            };
+            using std::false_type;
+            using std::true_type;
+            using std::integral_constant;
+            auto pick_w = [&](auto dqm, auto togp) -> int {
+                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}) : go(dqm, togp, integral_constant<int, 32>{});
+            };
+            rc = mode == 2 ? (pl->d_tog256 ? pick_w(true_type{}, true_type{}) : pick_w(true_type{}, false_type{}))
+                           : (pl->d_tog256 ? pick_w(false_type{}, true_type{}) : pick_w(false_type{}, false_type{}));
+            if (rc) return rc;
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
+            fast = true;
+        }
     }
     if constexpr (std::is_same<R, double>::value) {
         // float64 series: 31-bit range keys + tie repair, train_cell_f64.hpp
@@ -782,6 +831,46 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             else
             rc = ept == 4 ? pick_dqm(integral_constant<int, 4>{}) : ept == 8 ? pick_dqm(integral_constant<int, 8>{})
                                                                               : pick_dqm(integral_constant<int, 11>{});
+            if (rc) return rc;
+            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
+            fast = true;
+        }
+        // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
+        const bool fast_xlong = !fast && mode != 3 && pl->simple && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
+                                !(force && !strcmp(force, "rows"));
+        if (fast_xlong) {
+            void *flags, *scratch;
+            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
+            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
+            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
+            const unsigned nblk = (unsigned)std::min<int64_t>(C, ctx->n_cu);  // one block per CU (155 KB of LDS), cells walked grid-stride
+            auto go = [&](auto dqm, auto togp, auto wpl) -> int {
+                constexpr bool DQM = decltype(dqm)::value, TOGP = decltype(togp)::value;
+                constexpr int WPL = decltype(wpl)::value;
+                using X = xs::XLongGeo<WPL>;
+                int rc2;
+                if ((rc2 = ensure(ctx, S_SCR, X::scratch_bytes * nblk, &scratch))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
+                LaunchScope ls(ctx, "k_train_xlong");
+                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
+                                   (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
+                                   flag_count, flag_list, C, pl->d_tog256, (unsigned char *)scratch,
+#ifdef XSDBA_DIAG
+                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
+#else
+                                   0);
+#endif
+                return check_launch("k_train_xlong");
+            };
+            using std::false_type;
+            using std::true_type;
+            using std::integral_constant;
+            auto pick_w = [&](auto dqm, auto togp) -> int {
+                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}) : go(dqm, togp, integral_constant<int, 32>{});
+            };
+            rc = mode == 2 ? (pl->d_tog256 ? pick_w(true_type{}, true_type{}) : pick_w(true_type{}, false_type{}))
+                           : (pl->d_tog256 ? pick_w(false_type{}, true_type{}) : pick_w(false_type{}, false_type{}));
             if (rc) return rc;
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
             fast = true;

@@ -490,9 +490,10 @@ struct LdsVals {
 template <typename Geo, typename = void> struct togn_of { static constexpr int value = 1; };
 template <typename Geo> struct togn_of<Geo, std::void_t<decltype(Geo::TOGN)>> { static constexpr int value = Geo::TOGN; };
 
-template <typename Geo, bool DIAG, bool DQM, bool TOG64, typename Vals, typename Stamp>
+// (RankT: `const uint16_t *` into the LDS, or train_xlong.hpp's view of a rank table in global memory)
+template <typename Geo, bool DIAG, bool DQM, bool TOG64, typename Vals, typename Stamp, typename RankT>
 __device__ __forceinline__ void cell_group_quantiles(
-    const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid, int lane, int wid,
+    const Vals &vals, const RankT rank, uint32_t *bits_all, int nvalid, int lane, int wid,
     const int *__restrict__ row_ptr, const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr,
     const int *__restrict__ tog_idx, const int *__restrict__ tog64, int G, const typename Vals::value_type *__restrict__ q, int Q, int kind,
     int mode, int arr, int64_t c, typename Vals::value_type *__restrict__ af, typename Vals::value_type *out_hq,

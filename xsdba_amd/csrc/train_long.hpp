@@ -85,7 +85,8 @@ __device__ __attribute__((noinline)) void long_phase_c(const float *x, int n_tim
 // The sort of one series of up to TPAD steps: keys in registers, handles in LDS (see the header).  Returns the number of valid
 // values (0: nothing was sorted); leaves rank[t] in LDS and the time steps in rank order in `sorted_g`.  All 1024 threads; the
 // caller must drain the stores and meet at a barrier before anyone reads either.
-template <int EPT>
+// (COPY_OUT = false: the order stays in LDS only — train_xlong.hpp reads it there)
+template <int EPT, bool COPY_OUT = true>
 __device__ __forceinline__ int long_load_sort(const float *__restrict__ x, int Ti, unsigned char *smem, uint32_t *red, uint16_t *rank,
                                               uint16_t *sorted_g)
 {
@@ -298,7 +299,7 @@ __device__ __forceinline__ int long_load_sort(const float *__restrict__ x, int T
     }
     // the time steps in rank order leave the LDS (the walk's vectors take their place) in 16-byte pieces: scattered straight
     // to global memory they were 22 stores of 64 two-byte pieces per thread — a third of the sort's time
-    {
+    if constexpr (COPY_OUT) {
         const uint4 *sl = reinterpret_cast<const uint4 *>(sorted_l);
         uint4 *sg = reinterpret_cast<uint4 *>(sorted_g);
         for (int i = tid; i < TPAD / 8; i += NT) sg[i] = sl[i];
