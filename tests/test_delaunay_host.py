@@ -68,6 +68,56 @@ def test_triangles_match_qhull(lib, rows, Q, spread, row_order):
                         assert {tv[3 * t + (k + 1) % 3], tv[3 * t + (k + 2) % 3]} <= set(tv[3 * u:3 * u + 3])
 
 
+def table_rows(rng, rows, Q, spread=1.0, drop=()):
+    """table_nodes + the first node of every row (rows in `drop` are left empty)"""
+    xs_, ys_, rowb = [], [], [0]
+    for r in range(rows):
+        x = np.sort((280 + 10 * np.cos(r / rows * 6.28) + spread * 8 * rng.standard_normal(Q)).astype(np.float32)).astype(np.float64)
+        x = np.unique(x) if r not in drop else x[:0]
+        xs_.append(x)
+        ys_.append(np.full(len(x), float(r)))
+        rowb.append(rowb[-1] + len(x))
+    return np.concatenate(xs_), np.concatenate(ys_), np.array(rowb, np.int32)
+
+
+@pytest.mark.parametrize("rows,Q,spread,drop", [(14, 20, 1.0, ()), (14, 50, 0.2, ()), (6, 15, 3.0, ()), (3, 4, 1.0, ()), (40, 20, 1.0, ()),
+                                                 (2, 5, 1.0, ()), (14, 20, 0.02, ()), (14, 20, 30.0, ()), (14, 20, 1.0, (0, 5, 6, 13)),
+                                                 (367, 20, 1.0, ()), (14, 2, 1.0, ())])
+def test_row_construction_matches_qhull(lib, rows, Q, spread, drop):
+    """the row-parallel construction (dtp_*: strips, pockets, rounds of arbitrated Lawson flips; its lanes emulated one after the
+    other): Qhull's triangles, counter-clockwise, consistent neighbours; narrow and wide spreads (many / few flips), empty rows,
+    day-of-year height, two nodes per row"""
+    rng = np.random.default_rng(rows * 100 + Q)
+    for rep in range(3):
+        px, py, rowb = table_rows(rng, rows, Q, spread, drop)
+        n = len(px)
+        tv, tn, rounds = np.zeros(6 * n, np.uint16), np.zeros(6 * n, np.uint16), C.c_int(0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        nt = lib.dt_host_build_rows(C.c_int(n), p(px), p(py), p(tv), p(tn), C.c_int(rows), p(rowb), C.byref(rounds))
+        assert nt > 0 and rounds.value < 8 * n
+        ref = Delaunay(np.c_[px, py])
+        mine = {tuple(sorted(tv[3 * t:3 * t + 3])) for t in range(nt)}
+        theirs = {tuple(sorted(s)) for s in ref.simplices}
+        assert len(mine) == len(theirs) == nt
+        assert len(mine ^ theirs) <= 0.02 * len(mine) + 2  # (cocircular ties)
+        for t in range(nt):
+            a, b, c = tv[3 * t:3 * t + 3]
+            assert (px[b] - px[a]) * (py[c] - py[a]) - (py[b] - py[a]) * (px[c] - px[a]) > 0
+            for k in range(3):
+                u = tn[3 * t + k]
+                if u != 0xFFFF:
+                    assert t in tn[3 * u:3 * u + 3]
+                    assert {tv[3 * t + (k + 1) % 3], tv[3 * t + (k + 2) % 3]} <= set(tv[3 * u:3 * u + 3])
+
+
+def test_row_construction_declines_single_node_rows(lib):
+    px = np.array([1.0, 2.0, 3.0, 1.5, 0.5, 2.5]); py = np.array([0.0, 0.0, 0.0, 1.0, 2.0, 2.0])
+    rowb = np.array([0, 3, 4, 6], np.int32)
+    tv, tn = np.zeros(36, np.uint16), np.zeros(36, np.uint16)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert lib.dt_host_build_rows(C.c_int(6), p(px), p(py), p(tv), p(tn), C.c_int(3), p(rowb), None) == -1
+
+
 @pytest.mark.parametrize("rows,Q", [(14, 20), (14, 50), (6, 15), (40, 20)])
 def test_values_match_griddata_linear(lib, rows, Q):
     rng = np.random.default_rng(rows + Q)

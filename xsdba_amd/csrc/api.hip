@@ -1035,11 +1035,37 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
     if (use_lds && (rc = set_lds(xs::k_lin2d_adjust<R, true>, L.staged, ctx, "the triangulated table"))) return rc;
     for (int64_t c0 = 0; c0 < C; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, C - c0);
-        {
+        // the triangulations: a workgroup per cell (row construction + parallel flips, k_lin2d_build_rows); XSDBA_HIP_LIN2D_BUILD=sweep
+        // pins the one-thread-per-cell sweep of rounds 1-3 (A/B runs)
+        const char *bsel = getenv("XSDBA_HIP_LIN2D_BUILD");
+        if (bsel && !strcmp(bsel, "sweep")) {
             LaunchScope ls(ctx, "k_lin2d_build");
             hipLaunchKernelGGL(xs::k_lin2d_build<R>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream,
                                (const R *)dhq + (hq_is_row ? 0 : (size_t)c0 * G * Q), (const R *)daf + (size_t)c0 * G * Q, (const double *)dgc, G, Q, nc,
                                (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0, cubic);
+        } else {
+            {
+                // small tables are triangulated in LDS (64 B per node + the row tables): a wave per cell, as many cells per CU as fit
+                const size_t lds_small = xs::lin2d_rows_lds(G, Q, true);
+                const bool in_lds = lds_small <= 40 * 1024;
+                if (in_lds && (rc = set_lds(xs::k_lin2d_build_rows<R, true>, lds_small, ctx, "the table's triangulation"))) return rc;
+                LaunchScope ls(ctx, "k_lin2d_build_rows");
+                const unsigned nthr = in_lds ? 64u : 256u;
+                const int per_cu = in_lds ? (int)std::max<size_t>(1, std::min<size_t>(32, (size_t)ctx->lds_limit / lds_small)) : 8;
+                const unsigned nblk = (unsigned)std::min<int64_t>(nc, (int64_t)per_cu * ctx->n_cu);
+                auto launch = [&](auto k, size_t lds) {
+                    hipLaunchKernelGGL(k, dim3(nblk), dim3(nthr), lds, ctx->stream,
+                                       (const R *)dhq + (hq_is_row ? 0 : (size_t)c0 * G * Q), (const R *)daf + (size_t)c0 * G * Q, (const double *)dgc, G, Q,
+                                       nc, (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0, cubic);
+                };
+                if (in_lds) launch(xs::k_lin2d_build_rows<R, true>, lds_small);
+                else launch(xs::k_lin2d_build_rows<R, false>, xs::lin2d_rows_lds(G, Q, false));
+            }
+            if ((rc = check_launch("k_lin2d_build_rows"))) return rc;
+            if (cubic) {
+                LaunchScope ls(ctx, "k_lin2d_grad");
+                hipLaunchKernelGGL(xs::k_lin2d_grad, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream, G, Q, nc, (unsigned char *)scratch, L.total);
+            }
         }
         if ((rc = check_launch("k_lin2d_build"))) return rc;
         {

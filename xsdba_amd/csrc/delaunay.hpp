@@ -208,6 +208,144 @@ XS_HD int dt_build(Tri2D &d, const uint16_t *ord)
     return d.ntri;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-parallel construction (round 4).  The nodes of a table lie on R horizontal rows (ascending y), ascending x inside a
+// row: ANY triangulation of the convex hull can be flipped into the Delaunay one (Lawson), and a table has an obvious one —
+// the strips between consecutive non-empty rows, each zipped left to right, plus the pockets between the polylines of the
+// rows' first / last nodes and the hull.  The strips are independent (a lane each), the flips of a round are independent
+// once every flip owns the triangles it writes (the callers arbitrate with an atomic min per triangle), and no step puts a
+// whole cell behind one lane except the pocket scan (2 R steps).  The phases are separate functions so that the device
+// kernel (lin2d.hpp: k_lin2d_build_rows) and the host emulation (tests/native/delaunay_host.cpp) share them.
+
+// phase 0 (one lane): the non-empty rows ne[0, m) and the first triangle of every strip sbase[0, m).  Returns m, or -1 when
+// the rows do not support the construction (fewer than two non-empty rows, or a non-empty row of a single node: its strip
+// edge would bound both pockets) — the sweep of dt_build serves those tables.
+XS_HD int dtp_plan(const int *rowb, int R, uint16_t *ne, int *sbase)
+{
+    int m = 0;
+    for (int r = 0; r < R; r++) {
+        const int cnt = rowb[r + 1] - rowb[r];
+        if (cnt == 1) return -1;
+        if (cnt > 0) ne[m++] = (uint16_t)r;
+    }
+    if (m < 2) return -1;
+    int t = 0;
+    for (int s2 = 0; s2 + 1 < m; s2++) {
+        sbase[s2] = t;
+        t += (rowb[ne[s2] + 1] - rowb[ne[s2]]) + (rowb[ne[s2 + 1] + 1] - rowb[ne[s2 + 1]]) - 2;
+    }
+    sbase[m - 1] = t;
+    return m;
+}
+
+// phase 1 (a lane per strip s2 in [0, m - 1)): the strip between rows A = ne[s2] (below) and B = ne[s2 + 1] zipped from the
+// left; of the two possible next triangles the one whose circumcircle is free of the other candidate.  up[i] / dn[i]: the
+// triangle above / below the row edge (i, i + 1) (both preset to DT_NONE by the caller).
+XS_HD void dtp_zip(Tri2D &d, const int *rowb, const uint16_t *ne, const int *sbase, int s2, uint16_t *up, uint16_t *dn)
+{
+    const int A = ne[s2], B = ne[s2 + 1];
+    const int a0 = rowb[A], p = rowb[A + 1] - a0, b0 = rowb[B], q = rowb[B + 1] - b0;
+    const int t_first = sbase[s2], t_end = sbase[s2 + 1];
+    int i = 0, j = 0;
+    for (int t = t_first; t < t_end; t++) {
+        bool adv_a;
+        if (i + 1 >= p) adv_a = false;
+        else if (j + 1 >= q) adv_a = true;
+        else adv_a = !(dt_incircle(d, a0 + i, a0 + i + 1, b0 + j, b0 + j + 1) > 0.0);
+        const int prev = t > t_first ? t - 1 : DT_NONE, next = t + 1 < t_end ? t + 1 : DT_NONE;
+        if (adv_a) {  // (a_i, a_i+1, b_j): opposite a_i the right diagonal, opposite a_i+1 the left one, opposite b_j the row edge
+            dt_set(d, t, a0 + i, a0 + i + 1, b0 + j, next, prev, DT_NONE);
+            up[a0 + i] = (uint16_t)t;
+            i++;
+        } else {      // (a_i, b_j+1, b_j): opposite a_i the row edge, opposite b_j+1 the left diagonal, opposite b_j the right one
+            dt_set(d, t, a0 + i, b0 + j + 1, b0 + j, DT_NONE, prev, next);
+            dn[b0 + j] = (uint16_t)t;
+            j++;
+        }
+    }
+}
+
+// phase 2 (a lane per strip triangle): the neighbour across its row edge, from the tables of phase 1
+XS_HD void dtp_link(Tri2D &d, int t, const uint16_t *up, const uint16_t *dn)
+{
+    const int v0 = d.tv[3 * t], v1 = d.tv[3 * t + 1], v2 = d.tv[3 * t + 2];
+    if (d.py[v1] == d.py[v0]) d.tn[3 * t + 2] = dn[v0];  // row edge (a_i, a_i+1) below the triangle
+    else d.tn[3 * t] = up[v2];                            // row edge (b_j, b_j+1) above it
+}
+
+// phase 3 (one lane): the pockets left of the rows' first nodes and right of their last ones (a monotone-chain scan per side:
+// every pop is a triangle).  stk / own_t / own_s: work arrays of m entries.  Returns the number of triangles.
+XS_HD int dtp_pockets(Tri2D &d, const int *rowb, const uint16_t *ne, int m, const int *sbase, uint16_t *stk, uint16_t *own_t,
+                      uint16_t *own_s)
+{
+    int ntri = sbase[m - 1];
+    for (int side = 0; side < 2; side++) {
+        int sp = 0;
+        for (int k = 0; k < m; k++) {
+            const int P = side == 0 ? rowb[ne[k]] : rowb[ne[k] + 1] - 1;
+            int cur_t = DT_NONE, cur_s = 0;  // the triangle on the edge (stk[sp - 1], P) and its slot there
+            if (k > 0) {
+                if (side == 0) { cur_t = sbase[k - 1]; cur_s = 1; }
+                else {
+                    cur_t = sbase[k] - 1;  // the strip's last triangle: its right diagonal
+                    cur_s = d.py[d.tv[3 * cur_t + 1]] == d.py[d.tv[3 * cur_t]] ? 0 : 2;
+                }
+            }
+            while (sp >= 2) {
+                const int A = stk[sp - 2], B = stk[sp - 1];
+                const double o = dt_orient(d, A, B, P);
+                if (!(side == 0 ? o > 0.0 : o < 0.0)) break;
+                const int T = ntri++;
+                const int ab_t = own_t[sp - 2], ab_s = own_s[sp - 2];
+                if (side == 0) dt_set(d, T, A, B, P, cur_t, DT_NONE, ab_t);  // new hull edge (P, A): opposite B
+                else dt_set(d, T, A, P, B, cur_t, ab_t, DT_NONE);            // new hull edge (A, P): opposite B
+                d.tn[3 * cur_t + cur_s] = (uint16_t)T;
+                d.tn[3 * ab_t + ab_s] = (uint16_t)T;
+                cur_t = T;
+                cur_s = side == 0 ? 1 : 2;
+                sp--;
+            }
+            if (sp >= 1) { own_t[sp - 1] = (uint16_t)cur_t; own_s[sp - 1] = (uint16_t)cur_s; }
+            stk[sp++] = (uint16_t)P;
+        }
+    }
+    d.ntri = ntri;
+    return ntri;
+}
+
+// phase 4, per round and per (triangle t, slot i) with a neighbour across the edge opposite slot i: does the edge want a flip,
+// and which triangles would the flip write — t, u and the two outer neighbours whose back-pointers move (DT_NONE where there is
+// none).  The caller tests an edge once per round and lets a flip happen when it holds all four.
+XS_HD bool dtp_flip_sites(const Tri2D &d, int t, int i, int *sites)
+{
+    const int u = d.tn[3 * t + i];
+    if (u == DT_NONE) return false;
+    const int j = dt_slot_of(d, u, t);
+    const int a = d.tv[3 * t + i], b = d.tv[3 * t + (i + 1) % 3], c = d.tv[3 * t + (i + 2) % 3];
+    const int q = d.tv[3 * u + j];
+    if (!(dt_incircle(d, a, b, c, q) > 0.0)) return false;
+    if (!(dt_orient(d, a, b, q) > 0.0 && dt_orient(d, a, q, c) > 0.0)) return false;  // (rounding: the quadrilateral must stay convex)
+    sites[0] = t; sites[1] = u;
+    sites[2] = d.tn[3 * u + (j + 1) % 3];
+    sites[3] = d.tn[3 * t + (i + 1) % 3];
+    return true;
+}
+
+// the flip itself (dt_legalize's): t = (a, b, c), u = (q, c, b)  ->  t = (a, b, q), u = (a, q, c)
+XS_HD void dtp_flip_apply(Tri2D &d, int t, int i)
+{
+    const int u = d.tn[3 * t + i];
+    const int j = dt_slot_of(d, u, t);
+    const int a = d.tv[3 * t + i], b = d.tv[3 * t + (i + 1) % 3], c = d.tv[3 * t + (i + 2) % 3];
+    const int q = d.tv[3 * u + j];
+    const int X = d.tn[3 * u + (j + 1) % 3], Y = d.tn[3 * u + (j + 2) % 3];
+    const int Z = d.tn[3 * t + (i + 1) % 3], W = d.tn[3 * t + (i + 2) % 3];
+    dt_set(d, t, a, b, q, X, u, W);
+    dt_set(d, u, a, q, c, Y, Z, t);
+    if (X != DT_NONE) d.tn[3 * X + dt_slot_of(d, X, u)] = (uint16_t)t;
+    if (Z != DT_NONE) d.tn[3 * Z + dt_slot_of(d, Z, t)] = (uint16_t)u;
+}
+
 // Triangle containing (qx, qy), walking from `start`; -1 outside the hull.  Points within a relative tolerance of an
 // edge count as inside (scipy's _find_simplex works with eps = 100 * DBL_EPSILON on the barycentric coordinates).
 XS_HD int dt_locate(const Tri2D &d, double qx, double qy, int start)

@@ -21,7 +21,12 @@ namespace xs {
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
     size_t grad, adjp, adji;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form (build only)
+    size_t lock, work, cand;  // k_lin2d_build_rows only: a bid per triangle, the two work lists + their bitmaps, the flips wanted in a round
 };
+
+// a flip wanted in a round of k_lin2d_build_rows: its bid and the triangles it writes
+struct Lin2DCand { uint32_t bid; uint16_t t, i, sites[4]; };
+static_assert(sizeof(Lin2DCand) == 16, "one 16-byte record per wanted flip");
 
 __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = false)
 {
@@ -45,6 +50,11 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = f
     o = (o + 7) & ~(size_t)7;
     L.adjp = o; if (cubic) o += sizeof(int) * (N + 2);
     L.adji = o; if (cubic) o += sizeof(uint16_t) * (6 * N + 8);
+    o = (o + 15) & ~(size_t)15;
+    L.lock = o; o += sizeof(uint32_t) * 2 * N;
+    L.work = o; o += sizeof(uint16_t) * 4 * N + 2 * (((2 * N + 31) / 32) * 4);
+    o = (o + 15) & ~(size_t)15;
+    L.cand = o; o += sizeof(Lin2DCand) * 2 * N;
     L.total = (o + 15) & ~(size_t)15;
     return L;
 }
@@ -114,6 +124,218 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
         dt_adjacency(d, adjp, adji, d.hnext);
         dt_gradients(d, pv, adjp, adji, reinterpret_cast<double *>(base + L.grad));
     }
+}
+
+// The same slice as k_lin2d_build leaves, built by ONE WORKGROUP per cell (delaunay.hpp: dtp_*): a lane per table row compacts
+// the nodes, a lane per strip zips it, lane 0 scans the two pockets, then rounds of parallel Lawson flips — (A) every edge whose
+// triangles changed in the previous round is tested, a wanted flip is recorded with the triangles it writes and bids for them
+// (atomic min of a round-stamped edge number), (B) the flips that hold all their triangles are applied.  Tables the row
+// construction does not take (a row of one node, fewer than two rows) are swept by lane 0 (dt_build).  cubic: the gradients are
+// k_lin2d_grad's.  IN_LDS (tables of a few hundred nodes: monthly, seasonal): coordinates, triangles and the flip bookkeeping live
+// in LDS (64 bytes per node) and the triangles are copied to the slice at the end — in global memory a round costs a chain of L2
+// round trips per tested edge, 4.3 ms per cell; dynamic LDS: lin2d_rows_lds(G, Q, IN_LDS) bytes.
+__host__ __device__ inline size_t lin2d_rows_lds(int G, int Q, bool in_lds)
+{
+    const size_t N = (size_t)(G + 2) * Q;
+    return (size_t)(G + 3) * 16 + 64 + (in_lds ? N * 64 + 2 * (((2 * N + 31) / 32) * 4) : 0);
+}
+
+template <typename R, bool IN_LDS>
+__global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict__ yq, const double *__restrict__ gcoord, int G, int Q,
+                                   int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row, int cubic)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int NR = G + 2, tid = threadIdx.x, NT = blockDim.x;
+    int *rowb = reinterpret_cast<int *>(smem);                       // [NR + 1]
+    int *sbase = rowb + (NR + 1);                                    // [NR + 1]
+    uint16_t *ne = reinterpret_cast<uint16_t *>(sbase + (NR + 1));   // [NR] each
+    uint16_t *stk = ne + NR, *own_t = stk + NR, *own_s = own_t + NR;
+    int *sh = reinterpret_cast<int *>(smem + (size_t)(G + 3) * 16);  // [0] m, [1] ntri, [2] flips wanted in the round, [3] length of the next list
+    const Lin2DLayout L = lin2d_layout(G, Q, cubic != 0);
+    const size_t N = (size_t)NR * Q;
+    // IN_LDS working set: px | py (8 N each) | tv | tn (12 N each) | up | dn (2 N each), then over them the two work lists (4 N each;
+    // the sweep's hull ring + order: 8 N) | lock (8 N) | wanted flips (N / 2 records) | the lists' bitmaps
+    unsigned char *wk = smem + (size_t)(G + 3) * 16 + 64;
+    for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        unsigned char *base = scratch + (size_t)c * stride;
+        int *hdr = reinterpret_cast<int *>(base + L.hdr);
+        double *meta = reinterpret_cast<double *>(base + L.meta);
+        double *px = reinterpret_cast<double *>(base + L.px), *py = reinterpret_cast<double *>(base + L.py);
+        double *pv = reinterpret_cast<double *>(base + L.pv);
+        int *rowb_g = reinterpret_cast<int *>(base + L.rowb);
+        double *gcs = reinterpret_cast<double *>(base + L.gc);
+        // ---- the nodes: a lane per row counts, lane 0 sums, the lane writes (k_lin2d_build's rule, row by row)
+        auto row_nodes = [&](int r, int n0, bool write) {
+            const int g = ext_row(r, G);
+            const R *xr = xq_is_row ? xq : xq + ((size_t)c * G + g) * Q, *yr = yq + ((size_t)c * G + g) * Q;
+            double xf = __builtin_nan(""), xl = xf, yf = xf, yl = xf, last = 0.0;
+            bool fx = false, fy = false;
+            int n = n0;
+            for (int k = 0; k < Q; k++) {
+                const R xv = xr[k], yv = yr[k];
+                if (xv == xv) { if (!fx) { xf = (double)xv; fx = true; } xl = (double)xv; }
+                if (yv == yv) { if (!fy) { yf = (double)yv; fy = true; } yl = (double)yv; }
+                if (xv == xv && yv == yv) {
+                    if (n > n0 && !((double)xv > last)) continue;
+                    last = (double)xv;
+                    if (write) {
+                        px[n] = (double)xv; py[n] = gcoord[r]; pv[n] = (double)yv;
+                        if (IN_LDS) { reinterpret_cast<double *>(wk)[n] = (double)xv; reinterpret_cast<double *>(wk + 8 * N)[n] = gcoord[r]; }
+                    }
+                    n++;
+                }
+            }
+            if (write) { meta[4 * r] = xf; meta[4 * r + 1] = xl; meta[4 * r + 2] = yf; meta[4 * r + 3] = yl; gcs[r] = gcoord[r]; }
+            return n - n0;
+        };
+        for (int r = tid; r < NR; r += NT) sbase[r] = row_nodes(r, 0, false);
+        __syncthreads();
+        if (tid == 0) {
+            int n = 0;
+            for (int r = 0; r < NR; r++) { rowb[r] = n; n += sbase[r]; }
+            rowb[NR] = n;
+        }
+        __syncthreads();
+        const int n = rowb[NR];
+        for (int r = tid; r < NR; r += NT) { row_nodes(r, rowb[r], true); rowb_g[r] = rowb[r]; }
+        if (tid == 0) { rowb_g[NR] = n; hdr[0] = n; }
+        Tri2D d;
+        uint16_t *tv_g = reinterpret_cast<uint16_t *>(base + L.tv), *tn_g = reinterpret_cast<uint16_t *>(base + L.tn);
+        d.px = IN_LDS ? reinterpret_cast<const double *>(wk) : px;
+        d.py = IN_LDS ? reinterpret_cast<const double *>(wk + 8 * N) : py;
+        d.tv = IN_LDS ? reinterpret_cast<uint16_t *>(wk + 16 * N) : tv_g;
+        d.tn = IN_LDS ? reinterpret_cast<uint16_t *>(wk + 28 * N) : tn_g;
+        d.hnext = IN_LDS ? reinterpret_cast<uint16_t *>(wk + 40 * N) : reinterpret_cast<uint16_t *>(base + L.hull);
+        d.hprev = d.hnext + N;
+        d.htri = d.hprev + N;
+        d.n = n;
+        d.ntri = 0;
+        uint16_t *up = d.hnext, *dn = d.hprev;  // (the hull ring of the sweep is not needed by the row construction)
+        // work lists of the rounds (the triangles that changed) + a bit per triangle each; in LDS they take the place of up / dn
+        uint16_t *list0 = IN_LDS ? reinterpret_cast<uint16_t *>(wk + 40 * N) : reinterpret_cast<uint16_t *>(base + L.work);
+        const int BW = (int)((2 * N + 31) / 32);
+        uint32_t *bits0 = IN_LDS ? reinterpret_cast<uint32_t *>(wk + 64 * N) : reinterpret_cast<uint32_t *>(base + L.work + 8 * N);
+        uint32_t *lock = IN_LDS ? reinterpret_cast<uint32_t *>(wk + 48 * N) : reinterpret_cast<uint32_t *>(base + L.lock);
+        Lin2DCand *cand = IN_LDS ? reinterpret_cast<Lin2DCand *>(wk + 56 * N) : reinterpret_cast<Lin2DCand *>(base + L.cand);
+        const int CAP = IN_LDS ? (int)(N / 2) : (int)(2 * N);
+        const int NTRI_MAX = (int)(2 * N);
+        for (int i = tid; i < n; i += NT) { up[i] = DT_NONE; dn[i] = DT_NONE; }
+        for (int i = tid; i < NTRI_MAX; i += NT) lock[i] = 0xFFFFFFFFu;
+        if (tid == 0) sh[0] = dtp_plan(rowb, NR, ne, sbase);
+        __syncthreads();
+        const int m = sh[0];
+        int ntri = 0;
+        if (m < 0) {
+            if (tid == 0) {  // the sweep (k_lin2d_build)
+                uint16_t *ord = d.htri + N;
+                if (NR <= 32) dt_sort_order(d, ord);
+                else for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
+                sh[1] = dt_build(d, ord);
+            }
+            __syncthreads();
+            ntri = sh[1];
+        } else {
+            for (int s2 = tid; s2 + 1 < m; s2 += NT) dtp_zip(d, rowb, ne, sbase, s2, up, dn);
+            __syncthreads();
+            for (int t = tid; t < sbase[m - 1]; t += NT) dtp_link(d, t, up, dn);
+            __syncthreads();
+            if (tid == 0) sh[1] = dtp_pockets(d, rowb, ne, m, sbase, stk, own_t, own_s);
+            __syncthreads();
+            ntri = sh[1];
+            const int maxr = min(8 * n + 64, 16000);
+            uint16_t *cur = list0, *nxt = list0 + 2 * N;
+            uint32_t *bcur = bits0, *bnxt = bits0 + BW;
+            for (int t = tid; t < ntri; t += NT) cur[t] = (uint16_t)t;  // (up / dn are dead: the link phase is behind a barrier)
+            for (int w = tid; w < BW; w += NT) { bcur[w] = 0xFFFFFFFFu; bnxt[w] = 0u; }
+            int ncur = ntri;
+            for (int r = 1; r <= maxr; r++) {
+                if (tid == 0) { sh[2] = 0; sh[3] = 0; }
+                __syncthreads();
+                // (A) test the edges of the triangles on the list (an edge between two of them from the lower-numbered one), record, bid
+                for (int k = tid; k < ncur; k += NT) {
+                    const int t = cur[k];
+#pragma unroll
+                    for (int i = 0; i < 3; i++) {
+                        const int u = d.tn[3 * t + i];
+                        if (u == DT_NONE || (u < t && ((bcur[u >> 5] >> (u & 31)) & 1u))) continue;
+                        int sites[4];
+                        if (!dtp_flip_sites(d, t, i, sites)) continue;
+                        const int kc = atomicAdd(&sh[2], 1);
+                        if (kc >= CAP) {  // (no room: the triangle stays on the list)
+                            if (!((atomicOr(&bnxt[t >> 5], 1u << (t & 31)) >> (t & 31)) & 1u)) nxt[atomicAdd(&sh[3], 1)] = (uint16_t)t;
+                            continue;
+                        }
+                        const uint32_t bid = ((uint32_t)(16383 - r) << 18) | (uint32_t)(3 * t + i);
+                        Lin2DCand cd;
+                        cd.bid = bid; cd.t = (uint16_t)t; cd.i = (uint16_t)i;
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; k2++) {
+                            cd.sites[k2] = (uint16_t)sites[k2];
+                            if (sites[k2] != DT_NONE) atomicMin(&lock[sites[k2]], bid);
+                        }
+                        cand[kc] = cd;
+                    }
+                }
+                __syncthreads();
+                const int nc = min(sh[2], CAP);
+                if (nc == 0) break;  // (block-uniform)
+                // (B) the flips that hold every triangle they write; their triangles (a loser: its first) go on the next list
+                for (int k = tid; k < nc; k += NT) {
+                    const Lin2DCand cd = cand[k];
+                    bool mine = true;
+#pragma unroll
+                    for (int k2 = 0; k2 < 4; k2++) mine = mine && (cd.sites[k2] == DT_NONE || lock[cd.sites[k2]] == cd.bid);
+                    const int t = cd.t, u = cd.sites[1];
+                    if (mine) {
+                        dtp_flip_apply(d, t, cd.i);
+                        if (!((atomicOr(&bnxt[u >> 5], 1u << (u & 31)) >> (u & 31)) & 1u)) nxt[atomicAdd(&sh[3], 1)] = (uint16_t)u;
+                    }
+                    if (!((atomicOr(&bnxt[t >> 5], 1u << (t & 31)) >> (t & 31)) & 1u)) nxt[atomicAdd(&sh[3], 1)] = (uint16_t)t;
+                }
+                __syncthreads();
+                ncur = sh[3];
+                for (int w = tid; w < BW; w += NT) bcur[w] = 0u;  // (the old list's bits: the arrays swap)
+                { uint16_t *tl = cur; cur = nxt; nxt = tl; }
+                { uint32_t *tb = bcur; bcur = bnxt; bnxt = tb; }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (tid == 0) hdr[1] = ntri;
+        if (IN_LDS)
+            for (int i = tid; i < 3 * ntri; i += NT) { tv_g[i] = d.tv[i]; tn_g[i] = d.tn[i]; }
+        uint16_t *vt = reinterpret_cast<uint16_t *>(base + L.vt);
+        for (int i = tid; i < n; i += NT) vt[i] = 0;
+        __syncthreads();
+        for (int t = tid; t < ntri; t += NT) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
+        __syncthreads();  // the row tables in LDS are reused by the next cell
+    }
+}
+
+// cubic: the nodal gradients of the Clough-Tocher interpolant on a finished triangulation, a thread per cell (Gauss-Seidel sweeps
+// in node order: sequential by definition)
+__global__ void k_lin2d_grad(int G, int Q, int64_t C, unsigned char *__restrict__ scratch, size_t stride)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const Lin2DLayout L = lin2d_layout(G, Q, true);
+    unsigned char *base = scratch + (size_t)c * stride;
+    const int *hdr = reinterpret_cast<const int *>(base + L.hdr);
+    const size_t N = (size_t)(G + 2) * Q;
+    Tri2D d;
+    d.px = reinterpret_cast<const double *>(base + L.px);
+    d.py = reinterpret_cast<const double *>(base + L.py);
+    d.tv = reinterpret_cast<uint16_t *>(base + L.tv);
+    d.tn = reinterpret_cast<uint16_t *>(base + L.tn);
+    d.hnext = reinterpret_cast<uint16_t *>(base + L.hull);
+    d.hprev = d.hnext + N;
+    d.htri = d.hprev + N;
+    d.n = hdr[0];
+    d.ntri = hdr[1];
+    int *adjp = reinterpret_cast<int *>(base + L.adjp);
+    uint16_t *adji = reinterpret_cast<uint16_t *>(base + L.adji);
+    dt_adjacency(d, adjp, adji, d.hnext);
+    dt_gradients(d, reinterpret_cast<const double *>(base + L.pv), adjp, adji, reinterpret_cast<double *>(base + L.grad));
 }
 
 // numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside.
