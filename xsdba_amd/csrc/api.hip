@@ -1019,8 +1019,12 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
     SeriesOut o;
     if ((rc = series_out_begin<R>(ctx, S_OUT0, S_CM1, scen, T, C, ost, osc, &o))) return rc;
     const xs::Lin2DLayout L = xs::lin2d_layout(G, Q, cubic != 0);
-    // cells in chunks so that the triangulations of a chunk take at most ~2 GiB of scratch
-    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(C, (int64_t)((2ull << 30) / L.total)));
+    // cells in chunks so that the triangulations of a chunk take at most ~4 GiB of scratch
+    const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(C, (int64_t)((4ull << 30) / L.total)));
+    // strip lists (lin2d.hpp) keep the nodes as float32 pairs: float32 tables on row coordinates that float32 holds exactly
+    int strips = std::is_same<R, float>::value && !is_device_ptr(gcoord) ? 1 : 0;  // (row coordinates on the device: no host check, the walk)
+    for (int r = 0; r < G + 2 && strips; r++) strips = (double)(float)gcoord[r] == gcoord[r];
+    if (getenv("XSDBA_HIP_LIN2D_WALK")) strips = 0;  // (A/B runs: the walk of rounds 1-3)
     void *scratch;
     if ((rc = ensure(ctx, S_SCR, L.total * (size_t)chunk, &scratch))) return rc;
     const int use_lds = L.staged <= 64 * 1024 ? 1 : 0;
@@ -1056,7 +1060,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
                 auto launch = [&](auto k, size_t lds) {
                     hipLaunchKernelGGL(k, dim3(nblk), dim3(nthr), lds, ctx->stream,
                                        (const R *)dhq + (hq_is_row ? 0 : (size_t)c0 * G * Q), (const R *)daf + (size_t)c0 * G * Q, (const double *)dgc, G, Q,
-                                       nc, (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0, cubic);
+                                       nc, (unsigned char *)scratch, L.total, hq_is_row ? 1 : 0, cubic, strips);
                 };
                 if (in_lds) launch(xs::k_lin2d_build_rows<R, true>, lds_small);
                 else launch(xs::k_lin2d_build_rows<R, false>, xs::lin2d_rows_lds(G, Q, false));

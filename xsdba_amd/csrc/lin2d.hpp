@@ -21,12 +21,16 @@ namespace xs {
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
     size_t grad, adjp, adji;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form (build only)
+    size_t sofs, sedge, stri;  // strip lists (staged): first entry of every strip, the crossing edges left to right, the triangle right of each
     size_t lock, work, cand;  // k_lin2d_build_rows only: a bid per triangle, the two work lists + their bitmaps, the flips wanted in a round
 };
 
 // a flip wanted in a round of k_lin2d_build_rows: its bid and the triangles it writes
 struct Lin2DCand { uint32_t bid; uint16_t t, i, sites[4]; };
 static_assert(sizeof(Lin2DCand) == 16, "one 16-byte record per wanted flip");
+
+// entries of a cell's strip lists (an edge counts once per strip it crosses: about 2.2 per node on tables like the bench's)
+__host__ __device__ inline size_t lin2d_strip_cap(int G, int Q) { return (size_t)4 * (G + 2) * Q; }
 
 __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = false)
 {
@@ -45,6 +49,14 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = f
     L.rowb = o; o += sizeof(int) * (size_t)(G + 3);            // first node of every cyclic row
     o = (o + 7) & ~(size_t)7;
     L.grad = o; if (cubic) o += sizeof(double) * 2 * N;
+    // strip lists (k_lin2d_build_rows; hdr[2] says whether the cell has them): between two consecutive rows no node lies, so the
+    // edges crossing that strip are ordered left to right and exactly one triangle lies between two neighbours — a query is located
+    // by a bisection over its strip's edges instead of a walk through the triangulation
+    L.sofs = o; o += sizeof(int) * (size_t)(G + 2);
+    o = (o + 15) & ~(size_t)15;
+    L.sedge = o; o += 16 * lin2d_strip_cap(G, Q);
+    L.stri = o; o += sizeof(uint16_t) * lin2d_strip_cap(G, Q);
+    o = (o + 7) & ~(size_t)7;
     L.staged = o;
     L.hull = o; o += sizeof(uint16_t) * 4 * N;  // hull ring (3N) + insertion order (N): build only
     o = (o + 7) & ~(size_t)7;
@@ -115,6 +127,7 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     else for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
     const int ntri = dt_build(d, ord);
     hdr[1] = ntri;
+    hdr[2] = 0;  // no strip lists: the adjustment walks
     uint16_t *vt = reinterpret_cast<uint16_t *>(base + L.vt);
     for (int i = 0; i < n; i++) vt[i] = 0;
     for (int t = 0; t < ntri; t++) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
@@ -137,12 +150,12 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
 __host__ __device__ inline size_t lin2d_rows_lds(int G, int Q, bool in_lds)
 {
     const size_t N = (size_t)(G + 2) * Q;
-    return (size_t)(G + 3) * 16 + 64 + (in_lds ? N * 64 + 2 * (((2 * N + 31) / 32) * 4) : 0);
+    return (size_t)(G + 3) * 24 + 64 + (in_lds ? N * 64 + 2 * (((2 * N + 31) / 32) * 4) : 0);
 }
 
 template <typename R, bool IN_LDS>
 __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict__ yq, const double *__restrict__ gcoord, int G, int Q,
-                                   int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row, int cubic)
+                                   int64_t C, unsigned char *__restrict__ scratch, size_t stride, int xq_is_row, int cubic, int strips)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int NR = G + 2, tid = threadIdx.x, NT = blockDim.x;
@@ -150,12 +163,14 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
     int *sbase = rowb + (NR + 1);                                    // [NR + 1]
     uint16_t *ne = reinterpret_cast<uint16_t *>(sbase + (NR + 1));   // [NR] each
     uint16_t *stk = ne + NR, *own_t = stk + NR, *own_s = own_t + NR;
-    int *sh = reinterpret_cast<int *>(smem + (size_t)(G + 3) * 16);  // [0] m, [1] ntri, [2] flips wanted in the round, [3] length of the next list
+    int *sofs = reinterpret_cast<int *>(smem + (size_t)(G + 3) * 16);  // [NR + 1] strip counts, then offsets
+    uint16_t *start_t = reinterpret_cast<uint16_t *>(sofs + (NR + 1)), *start_i = start_t + NR;  // [NR] each: the left hull edge of a strip
+    int *sh = reinterpret_cast<int *>(smem + (size_t)(G + 3) * 24);  // [0] m, [1] ntri, [2] flips wanted in the round, [3] length of the next list, [4] strips fine
     const Lin2DLayout L = lin2d_layout(G, Q, cubic != 0);
     const size_t N = (size_t)NR * Q;
     // IN_LDS working set: px | py (8 N each) | tv | tn (12 N each) | up | dn (2 N each), then over them the two work lists (4 N each;
     // the sweep's hull ring + order: 8 N) | lock (8 N) | wanted flips (N / 2 records) | the lists' bitmaps
-    unsigned char *wk = smem + (size_t)(G + 3) * 16 + 64;
+    unsigned char *wk = smem + (size_t)(G + 3) * 24 + 64;
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         unsigned char *base = scratch + (size_t)c * stride;
         int *hdr = reinterpret_cast<int *>(base + L.hdr);
@@ -308,6 +323,77 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
         for (int i = tid; i < n; i += NT) vt[i] = 0;
         __syncthreads();
         for (int t = tid; t < ntri; t += NT) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
+        // ---- strip lists (strips: the coordinates are float-exact, host-checked): count the edges crossing every strip (a lane per
+        // edge), note the strip's left hull edge, then a lane per strip walks from it to the right hull edge — the crossing edges
+        // come out in order, each with the triangle on its right
+        __syncthreads();
+        if (strips && ntri > 0) {
+            auto row_of = [&](int v) { int lo = 0, hi = NR - 1; while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (rowb[mid] <= v) lo = mid; else hi = mid - 1; } return lo; };
+            for (int s2 = tid; s2 < NR; s2 += NT) { sofs[s2] = 0; start_t[s2] = DT_NONE; }
+            if (tid == 0) sh[4] = 1;
+            __syncthreads();
+            for (int e = tid; e < 3 * ntri; e += NT) {
+                const int t = e / 3, i = e - 3 * t;
+                const int u = d.tn[3 * t + i];
+                if (u != DT_NONE && u < t) continue;  // (every edge once)
+                const int a = d.tv[3 * t + (i + 1) % 3], b = d.tv[3 * t + (i + 2) % 3];
+                // (a row keeps its nodes together: an empty row has rowb[r] == rowb[r + 1] and is skipped by the bisection)
+                const int ra = row_of(a), rb = row_of(b);
+                if (ra == rb) continue;
+                const int lo = min(ra, rb), hi = max(ra, rb);
+                for (int s2 = lo; s2 < hi; s2++) atomicAdd(&sofs[s2], 1);
+                if (u == DT_NONE && ra > rb)  // counter-clockwise a -> b runs downwards: the hull's left side
+                    for (int s2 = lo; s2 < hi; s2++) { start_t[s2] = (uint16_t)t; start_i[s2] = (uint16_t)i; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int acc = 0;
+                for (int s2 = 0; s2 < NR; s2++) { const int c2 = sofs[s2]; sofs[s2] = acc; acc += c2; }
+                sofs[NR] = acc;
+                if ((size_t)acc > lin2d_strip_cap(G, Q)) sh[4] = 0;
+            }
+            __syncthreads();
+            int *sofs_g = reinterpret_cast<int *>(base + L.sofs);
+            float4 *sedge = reinterpret_cast<float4 *>(base + L.sedge);
+            uint16_t *stri = reinterpret_cast<uint16_t *>(base + L.stri);
+            if (sh[4]) {
+                for (int s2 = tid; s2 < NR; s2 += NT) sofs_g[s2] = sofs[s2];
+                for (int s2 = tid; s2 + 1 < NR; s2 += NT) {
+                    int k = sofs[s2];
+                    const int kend = sofs[s2 + 1];
+                    int t = start_t[s2];
+                    if (t == DT_NONE) { if (k != kend) sh[4] = 0; continue; }
+                    const int i0 = start_i[s2];
+                    int hi_v = d.tv[3 * t + (i0 + 1) % 3], lo_v = d.tv[3 * t + (i0 + 2) % 3];
+                    const double yhi = gcoord[s2 + 1];
+                    for (int guard = 0; guard <= kend - sofs[s2] && k < kend; guard++) {
+                        sedge[k] = make_float4((float)d.px[lo_v], (float)d.py[lo_v], (float)d.px[hi_v], (float)d.py[hi_v]);
+                        stri[k] = (uint16_t)t;
+                        k++;
+                        const int v0 = d.tv[3 * t], v1 = d.tv[3 * t + 1], v2 = d.tv[3 * t + 2];
+                        const int cth = (v0 != lo_v && v0 != hi_v) ? v0 : ((v1 != lo_v && v1 != hi_v) ? v1 : v2);
+                        // the third corner lies on or beyond one of the two rows: the way out is the edge from it to the far end
+                        int opp;
+                        if (d.py[cth] >= yhi) { opp = hi_v; hi_v = cth; } else { opp = lo_v; lo_v = cth; }
+                        const int slot = v0 == opp ? 0 : (v1 == opp ? 1 : 2);
+                        const int u = d.tn[3 * t + slot];
+                        if (u == DT_NONE) {  // the hull's right side
+                            if (k < kend) {
+                                sedge[k] = make_float4((float)d.px[lo_v], (float)d.py[lo_v], (float)d.px[hi_v], (float)d.py[hi_v]);
+                                stri[k] = DT_NONE;
+                                k++;
+                            }
+                            t = DT_NONE;
+                            break;
+                        }
+                        t = u;
+                    }
+                    if (k != kend || t != DT_NONE) sh[4] = 0;  // (never seen: the cell then walks)
+                }
+            }
+            __syncthreads();
+            if (tid == 0) hdr[2] = sh[4];
+        } else if (tid == 0) hdr[2] = 0;
         __syncthreads();  // the row tables in LDS are reused by the next cell
     }
 }
@@ -410,6 +496,10 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         d.hnext = d.hprev = d.htri = nullptr;
         d.n = hdr[0];
         d.ntri = hdr[1];
+        const bool has_strips = hdr[2] != 0;
+        const int *sofs = reinterpret_cast<const int *>(base + L.sofs);
+        const float4 *sedge = reinterpret_cast<const float4 *>(base + L.sedge);
+        const uint16_t *stri = reinterpret_cast<const uint16_t *>(base + L.stri);
         const R *x = sim + c * sc;
         const R *trc = trend ? trend + (size_t)c * T : nullptr;
         const double *lk = lookup ? lookup + (size_t)c * T : nullptr;  // the abscissa to look up when it is not the series itself (QDM: sim_q)
@@ -422,18 +512,45 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
             R a = nan_of<R>();
             const double vx = lk ? lk[t] : (double)v;
             if (vx == vx && g == g && d.n > 0) {  // (a cell without a single valid node stays NaN: utils.py:384-390)
-                // start the walk at a triangle of the node nearest in (row, x): the row next to g, bisection on its abscissae
                 const int jr = jrow[t];
-                const int r0 = jr == -1 ? 0 : (jr == -2 ? G : jr), r1 = r0 + 1;
-                int r = (g - gcoord[r0] <= gcoord[r1] - g) ? r0 : r1;
-                if (rowb[r + 1] == rowb[r]) r = r == r0 ? r1 : r0;
-                int hint = 0;
-                if (rowb[r + 1] > rowb[r]) {
-                    int lo = rowb[r], hi = rowb[r + 1] - 1;
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.px[mid] < vx) lo = mid + 1; else hi = mid; }
-                    hint = vt[lo];
+                int tri;
+                if (has_strips && jr >= 0) {
+                    // the strip between rows jr and jr + 1: its crossing edges run left to right, (x_lo, y_lo, x_hi, y_hi) each; the
+                    // first edge the query lies strictly left of ends the bisection, the triangle right of the one before holds it
+                    const int s0 = sofs[jr], s1 = sofs[jr + 1];
+                    auto side = [&](int k) {  // > 0: the query is left of edge k (dt_orient_q with the lower end first)
+                        const float4 e4 = sedge[k];
+                        return ((double)e4.z - (double)e4.x) * (g - (double)e4.y) - ((double)e4.w - (double)e4.y) * (vx - (double)e4.x);
+                    };
+                    auto beyond = [&](int k, double o) {  // the tolerance of dt_locate at a hull edge
+                        const float4 e4 = sedge[k];
+                        const double scale = (fabs((double)e4.z - (double)e4.x) + fabs((double)e4.w - (double)e4.y)) *
+                                             (fabs(vx - (double)e4.x) + fabs(g - (double)e4.y) + 1.0);
+                        return fabs(o) > 2.3e-14 * scale;
+                    };
+                    int lo = s0, hi = s1;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (side(mid) > 0.0) hi = mid; else lo = mid + 1; }
+                    tri = -1;
+                    if (s1 > s0) {
+                        if (lo == s0) { if (!beyond(s0, side(s0))) tri = stri[s0]; }  // left of the hull's left side: by a rounding only?
+                        else {
+                            tri = stri[lo - 1];
+                            if (tri == DT_NONE) tri = (lo - 2 >= s0 && !beyond(lo - 1, side(lo - 1))) ? (int)stri[lo - 2] : -1;
+                        }
+                    }
+                } else {
+                    // walk, from a triangle of the node nearest in (row, x): the row next to g, bisection on its abscissae
+                    const int r0 = jr == -1 ? 0 : (jr == -2 ? G : jr), r1 = r0 + 1;
+                    int r = (g - gcoord[r0] <= gcoord[r1] - g) ? r0 : r1;
+                    if (rowb[r + 1] == rowb[r]) r = r == r0 ? r1 : r0;
+                    int hint = 0;
+                    if (rowb[r + 1] > rowb[r]) {
+                        int lo = rowb[r], hi = rowb[r + 1] - 1;
+                        while (lo < hi) { const int mid = (lo + hi) >> 1; if (d.px[mid] < vx) lo = mid + 1; else hi = mid; }
+                        hint = vt[lo];
+                    }
+                    tri = dt_locate(d, vx, g, hint);
                 }
-                const int tri = dt_locate(d, vx, g, hint);
                 if (tri >= 0) a = (R)(cubic ? dt_eval_ct(d, pv, grad, tri, vx, g) : dt_eval(d, pv, tri, vx, g));
                 // nbutils._extrapolate_on_quantiles: below / above the group-interpolated first / last node
                 const double lo = extrap == 0 ? np_interp_at(jr, g, gcoord, meta, 4, G + 2) : 0.0;
