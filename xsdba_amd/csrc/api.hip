@@ -1051,10 +1051,11 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
             {
                 // small tables are triangulated in LDS (64 B per node + the row tables): a wave per cell, as many cells per CU as fit
                 const size_t lds_small = xs::lin2d_rows_lds(G, Q, true);
-                const bool in_lds = lds_small <= 40 * 1024;
+                const bool in_lds = lds_small <= (size_t)ctx->lds_limit;  // (up to ~2 400 nodes; day-of-year tables work in global memory)
                 if (in_lds && (rc = set_lds(xs::k_lin2d_build_rows<R, true>, lds_small, ctx, "the table's triangulation"))) return rc;
                 LaunchScope ls(ctx, "k_lin2d_build_rows");
-                const unsigned nthr = in_lds ? 64u : 256u;
+                const char *bt = getenv("XSDBA_HIP_LIN2D_THREADS");  // (tuning aid)
+                const unsigned nthr = bt ? (unsigned)std::min(1024, std::max(64, atoi(bt) / 64 * 64)) : (in_lds && (int64_t)(G + 2) * Q <= 640 ? 64u : 256u);
                 const int per_cu = in_lds ? (int)std::max<size_t>(1, std::min<size_t>(32, (size_t)ctx->lds_limit / lds_small)) : 8;
                 const unsigned nblk = (unsigned)std::min<int64_t>(nc, (int64_t)per_cu * ctx->n_cu);
                 auto launch = [&](auto k, size_t lds) {
