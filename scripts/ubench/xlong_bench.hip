@@ -61,6 +61,15 @@ int main(int argc, char **argv)
         tog_ptr[i + 1] = (int)tog_idx.size();
         maxlen = std::max(maxlen, tog_idx.size() - b);
     }
+    // positions (api.hip: d_xl_pos): the members of group 0 in time order, then group 1's, ...; the kernel's lists hold positions
+    std::vector<int> pos(T), tim(T);
+    {
+        int k = 0;
+        for (int g = 0; g < G; g++)
+            for (int t = g; t < T; t += G) { pos[t] = k; tim[k] = t; k++; }
+    }
+    for (auto &v : rows) v = pos[v];
+    for (auto &v : tog_idx) v = pos[v];
     std::vector<int> t128((size_t)G * 256, -1);
     for (int i = 0; i + 1 < G; i++) {
         const int b = tog_ptr[i], n = tog_ptr[i + 1] - b;
@@ -69,6 +78,7 @@ int main(int argc, char **argv)
         std::copy(tog_idx.begin() + b, tog_idx.begin() + b + n, row);
     }
     int *d_rp = upload(row_ptr), *d_rows = upload(rows), *d_tp = upload(tog_ptr), *d_ti = upload(tog_idx), *d_t128 = upload(t128);
+    int *d_pos = upload(pos), *d_tim = upload(tim);
     std::vector<float> q(Q);
     for (int k = 0; k < Q; k++) q[k] = (float)((k + 0.5) / Q);
     float *dq = upload(q);
@@ -119,7 +129,7 @@ int main(int argc, char **argv)
             }
             auto launch = [&]() {
                 hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), lds, 0, ref, hist, (int64_t)T, (int64_t)T, d_rp, d_rows, d_tp, d_ti, G, dq, Q, (int)'+', 1, af, hq,
-                                   (float *)nullptr, flags, flags + 1, (int64_t)C, wide ? (const int *)d_t128 : (const int *)nullptr, scratch, phase);
+                                   (float *)nullptr, flags, flags + 1, (int64_t)C, wide ? (const int *)d_t128 : (const int *)nullptr, d_pos, d_tim, scratch, phase);
             };
             char what[64];
             snprintf(what, sizeof what, "k_train_xlong: debug_phase %d", phase);

@@ -72,7 +72,11 @@ struct Plan {
     int *d_tog64 = nullptr;  // [G][64] padded toggle table when every list has <= 64 entries, else null
     int *d_tog64p = nullptr;  // the same table for k_train_cell3: no -1 entries (see get_plan)
     int *d_tog128 = nullptr;  // [G][128] padded toggle table of the long series (k_train_long) when every list has <= 128 entries
-    int *d_tog256 = nullptr;  // [G][256]: the same for k_train_xlong (series beyond 22 528 steps)
+    // k_train_xlong (series beyond 22 528 steps) keeps rank[] in global memory, ordered by (base group, occurrence) instead of by
+    // time — the steps a group transition toggles are whole base groups, i.e. contiguous there: its lists hold those positions
+    int *d_tog256 = nullptr;  // [G][256] padded toggle table (positions) when every list has <= 256 entries
+    int *d_xl_pos = nullptr, *d_xl_time = nullptr;  // [T] position of a time step, time step of a position
+    int *d_xl_rows = nullptr, *d_xl_tog = nullptr;  // row_sorted / tog_idx in positions
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     int *d_mem_t64 = nullptr;  // [32][G] the same for groups of 33 .. 64 members (the regression of k_group_trend on 60-year series)
     bool has_ungrouped = false;  // some time step belongs to no group
@@ -244,6 +248,10 @@ void free_plan(Plan *p)
     if (p->d_tog64) (void)hipFree(p->d_tog64);
     if (p->d_tog64p) (void)hipFree(p->d_tog64p);
     if (p->d_tog256) (void)hipFree(p->d_tog256);
+    if (p->d_xl_pos) (void)hipFree(p->d_xl_pos);
+    if (p->d_xl_time) (void)hipFree(p->d_xl_time);
+    if (p->d_xl_rows) (void)hipFree(p->d_xl_rows);
+    if (p->d_xl_tog) (void)hipFree(p->d_xl_tog);
     if (p->d_tog128) (void)hipFree(p->d_tog128);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
     if (p->d_mem_t64) (void)hipFree(p->d_mem_t64);
@@ -364,11 +372,24 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
                 std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t128.begin() + (size_t)(i + 1) * 128);
             if ((rc = upload_ints(ctx, t128, &pl->d_tog128))) return rc;
         }
-        if (maxlen <= 256 && T > xs::LongCfg<11>::TPAD && T <= 65535) {
-            std::vector<int> t256((size_t)G * 256, -1);
-            for (int i = 0; i + 1 < G; i++)
-                std::copy(tog_idx.begin() + tog_ptr[(size_t)i], tog_idx.begin() + tog_ptr[(size_t)i + 1], t256.begin() + (size_t)(i + 1) * 256);
-            if ((rc = upload_ints(ctx, t256, &pl->d_tog256))) return rc;
+        if (T > xs::LongCfg<11>::TPAD && T <= 65535) {
+            // positions: the members of group 0 in time order, then group 1's, ..., then the steps of no group
+            std::vector<int> pos((size_t)T, -1), tim((size_t)T, 0);
+            for (size_t k = 0; k < pl->mem_idx.size(); k++) { pos[(size_t)pl->mem_idx[k]] = (int)k; tim[k] = pl->mem_idx[k]; }
+            int next = (int)pl->mem_idx.size();
+            for (int64_t t = 0; t < T; t++)
+                if (pos[(size_t)t] < 0) { pos[(size_t)t] = next; tim[(size_t)next] = (int)t; next++; }
+            std::vector<int> rows_p(row_sorted.size()), tog_p(tog_idx.size());
+            for (size_t k = 0; k < row_sorted.size(); k++) rows_p[k] = pos[(size_t)row_sorted[k]];
+            for (size_t k = 0; k < tog_idx.size(); k++) tog_p[k] = pos[(size_t)tog_idx[k]];
+            if ((rc = upload_ints(ctx, pos, &pl->d_xl_pos)) || (rc = upload_ints(ctx, tim, &pl->d_xl_time)) ||
+                (rc = upload_ints(ctx, rows_p, &pl->d_xl_rows)) || (rc = upload_ints(ctx, tog_p, &pl->d_xl_tog))) return rc;
+            if (maxlen <= 256) {
+                std::vector<int> t256((size_t)G * 256, -1);
+                for (int i = 0; i + 1 < G; i++)
+                    std::copy(tog_p.begin() + tog_ptr[(size_t)i], tog_p.begin() + tog_ptr[(size_t)i + 1], t256.begin() + (size_t)(i + 1) * 256);
+                if ((rc = upload_ints(ctx, t256, &pl->d_tog256))) return rc;
+            }
         }
     }
     if (G > 1 && pl->max_mem > 32 && pl->max_mem <= 64 && T < 65535) {
@@ -739,7 +760,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             fast = true;
         }
         // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
-        const bool fast_xlong = !fast && mode != 3 && pl->simple && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
+        const bool fast_xlong = !fast && mode != 3 && pl->simple && pl->d_xl_pos && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
                                 !(force && !strcmp(force, "rows"));
         if (fast_xlong) {
             void *flags, *scratch;
@@ -756,9 +777,9 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
                 LaunchScope ls(ctx, "k_train_xlong");
                 hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
-                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_xl_rows, pl->d_tog_ptr, pl->d_xl_tog, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
-                                   flag_count, flag_list, C, pl->d_tog256, (unsigned char *)scratch,
+                                   flag_count, flag_list, C, pl->d_tog256, pl->d_xl_pos, pl->d_xl_time, (unsigned char *)scratch,
 #ifdef XSDBA_DIAG
                                    getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
 #else
@@ -836,7 +857,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             fast = true;
         }
         // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
-        const bool fast_xlong = !fast && mode != 3 && pl->simple && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
+        const bool fast_xlong = !fast && mode != 3 && pl->simple && pl->d_xl_pos && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
                                 !(force && !strcmp(force, "rows"));
         if (fast_xlong) {
             void *flags, *scratch;
@@ -853,9 +874,9 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
                 if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
                 LaunchScope ls(ctx, "k_train_xlong");
                 hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
-                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_row_sorted, pl->d_tog_ptr, pl->d_tog_idx, G,
+                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_xl_rows, pl->d_tog_ptr, pl->d_xl_tog, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
-                                   flag_count, flag_list, C, pl->d_tog256, (unsigned char *)scratch,
+                                   flag_count, flag_list, C, pl->d_tog256, pl->d_xl_pos, pl->d_xl_time, (unsigned char *)scratch,
 #ifdef XSDBA_DIAG
                                    getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
 #else
