@@ -158,7 +158,9 @@ def main():
     o_sc = ctx.empty((C, G), f32) if method == "dqm" else None
     ctx.synchronize()
 
-    tm_out = False  # the time-major leg (below) asks for scen in the layout of sim
+    # scen in the layout of sim: the time-major leg (below), and --time-major itself on one GPU (the N > 1 gather verifies
+    # cell-major blocks)
+    tm_out = bool(args.time_major) and method == "eqm" and G > 1 and world == 1
 
     def step():
         """one pass of the hot path over this rank's cells; returns the device outputs"""
