@@ -6,8 +6,12 @@
 // nbutils._extrapolate_on_quantiles (nbutils.py:397-416) replaces what lies below / above the (group-interpolated) first /
 // last node by the (group-interpolated) first / last factor, or NaN.
 //
-//   k_lin2d_build : one THREAD per cell builds the cell's node list and triangulation (delaunay.hpp) in global scratch
-//   k_lin2d_adjust: one BLOCK per cell stages the triangulation in LDS (when it fits) and maps the series
+//   k_lin2d_build_rows: one WORKGROUP per cell builds the cell's node list, its Delaunay triangulation (delaunay.hpp: row strips
+//                   + pockets + arbitrated parallel Lawson flips) and the strip lists (the edges crossing every strip between two
+//                   rows, left to right); in LDS for small tables, in global scratch for day-of-year ones (round 4)
+//   k_lin2d_build : the one-THREAD-per-cell sweep of rounds 1-3 (XSDBA_HIP_LIN2D_BUILD=sweep; also the fallback inside the above)
+//   k_lin2d_adjust: one BLOCK per cell stages the triangulation in LDS (when it fits) and maps the series: an element is located
+//                   by a bisection over the edges of its strip (or, without strip lists, by a walk through the triangulation)
 //
 // Grouped interp="cubic" takes the same route with griddata(method="cubic") = scipy's CloughTocher2DInterpolator: the build
 // kernel also estimates the nodal gradients (Gauss-Seidel sweeps, delaunay.hpp: dt_gradients) and the adjust kernel evaluates
