@@ -25,7 +25,7 @@
 
 struct Plan {
     int G = 0, max_row = 0;
-    int *d_row_ptr = nullptr, *d_row_sorted = nullptr, *d_tog64 = nullptr;
+    int *d_row_ptr = nullptr, *d_row_sorted = nullptr, *d_tog64 = nullptr, *d_mem_ptr = nullptr, *d_mem_idx = nullptr, *d_mem_t32 = nullptr;
 };
 
 template <typename T> static T *upload(const std::vector<T> &v)
@@ -69,6 +69,19 @@ static Plan make_plan(int T, int G, int W)
     pl.d_row_ptr = upload(row_ptr);
     pl.d_row_sorted = upload(rows);
     pl.d_tog64 = upload(t64);
+    // the members of every group in time order + the packed member table (api.hip: d_mem_t32), for dqm_train's group sums
+    std::vector<int> mem_ptr(G + 1, 0), mem_idx, mt((size_t)16 * G, -1);
+    for (int g = 0; g < G; g++) {
+        int y = 0;
+        for (int t = g; t < T; t += G, y++) {
+            mem_idx.push_back(t);
+            uint32_t w = (uint32_t)mt[(size_t)(y / 2) * G + g];
+            w = (y & 1) ? ((w & 0x0000FFFFu) | ((uint32_t)t << 16)) : ((w & 0xFFFF0000u) | (uint32_t)t);
+            mt[(size_t)(y / 2) * G + g] = (int)w;
+        }
+        mem_ptr[g + 1] = (int)mem_idx.size();
+    }
+    pl.d_mem_ptr = upload(mem_ptr); pl.d_mem_idx = upload(mem_idx); pl.d_mem_t32 = upload(mt);
     return pl;
 }
 
@@ -79,20 +92,20 @@ static uint64_t fnv(const void *p, size_t n, uint64_t h = 1469598103934665603ull
     return h;
 }
 
-template <int STOP>
+template <int STOP, bool DQM = false>
 static void run(const char *what, const float *ref, const float *hist, int T, int C, const Plan &pl, const float *dq, int Q, float *af, float *hq,
-                int *flags, int reps, bool checksum)
+                int *flags, int reps, bool checksum, float *scaling = nullptr)
 {
     constexpr int EPT = 11;
-    auto kern = xs::k_train_cell3<EPT, true, false, STOP>;
-    const size_t lds = xs::CellCfg3<EPT>::lds_bytes;
+    auto kern = xs::k_train_cell3<EPT, true, DQM, STOP>;
+    const size_t lds = xs::CellCfg3<EPT>::lds_bytes + (DQM ? ((size_t)pl.G + 1) * sizeof(double) : 0);
     CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const unsigned nblk = (unsigned)std::min(C, 4 * 256);
     CK(hipMemset(flags, 0, 4));
     auto launch = [&]() {
-        hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), lds, 0, ref, hist, (int64_t)T, (int64_t)T, pl.d_row_ptr, pl.d_row_sorted, pl.G, dq, Q, (int)'+', 1,
-                           af, hq, (float *)nullptr, flags, flags + 1, (int64_t)C, pl.d_tog64, (const int *)nullptr, (const int *)nullptr,
-                           (const int *)nullptr, 31);
+        hipLaunchKernelGGL(kern, dim3(nblk), dim3(1024), lds, 0, ref, hist, (int64_t)T, (int64_t)T, pl.d_row_ptr, pl.d_row_sorted, pl.G, dq, Q, (int)'+', DQM ? 2 : 1,
+                           af, hq, scaling, flags, flags + 1, (int64_t)C, pl.d_tog64, DQM ? pl.d_mem_ptr : (const int *)nullptr,
+                           DQM ? pl.d_mem_idx : (const int *)nullptr, DQM ? pl.d_mem_t32 : (const int *)nullptr, 31);
     };
     launch();
     CK(hipDeviceSynchronize());
@@ -151,5 +164,15 @@ int main(int argc, char **argv)
     if (stop < 0 || stop == 3) run<3>("load + sort + build / copies / fast-forward", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
     if (stop < 0 || stop == 4) run<4>("... + group loop without the select", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false);
     if (stop < 0 || stop == 0) run<0>("full kernel", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, true);
+    if (getenv("DQM")) {  // dqm_train (mode 2): group sums by the load hook, normalised quantiles, scaling
+        float *scaling;
+        CK(hipMalloc(&scaling, (size_t)C * G * 4));
+        printf("# k_train_cell3<11, P10, DQM>\n");
+        run<1, true>("DQM: load + group sums", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false, scaling);
+        run<2, true>("DQM: ... + sort", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false, scaling);
+        run<3, true>("DQM: ... + build / copies / fast-forward", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false, scaling);
+        run<4, true>("DQM: ... + group loop without the select", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, false, scaling);
+        run<0, true>("DQM: full kernel", ref, hist, T, C, pl, dq, Q, af, hq, flags, reps, true, scaling);
+    }
     return 0;
 }
