@@ -115,7 +115,8 @@ int main(int argc, char **argv)
     };
     {
         const bool wide = !getenv("CSR");
-        auto kern = wide ? xs::k_train_xlong<false, true, 22> : xs::k_train_xlong<false, false, 22>;
+        auto kern = T <= 2 * xs::LongCfg<8>::TPAD ? (wide ? xs::k_train_xlong<false, true, 22, 8> : xs::k_train_xlong<false, false, 22, 8>)
+                                                   : (wide ? xs::k_train_xlong<false, true, 22> : xs::k_train_xlong<false, false, 22>);
         const size_t lds = XG::lds_bytes;
         CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         for (int phase : {2, 5, 6, 4, 1, 3, 0}) {

@@ -768,15 +768,15 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const unsigned nblk = (unsigned)std::min<int64_t>(C, ctx->n_cu);  // one block per CU (155 KB of LDS), cells walked grid-stride
-            auto go = [&](auto dqm, auto togp, auto wpl) -> int {
+            auto go = [&](auto dqm, auto togp, auto wpl, auto ce) -> int {
                 constexpr bool DQM = decltype(dqm)::value, TOGP = decltype(togp)::value;
-                constexpr int WPL = decltype(wpl)::value;
+                constexpr int WPL = decltype(wpl)::value, CE = decltype(ce)::value;
                 using X = xs::XLongGeo<WPL>;
                 int rc2;
                 if ((rc2 = ensure(ctx, S_SCR, X::scratch_bytes * nblk, &scratch))) return rc2;
-                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL, CE>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
                 LaunchScope ls(ctx, "k_train_xlong");
-                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL, CE>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_xl_rows, pl->d_tog_ptr, pl->d_xl_tog, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
                                    flag_count, flag_list, C, pl->d_tog256, pl->d_xl_pos, pl->d_xl_time, (unsigned char *)scratch,
@@ -791,7 +791,10 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             using std::true_type;
             using std::integral_constant;
             auto pick_w = [&](auto dqm, auto togp) -> int {
-                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}) : go(dqm, togp, integral_constant<int, 32>{});
+                // (up to 32 768 steps: two chunks of at most 16 384, sorted with sixteen keys per thread instead of twenty-two)
+                if (T <= 2 * xs::LongCfg<8>::TPAD) return go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 8>{});
+                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 11>{})
+                                                   : go(dqm, togp, integral_constant<int, 32>{}, integral_constant<int, 11>{});
             };
             rc = mode == 2 ? (pl->d_tog256 ? pick_w(true_type{}, true_type{}) : pick_w(true_type{}, false_type{}))
                            : (pl->d_tog256 ? pick_w(false_type{}, true_type{}) : pick_w(false_type{}, false_type{}));
@@ -865,15 +868,15 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const unsigned nblk = (unsigned)std::min<int64_t>(C, ctx->n_cu);  // one block per CU (155 KB of LDS), cells walked grid-stride
-            auto go = [&](auto dqm, auto togp, auto wpl) -> int {
+            auto go = [&](auto dqm, auto togp, auto wpl, auto ce) -> int {
                 constexpr bool DQM = decltype(dqm)::value, TOGP = decltype(togp)::value;
-                constexpr int WPL = decltype(wpl)::value;
+                constexpr int WPL = decltype(wpl)::value, CE = decltype(ce)::value;
                 using X = xs::XLongGeo<WPL>;
                 int rc2;
                 if ((rc2 = ensure(ctx, S_SCR, X::scratch_bytes * nblk, &scratch))) return rc2;
-                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL, CE>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
                 LaunchScope ls(ctx, "k_train_xlong");
-                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
+                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL, CE>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
                                    (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_xl_rows, pl->d_tog_ptr, pl->d_xl_tog, G,
                                    (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
                                    flag_count, flag_list, C, pl->d_tog256, pl->d_xl_pos, pl->d_xl_time, (unsigned char *)scratch,
@@ -888,7 +891,10 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             using std::true_type;
             using std::integral_constant;
             auto pick_w = [&](auto dqm, auto togp) -> int {
-                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}) : go(dqm, togp, integral_constant<int, 32>{});
+                // (up to 32 768 steps: two chunks of at most 16 384, sorted with sixteen keys per thread instead of twenty-two)
+                if (T <= 2 * xs::LongCfg<8>::TPAD) return go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 8>{});
+                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 11>{})
+                                                   : go(dqm, togp, integral_constant<int, 32>{}, integral_constant<int, 11>{});
             };
             rc = mode == 2 ? (pl->d_tog256 ? pick_w(true_type{}, true_type{}) : pick_w(true_type{}, false_type{}))
                            : (pl->d_tog256 ? pick_w(false_type{}, true_type{}) : pick_w(false_type{}, false_type{}));

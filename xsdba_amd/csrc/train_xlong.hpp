@@ -210,7 +210,9 @@ __device__ __attribute__((noinline)) void xlong_phase_c(const float *x, int n_ti
                                                           mode, arr, c, af, out_hq, scaling, flag_cell, 0, nostamp);
 }
 
-template <bool DQM, bool TOGP, int WPL>
+// CE: pairs of elements per thread of the chunk sort — 11 (chunks of up to 22 528 steps) or 8 (up to 16 384: series of up to 32 768
+// steps are two such chunks, and their sorts pay for 16 384 places instead of 22 528)
+template <bool DQM, bool TOGP, int WPL, int CE = 11>
 __global__ __launch_bounds__(1024) void k_train_xlong(
     const float *__restrict__ x0, const float *__restrict__ x1, int64_t T, int64_t sc, const int *__restrict__ row_ptr,
     const int *__restrict__ row_sorted, const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, int G,
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(1024) void k_train_xlong(
     const int *__restrict__ pos_of, const int *__restrict__ time_of, unsigned char *__restrict__ gscratch, int debug_phase)
 {
     // (row_sorted, tog_idx, togp: in POSITIONS, see RankGlobal)
-    using L = LongCfg<11>;
+    using L = LongCfg<CE>;
     using X = XLongGeo<WPL>;
     using u64 = unsigned long long;
     constexpr int NT = X::NT;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_train_xlong(
             u64 *S = run_a, *O = run_b;
             for (int j = 0; j < K; j++) {
                 const int base = j * CL, len = min(CL, Ti - base);
-                const int nvj = long_load_sort<11, false>(x + base, len, smem, red, rank_l, nullptr);
+                const int nvj = long_load_sort<CE, false>(x + base, len, smem, red, rank_l, nullptr);
                 // steps without a value are no members: rank 0xFFFF (behind the valid ranks of the chunk's order, among padding steps)
                 if (nvj == 0) {  // (block-uniform; the sort has met at a barrier and left no order)
                     for (int t = tid; t < len; t += NT) rank_g[pos_of[base + t]] = 0xFFFFu;
