@@ -1096,7 +1096,9 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
             if ((rc = check_launch("k_lin2d_build_rows"))) return rc;
             if (cubic) {
                 LaunchScope ls(ctx, "k_lin2d_grad");
-                hipLaunchKernelGGL(xs::k_lin2d_grad, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream, G, Q, nc, (unsigned char *)scratch, L.total);
+                // (node records once the launch is wide enough to be bound by the L2: about a wave per SIMD)
+                hipLaunchKernelGGL(xs::k_lin2d_grad, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, ctx->stream, G, Q, nc, (unsigned char *)scratch, L.total,
+                                   nc >= (int64_t)128 * ctx->n_cu ? 1 : 0);
             }
         }
         if ((rc = check_launch("k_lin2d_build"))) return rc;

@@ -24,7 +24,7 @@ namespace xs {
 
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
-    size_t grad, adjp, adji;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form (build only)
+    size_t grad, adjp, adji, grec;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form, 64-byte node records (build only)
     size_t sofs, sedge, stri;  // strip lists (staged): first entry of every strip, the crossing edges left to right, the triangle right of each
     size_t lock, work, cand;  // k_lin2d_build_rows only: a bid per triangle, the two work lists + their bitmaps, the flips wanted in a round
 };
@@ -32,6 +32,10 @@ struct Lin2DLayout {
 // a flip wanted in a round of k_lin2d_build_rows: its bid and the triangles it writes
 struct Lin2DCand { uint32_t bid; uint16_t t, i, sites[4]; };
 static_assert(sizeof(Lin2DCand) == 16, "one 16-byte record per wanted flip");
+
+// tables up to this many nodes get 64-byte node records for the gradient sweeps (k_lin2d_grad): larger ones — day-of-year tables —
+// are launched a few thousand cells at a time, where the sweeps wait for single reads and the records would only shrink the chunks
+constexpr size_t LIN2D_REC_MAX_NODES = 2048;
 
 // entries of a cell's strip lists (an edge counts once per strip it crosses: about 2.2 per node on tables like the bench's)
 __host__ __device__ inline size_t lin2d_strip_cap(int G, int Q) { return (size_t)4 * (G + 2) * Q; }
@@ -66,6 +70,8 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = f
     o = (o + 7) & ~(size_t)7;
     L.adjp = o; if (cubic) o += sizeof(int) * (N + 2);
     L.adji = o; if (cubic) o += sizeof(uint16_t) * (6 * N + 8);
+    o = (o + 63) & ~(size_t)63;
+    L.grec = o; if (cubic && N <= LIN2D_REC_MAX_NODES) o += 64 * N;  // (small tables only: see k_lin2d_grad)
     o = (o + 15) & ~(size_t)15;
     L.lock = o; o += sizeof(uint32_t) * 2 * N;
     L.work = o; o += sizeof(uint16_t) * 4 * N + 2 * (((2 * N + 31) / 32) * 4);
@@ -404,7 +410,7 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
 
 // cubic: the nodal gradients of the Clough-Tocher interpolant on a finished triangulation, a thread per cell (Gauss-Seidel sweeps
 // in node order: sequential by definition)
-__global__ void k_lin2d_grad(int G, int Q, int64_t C, unsigned char *__restrict__ scratch, size_t stride)
+__global__ void k_lin2d_grad(int G, int Q, int64_t C, unsigned char *__restrict__ scratch, size_t stride, int use_rec)
 {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
@@ -425,7 +431,49 @@ __global__ void k_lin2d_grad(int G, int Q, int64_t C, unsigned char *__restrict_
     int *adjp = reinterpret_cast<int *>(base + L.adjp);
     uint16_t *adji = reinterpret_cast<uint16_t *>(base + L.adji);
     dt_adjacency(d, adjp, adji, d.hnext);
-    dt_gradients(d, reinterpret_cast<const double *>(base + L.pv), adjp, adji, reinterpret_cast<double *>(base + L.grad));
+    if (!use_rec || (size_t)(G + 2) * Q > LIN2D_REC_MAX_NODES) {  // (few cells: the kernel waits for single reads, not for the L2 — the records' two extra passes would only add to it)
+        dt_gradients(d, reinterpret_cast<const double *>(base + L.pv), adjp, adji, reinterpret_cast<double *>(base + L.grad));
+        return;
+    }
+    // dt_gradients (delaunay.hpp) on 64-byte node records (x, y, value, gradient): with a thread per cell every read of a lane is a
+    // sector of its own, and the kernel ran at the L2's bandwidth — coordinates, value and gradient of a neighbour in four arrays
+    // were four or five sectors, the record is one.  Same sweeps, same order, same expressions.
+    const int n = d.n;
+    const double *pv = reinterpret_cast<const double *>(base + L.pv);
+    double *rec = reinterpret_cast<double *>(base + L.grec);
+    for (int i = 0; i < n; i++) { double *r = rec + 8 * (size_t)i; r[0] = d.px[i]; r[1] = d.py[i]; r[2] = pv[i]; r[3] = 0.0; r[4] = 0.0; }
+    for (int iter = 0; iter < 400; iter++) {
+        double err = 0.0;
+        for (int ip = 0; ip < n; ip++) {
+            const int j0 = adjp[ip], j1 = adjp[ip + 1];
+            if (j1 == j0) continue;  // a node outside the triangulation
+            double *me = rec + 8 * (size_t)ip;
+            double Q0 = 0.0, Q1 = 0.0, Q3 = 0.0, s0 = 0.0, s1 = 0.0;
+            const double x1 = me[0], y1 = me[1], f1 = me[2];
+            for (int j = j0; j < j1; j++) {
+                const double *nb = rec + 8 * (size_t)adji[j];
+                const double ex = nb[0] - x1, ey = nb[1] - y1;
+                const double Ln = sqrt(ex * ex + ey * ey), L3 = Ln * Ln * Ln;
+                const double f2 = nb[2];
+                const double df2 = -ex * nb[3] - ey * nb[4];
+                Q0 += 4.0 * ex * ex / L3;
+                Q1 += 4.0 * ex * ey / L3;
+                Q3 += 4.0 * ey * ey / L3;
+                s0 += (6.0 * (f1 - f2) - 2.0 * df2) * ex / L3;
+                s1 += (6.0 * (f1 - f2) - 2.0 * df2) * ey / L3;
+            }
+            const double det = Q0 * Q3 - Q1 * Q1;
+            const double r0 = (Q3 * s0 - Q1 * s1) / det, r1 = (-Q1 * s0 + Q0 * s1) / det;
+            double change = fmax(fabs(me[3] + r0), fabs(me[4] + r1));
+            me[3] = -r0;
+            me[4] = -r1;
+            change /= fmax(1.0, fmax(fabs(r0), fabs(r1)));
+            err = fmax(err, change);
+        }
+        if (err < 1e-6) break;
+    }
+    double *grad = reinterpret_cast<double *>(base + L.grad);
+    for (int i = 0; i < n; i++) { grad[2 * i] = rec[8 * (size_t)i + 3]; grad[2 * i + 1] = rec[8 * (size_t)i + 4]; }
 }
 
 // numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside.
