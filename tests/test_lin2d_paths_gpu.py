@@ -112,3 +112,28 @@ def test_cubic_and_tables_that_take_the_walk(monkeypatch):
     af64, hq64 = af.astype(np.float64), hq.astype(np.float64)
     ref = _run(monkeypatch, "sweep", True, sim.astype(np.float64), af64, hq64, gcoord, newg, "constant", "+")
     _agree(_run(monkeypatch, "rows", False, sim.astype(np.float64), af64, hq64, gcoord, newg, "constant", "+"), ref, what="float64")
+
+
+@pytest.mark.parametrize("spread", [0.02, 0.3, 300.0])
+def test_dense_and_sparse_rows_many_flip_rounds(monkeypatch, spread):
+    """rows much denser than they are apart (nearly every row edge of the strip triangulation is flipped: more flips wanted in the
+    first rounds than the LDS list of wanted flips holds, ~150 rounds) and much sparser (hardly a flip): the row construction
+    against the sweep, and against griddata"""
+    rng = np.random.default_rng(int(spread * 100) + 3)
+    C, T, G, Q = 16, 2000, 12, 20
+    hq = np.sort(280 + spread * rng.standard_normal((C, G, Q)), axis=2).astype(np.float32)
+    af = rng.standard_normal((C, G, Q)).astype(np.float32)
+    sim = (280 + 1.5 * spread * rng.standard_normal((C, T))).astype(np.float32)
+    newg = rng.uniform(0.5, G + 0.5, T)
+    gcoord = np.arange(0, G + 2.0)
+    ref = _run(monkeypatch, "sweep", True, sim, af, hq, gcoord, newg, "nan", "+")
+    got = _run(monkeypatch, "rows", False, sim, af, hq, gcoord, newg, "nan", "+")
+    _agree(got, ref, frac=3e-3, what="rows vs sweep", atol=1e-4)
+    for c in (0, 7):
+        tab_x = np.concatenate([hq[c][-1:], hq[c], hq[c][:1]]).astype(np.float64)
+        tab_v = np.concatenate([af[c][-1:], af[c], af[c][:1]]).astype(np.float64)
+        keep = np.ones_like(tab_x, bool)
+        keep[:, 1:] = tab_x[:, 1:] > tab_x[:, :-1]       # of exactly repeated abscissae the first is kept
+        yy = np.repeat(gcoord[:, None], Q, 1)
+        exp = griddata((tab_x[keep], yy[keep]), tab_v[keep], (sim[c].astype(np.float64), newg), method="linear")
+        _agree(got[c] - sim[c], exp.astype(np.float32), frac=1e-2, what=f"griddata cell {c}", atol=2e-4)
