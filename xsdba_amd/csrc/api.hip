@@ -1054,7 +1054,8 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
     if (getenv("XSDBA_HIP_LIN2D_WALK")) strips = 0;  // (A/B runs: the walk of rounds 1-3)
     void *scratch;
     if ((rc = ensure(ctx, S_SCR, L.total * (size_t)chunk, &scratch))) return rc;
-    const int use_lds = L.staged <= 64 * 1024 ? 1 : 0;
+    const size_t lds_staged = xs::lin2d_lds_staged(L, cubic != 0);
+    const int use_lds = lds_staged <= 64 * 1024 ? 1 : 0;
     void *jrow;  // the row bracket of every time step, shared by all cells
     if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (size_t)T, &jrow))) return rc;
     {
@@ -1063,7 +1064,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
                            (const double *)dgc, G + 2, T, (int *)jrow);
     }
     if ((rc = check_launch("k_lin2d_rows"))) return rc;
-    if (use_lds && (rc = set_lds(xs::k_lin2d_adjust<R, true>, L.staged, ctx, "the triangulated table"))) return rc;
+    if (use_lds && (rc = set_lds(xs::k_lin2d_adjust<R, true>, lds_staged, ctx, "the triangulated table"))) return rc;
     for (int64_t c0 = 0; c0 < C; c0 += chunk) {
         const int64_t nc = std::min<int64_t>(chunk, C - c0);
         // the triangulations: a workgroup per cell (row construction + parallel flips, k_lin2d_build_rows); XSDBA_HIP_LIN2D_BUILD=sweep
@@ -1111,7 +1112,7 @@ int qm_adjust_linear2d_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int6
                                    (int)kind, dtr ? (const R *)dtr + (size_t)c0 * T : (const R *)nullptr,
                                    (R *)o.kernel_dst + (size_t)c0 * T, T, dlk ? (const double *)dlk + (size_t)c0 * T : (const double *)nullptr, cubic);
             };
-            if (use_lds) launch(xs::k_lin2d_adjust<R, true>, L.staged);
+            if (use_lds) launch(xs::k_lin2d_adjust<R, true>, lds_staged);
             else launch(xs::k_lin2d_adjust<R, false>, 0);
         }
         if ((rc = check_launch("k_lin2d_adjust"))) return rc;

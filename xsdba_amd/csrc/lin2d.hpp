@@ -25,6 +25,7 @@ namespace xs {
 struct Lin2DLayout {
     size_t px, py, pv, tv, tn, vt, rowb, hull, meta, gc, hdr, total, staged;  // byte offsets inside a cell's slice; `staged`: bytes the adjust kernel needs
     size_t grad, adjp, adji, grec;  // cubic only: nodal gradients (staged), vertex adjacency in CSR form, 64-byte node records (build only)
+    size_t plane;              // linear only (staged): the interpolant of every triangle as a plane, hdr[3] says whether they stand
     size_t sofs, sedge, stri;  // strip lists (staged): first entry of every strip, the crossing edges left to right, the triangle right of each
     size_t lock, work, cand;  // k_lin2d_build_rows only: a bid per triangle, the two work lists + their bitmaps, the flips wanted in a round
 };
@@ -65,6 +66,8 @@ __host__ __device__ inline Lin2DLayout lin2d_layout(int G, int Q, bool cubic = f
     L.sedge = o; o += 16 * lin2d_strip_cap(G, Q);
     L.stri = o; o += sizeof(uint16_t) * lin2d_strip_cap(G, Q);
     o = (o + 7) & ~(size_t)7;
+    // planes (k_lin2d_build_rows): v = p[2] + p[0] * (x - x_ref) + p[1] * y on triangle t, p = plane + 3 t; plane[6 N] = x_ref
+    L.plane = o; if (!cubic) o += sizeof(double) * (6 * N + 1);
     L.staged = o;
     L.hull = o; o += sizeof(uint16_t) * 4 * N;  // hull ring (3N) + insertion order (N): build only
     o = (o + 7) & ~(size_t)7;
@@ -138,6 +141,7 @@ __global__ void k_lin2d_build(const R *__restrict__ xq, const R *__restrict__ yq
     const int ntri = dt_build(d, ord);
     hdr[1] = ntri;
     hdr[2] = 0;  // no strip lists: the adjustment walks
+    hdr[3] = 0;  // no planes: it evaluates the barycentric form
     uint16_t *vt = reinterpret_cast<uint16_t *>(base + L.vt);
     for (int i = 0; i < n; i++) vt[i] = 0;
     for (int t = 0; t < ntri; t++) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
@@ -333,6 +337,22 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
         for (int i = tid; i < n; i += NT) vt[i] = 0;
         __syncthreads();
         for (int t = tid; t < ntri; t += NT) { vt[d.tv[3 * t]] = (uint16_t)t; vt[d.tv[3 * t + 1]] = (uint16_t)t; vt[d.tv[3 * t + 2]] = (uint16_t)t; }
+        // ---- linear: the interpolant of every triangle as a plane around x_ref (the barycentric form costs the adjustment twelve
+        // LDS reads and two divisions per element; the plane three reads)
+        if (!cubic) {
+            double *plane = reinterpret_cast<double *>(base + L.plane);
+            const double xref = n > 0 ? d.px[0] : 0.0;
+            for (int t = tid; t < ntri; t += NT) {
+                const int a = d.tv[3 * t], b = d.tv[3 * t + 1], c2 = d.tv[3 * t + 2];
+                const double xa = d.px[a], ya = d.py[a], va = pv[a];
+                const double bx = d.px[b] - xa, by = d.py[b] - ya, bv = pv[b] - va;
+                const double cx = d.px[c2] - xa, cy = d.py[c2] - ya, cv = pv[c2] - va;
+                const double det = bx * cy - cx * by;
+                const double gx = (bv * cy - cv * by) / det, gy = (cv * bx - bv * cx) / det;
+                plane[3 * t] = gx; plane[3 * t + 1] = gy; plane[3 * t + 2] = va - gx * (xa - xref) - gy * ya;
+            }
+            if (tid == 0) { plane[6 * N] = xref; hdr[3] = 1; }
+        } else if (tid == 0) hdr[3] = 0;
         // ---- strip lists (strips: the coordinates are float-exact, host-checked): count the edges crossing every strip (a lane per
         // edge), note the strip's left hull edge, then a lane per strip walks from it to the right hull edge — the crossing edges
         // come out in order, each with the triangle on its right
@@ -476,6 +496,9 @@ __global__ void k_lin2d_grad(int G, int Q, int64_t C, unsigned char *__restrict_
     for (int i = 0; i < n; i++) { grad[2 * i] = rec[8 * (size_t)i + 3]; grad[2 * i + 1] = rec[8 * (size_t)i + 4]; }
 }
 
+// bytes of a cell's slice the adjust kernel stages in LDS: everything up to the planes (linear), which only the global path reads
+__host__ __device__ inline size_t lin2d_lds_staged(const Lin2DLayout &L, bool cubic) { return cubic ? L.staged : L.plane; }
+
 // numpy.interp (compiled_base.c) on the G + 2 row coordinates: clamped outside, slope * (x - xp[j]) + fp[j] inside.
 // The bracket j of every time step (xp[j] <= x < xp[j+1]; -1 below the first row, -2 at or above the last, -3 NaN) is the
 // same for all cells: k_lin2d_rows finds it once.
@@ -513,7 +536,7 @@ __device__ __forceinline__ double np_interp_at(int j, double x, const double *xp
 }
 
 // trend != nullptr: the series is detrended with it before the mapping and retrended after (DQM: the caller passes the
-// scaled series).  dynamic LDS: L.staged bytes when use_lds, else 0.
+// scaled series).  dynamic LDS: lin2d_lds_staged() bytes when use_lds, else 0.
 template <typename R, bool USE_LDS>
 __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const double *__restrict__ newg,
                                const int *__restrict__ jrow, int G, int Q, const unsigned char *__restrict__ scratch,
@@ -527,7 +550,7 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         if constexpr (USE_LDS) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(scratch + (size_t)c * stride);
             uint32_t *dst = reinterpret_cast<uint32_t *>(smem);
-            for (size_t i = threadIdx.x; i < L.staged / 4; i += blockDim.x) dst[i] = src[i];
+            for (size_t i = threadIdx.x; i < lin2d_lds_staged(L, cubic != 0) / 4; i += blockDim.x) dst[i] = src[i];
             __syncthreads();
             base = smem;
         } else {
@@ -548,7 +571,11 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
         d.hnext = d.hprev = d.htri = nullptr;
         d.n = hdr[0];
         d.ntri = hdr[1];
-        const bool has_strips = hdr[2] != 0;
+        // (the planes serve the tables that stay in global memory — day-of-year: one sector per element instead of ten; staged in LDS
+        //  with the rest they cost a monthly table a block per CU: 10.5 -> 12.6 ms per 64 800 cells)
+        const bool has_strips = hdr[2] != 0, has_plane = !USE_LDS && !cubic && hdr[3] != 0;
+        const double *plane = reinterpret_cast<const double *>(base + L.plane);
+        const double xref = has_plane ? plane[6 * (size_t)(G + 2) * Q] : 0.0;
         const int *sofs = reinterpret_cast<const int *>(base + L.sofs);
         const float4 *sedge = reinterpret_cast<const float4 *>(base + L.sedge);
         const uint16_t *stri = reinterpret_cast<const uint16_t *>(base + L.stri);
@@ -603,7 +630,9 @@ __global__ void k_lin2d_adjust(const R *__restrict__ sim, int64_t T, int64_t C, 
                     }
                     tri = dt_locate(d, vx, g, hint);
                 }
-                if (tri >= 0) a = (R)(cubic ? dt_eval_ct(d, pv, grad, tri, vx, g) : dt_eval(d, pv, tri, vx, g));
+                if (tri >= 0)
+                    a = (R)(cubic ? dt_eval_ct(d, pv, grad, tri, vx, g)
+                                  : (has_plane ? plane[3 * tri + 2] + plane[3 * tri] * (vx - xref) + plane[3 * tri + 1] * g : dt_eval(d, pv, tri, vx, g)));
                 // nbutils._extrapolate_on_quantiles: below / above the group-interpolated first / last node
                 const double lo = extrap == 0 ? np_interp_at(jr, g, gcoord, meta, 4, G + 2) : 0.0;
                 const double hi = extrap == 0 ? np_interp_at(jr, g, gcoord, meta + 1, 4, G + 2) : 0.0;
