@@ -135,3 +135,35 @@ def test_every_key_width_short_and_long(hip, bits):
         eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, 31, q, "+")
         assert_close(hq, ehq, rtol=0.0, what=f"hist_q bits={bits} T={T}")
         assert_close(af, eaf, rtol=0.0, what=f"af bits={bits} T={T}")
+
+
+def test_partial_year_series_empty_middle_groups(hip):
+    """Day-of-year groups on series that populate part of the year only (and group indexes with -1 gaps): a wave of the
+    three-stream kernel whose MIDDLE group has an empty row still has to apply the toggle lists of the populated groups beside
+    it (train_cell3.hpp: the early list requests sit inside the middle row's loop).  The end of the data is swept over every
+    offset of a wave's 23 groups, from both sides; EQM, DQM and plain quantiles against the oracle, bit for bit."""
+    rng = np.random.default_rng(11)
+    q = ((np.arange(20) + 0.5) / 20).astype(np.float32)
+    C = 2
+    for start, T in [(0, t) for t in range(188, 236, 3)] + [(170, t) for t in range(100, 148, 5)]:
+        gidx = ((np.arange(T) + start) % 365).astype(np.int32)
+        ref = (280 + 5 * rng.standard_normal((C, T))).astype(np.float32)
+        hist = (281 + 4 * rng.standard_normal((C, T))).astype(np.float32)
+        af, hq = hip.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+        assert_close(hq, ehq, rtol=0.0, what=f"hist_q start={start} T={T}")
+        assert_close(af, eaf, rtol=0.0, what=f"af start={start} T={T}")
+    # gaps in the group index: a block of days belongs to no group, its neighbours' windows still reach into it
+    T = 1460
+    gidx = (np.arange(T) % 365).astype(np.int32)
+    gidx[(gidx >= 200) & (gidx < 231)] = -1
+    ref = (280 + 5 * rng.standard_normal((C, T))).astype(np.float32)
+    hist = (281 + 4 * rng.standard_normal((C, T))).astype(np.float32)
+    af, hq = hip.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+    eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+    assert_close(hq, ehq, rtol=0.0, what="hist_q with gaps")
+    assert_close(af, eaf, rtol=0.0, what="af with gaps")
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, 365, 31, q, "+")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, 365, 31, q, "+")
+    assert_close(sc, esc, rtol=2.4e-7, atol=1e-4, what="scaling with gaps")
+    assert_close(hq, ehq, rtol=2.4e-7, atol=1e-4, what="dqm hist_q with gaps")

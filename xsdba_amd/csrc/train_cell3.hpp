@@ -286,7 +286,9 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     {
         const int *l = row_sorted + row_ptr[gb];
         const int len = row_ptr[gb + 1] - row_ptr[gb];
-        early = PADT && len <= 1024 && nA <= 8;  // (wave-uniform)
+        // (wave-uniform; len > 0: the early lists are requested inside the row loop, which an EMPTY middle group — a series that
+        //  covers part of the year only, gaps in the group index — never enters: the lists are then fetched where they are used)
+        early = PADT && len > 0 && len <= 1024 && nA <= 8;
         // 1024 entries per round (all of a day-of-year window's row): their reads are in flight together — one L2 round trip
         // where every wave of the block waits at the same time
         for (int i0 = 0; i0 < len; i0 += 1024) {
