@@ -230,8 +230,11 @@ template <int EPT> struct GroupSumHook {
 // for NaN / padding steps.
 // NR: rounds of the select per group step — a stream's 21 lanes serve quantiles k, k + 21, ... (Q <= 21 NR nodes); everything up
 // to the packed counts is done once per step whatever NR.
-template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false, int NR = 1>
-__device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid,
+// Cfg: the geometry of the vectors (TPAD, WPL, VSTRIDE, NLANE, NWAVE: CellCfg3<EPT>, or train_cell4.hpp's 8-wave blocks);
+// RankT: `const uint16_t *` into the LDS (lists in time steps), or a view of a rank table in global memory indexed by POSITION
+// (train_xlong.hpp: RankGlobal; the row and toggle lists are then in positions too).
+template <typename Cfg, typename RankT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false, int NR = 1>
+__device__ __forceinline__ void cell_group_quantiles3g(const Vals &vals, const RankT rank, uint32_t *bits_all, int nvalid,
                                                       int lane, int wid, const int *__restrict__ row_ptr,
                                                       const int *__restrict__ row_sorted, const int *__restrict__ tog64, int G,
                                                       const typename Vals::value_type *__restrict__ q, int Q, int kind, int mode,
@@ -242,7 +245,6 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
                                                       typename Vals::value_type *hqk = nullptr)
 {
     using R = typename Vals::value_type;
-    using Cfg = CellCfg3<EPT>;
     constexpr int TPAD = Cfg::TPAD, WPL = Cfg::WPL, VS = Cfg::VSTRIDE, NL = Cfg::NLANE, QL = 21;
     wid = __builtin_amdgcn_readfirstlane(wid);  // (wave-uniform, and known to be: the group ranges below live in scalar registers)
     const int gpw = (G + Cfg::NWAVE - 1) / Cfg::NWAVE;
@@ -384,7 +386,10 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     // them the second pass reads the whole hist_q table back (20 % on top of the kernel's algorithmic bytes).  A queue rather than
     // an indexed array (that would live in scratch): pushed at [0] in the first pass, moved up so that step 0 stands at [7],
     // popped from [7] in the second.  More than eight steps per wave (G > 384): the table is read back.
-    const bool keep = NR == 1 && hqk != nullptr && mode != 0 && nA <= 8;  // (wave-uniform)
+#ifndef XS_HQK_KEEP
+#define XS_HQK_KEEP 1
+#endif
+    const bool keep = XS_HQK_KEEP && NR == 1 && hqk != nullptr && mode != 0 && nA <= 8;  // (wave-uniform)
     auto hqk_up = [&]() {
 #pragma unroll
         for (int j = 7; j > 0; j--) hqk[j] = hqk[j - 1];
@@ -679,6 +684,20 @@ __device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const ui
     }
     if (keep && !ref_pass)
         for (int s_ = nA; s_ < 8; s_++) hqk_up();  // step 0 to the head of the queue
+}
+
+template <int EPT, bool P10, bool DQM, typename Vals, bool PRESUM = false, int STOP = 0, bool PADT = false, int NR = 1>
+__device__ __forceinline__ void cell_group_quantiles3(const Vals &vals, const uint16_t *rank, uint32_t *bits_all, int nvalid, int lane, int wid,
+                                                      const int *__restrict__ row_ptr, const int *__restrict__ row_sorted,
+                                                      const int *__restrict__ tog64, int G, const typename Vals::value_type *__restrict__ q, int Q,
+                                                      int kind, int mode, int arr, int64_t c, typename Vals::value_type *__restrict__ af,
+                                                      typename Vals::value_type *out_hq, typename Vals::value_type *scaling, bool &flag_cell,
+                                                      const double *gsum = nullptr, const double *guard = nullptr, int n_time = 0,
+                                                      const uint32_t *lut = nullptr, typename Vals::value_type *hqk = nullptr)
+{
+    cell_group_quantiles3g<CellCfg3<EPT>, const uint16_t *, P10, DQM, Vals, PRESUM, STOP, PADT, NR>(
+        vals, rank, bits_all, nvalid, lane, wid, row_ptr, row_sorted, tog64, G, q, Q, kind, mode, arr, c, af, out_hq, scaling, flag_cell, gsum, guard,
+        n_time, lut, hqk);
 }
 
 template <int EPT, bool P10, bool DQM, int STOP = 0, int NR = 1>
