@@ -5,6 +5,7 @@ that is present, or no MI355X is visible, the calls below raise — there is no 
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import subprocess
@@ -313,12 +314,74 @@ class Context:
 
 
 _default_ctx: dict[int, Context] = {}
+_tls = threading.local()
 
 
 def default_context(device: int | None = None) -> Context:
+    """The context a call without an explicit one runs on: the one bound to this thread by :func:`use_context` (the block
+    workers of ``map_blocks``), else the process's context of ``LOCAL_RANK`` / ``XSDBA_AMD_DEVICE`` (default 0)."""
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", os.environ.get("XSDBA_AMD_DEVICE", "0")))
-        device = device % max(device_count(), 1)
+        bound = getattr(_tls, "ctx", None)
+        if bound is not None:
+            return bound
+        device = _default_device()
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
     return _default_ctx[device]
+
+
+def _default_device() -> int:
+    device = int(os.environ.get("LOCAL_RANK", os.environ.get("XSDBA_AMD_DEVICE", "0")))
+    return device % max(device_count(), 1)
+
+
+@contextlib.contextmanager
+def use_context(ctx: Context):
+    """Bind `ctx` to the calling thread: every library call of the thread that is not given a context runs on it."""
+    prev = getattr(_tls, "ctx", None)
+    _tls.ctx = ctx
+    try:
+        yield ctx
+    finally:
+        _tls.ctx = prev
+
+
+# ---- the node behind the API: one context per device for the cell blocks of map_blocks ---------------------------------------
+_worker_ctx: dict[str, list[Context]] = {}
+
+
+def worker_devices() -> list[int]:
+    """Device ordinals the blocks of a host-backed call are dealt over (the role the dask workers play for the reference,
+    base.py:640-650).  ``XSDBA_AMD_DEVICES`` = ``all`` | ``0,1,...`` (an ordinal may repeat: several contexts on one device);
+    unset: every visible device — unless the process was given ONE device (``LOCAL_RANK`` of a one-process-per-GPU launch,
+    ``XSDBA_AMD_DEVICE``), which it then keeps to."""
+    spec = os.environ.get("XSDBA_AMD_DEVICES", "").strip().lower()
+    n = max(device_count(), 1)
+    if not spec:
+        if "LOCAL_RANK" in os.environ or "XSDBA_AMD_DEVICE" in os.environ:
+            return [_default_device()]
+        spec = "all"
+    if spec == "all":
+        return list(range(n))
+    devs = [int(tok) for tok in spec.split(",") if tok.strip() != ""]
+    for d in devs:
+        if d < 0 or d >= n:
+            raise ValueError(f"XSDBA_AMD_DEVICES names device {d}; {n} visible")
+    return devs or [_default_device()]
+
+
+def worker_contexts() -> list[Context]:
+    """One context per entry of :func:`worker_devices` (created on first use, kept for the process).  The first entry of the
+    process's own device is its default context, so that a one-device run is exactly the plain path."""
+    devs = worker_devices()
+    key = ",".join(map(str, devs))
+    if key not in _worker_ctx:
+        out, seen = [], set()
+        for d in devs:
+            if d not in seen and d == _default_device():
+                out.append(default_context())
+            else:
+                out.append(Context(d))
+            seen.add(d)
+        _worker_ctx[key] = out
+    return _worker_ctx[key]

@@ -51,13 +51,20 @@ def update_history(hist_str: str, *inputs, new_name: str | None = None) -> str:
 
 def _device_resident(da):
     """Large host series are moved to the GPU ONCE, before the adjustment code sees them (labeled.to_device_if_large) —
-    unless they are so large that ``map_blocks`` will cut them into blocks of cells (base.block_budget_bytes): those stay on
-    the host and every block is uploaded on its own."""
+    unless ``map_blocks`` will cut them into blocks of cells: because they are that large (base.block_budget_bytes) or because
+    several devices share the work (_lib.worker_devices): those stay on the host and every block is uploaded on its own, to
+    the device that computes it."""
+    import os
+
+    from ._lib import worker_devices
     from .base import block_budget_bytes
     from .labeled import to_device_if_large
 
-    if getattr(da, "device_data", None) is None and da.values.nbytes > block_budget_bytes() / 3:
-        return da
+    if getattr(da, "device_data", None) is None:
+        if da.values.nbytes > block_budget_bytes() / 3:
+            return da
+        if len(worker_devices()) > 1 and da.values.nbytes >= float(os.environ.get("XSDBA_AMD_MULTI_MIN_MB", "64")) * 2 ** 20 / 3:
+            return da
     return to_device_if_large(da)
 
 

@@ -384,10 +384,14 @@ def block_budget_bytes() -> float:
     return float(os.environ.get("XSDBA_AMD_BLOCK_MAX_MB", "65536")) * 2 ** 20
 
 
-def _plan_blocks(ds, base_dims, keep_whole=()):
-    """(dim, step) when the host-backed variables of `ds` exceed the block budget and can be cut along a dimension the block
-    function neither reduces nor creates — never the grouping dimension (`keep_whole`: ranks, trends and windows need the whole
-    series); None otherwise (device-resident inputs are already where they are used)."""
+def _plan_blocks(ds, base_dims, keep_whole=(), n_workers=1):
+    """(dim, step) when the host-backed variables of `ds` are to be cut along a dimension the block function neither reduces nor
+    creates — never the grouping dimension (`keep_whole`: ranks, trends and windows need the whole series) —: because they
+    exceed the block budget, or because several devices are there to share them (`n_workers` > 1 and at least
+    ``XSDBA_AMD_MULTI_MIN_MB``, default 64, of series: two blocks per device, so that a device's next upload runs under another
+    one's kernels).  None otherwise (device-resident inputs are already where they are used)."""
+    import os
+
     base_dims = [d for d in base_dims if d not in keep_whole]
     variables = list(ds.data_vars.values()) if isinstance(ds, Dataset) else [ds]
     if any(getattr(v, "device_data", None) is not None for v in variables):
@@ -395,15 +399,35 @@ def _plan_blocks(ds, base_dims, keep_whole=()):
     cut = [v for v in variables if any(d in base_dims and v.sizes[d] > 1 for d in v.dims)]
     total = sum(v.values.nbytes for v in cut)
     budget = block_budget_bytes()
-    if not cut or total <= budget:
+    share = n_workers > 1 and total >= float(os.environ.get("XSDBA_AMD_MULTI_MIN_MB", "64")) * 2 ** 20
+    if not cut or (total <= budget and not share):
         return None
     big = max(cut, key=lambda v: v.values.nbytes)
     cands = [d for d in big.dims if d in base_dims and big.sizes[d] > 1]
     # the outermost such dimension: its blocks are contiguous pieces of a C-ordered cube
     dim = cands[0]
     n = big.sizes[dim]
-    step = max(1, int(n * budget // total))
+    step = max(1, int(n * budget // total)) if total > budget else n
+    if share:
+        step = min(step, -(-n // (2 * n_workers)))
     return (dim, step) if step < n else None
+
+
+_block_pools: dict = {}
+
+
+def _block_workers():
+    """(contexts, executors): one single-thread executor per worker context — a context is only ever driven by its own thread
+    (the C ABI: contexts are independent, one context is not re-entrant), ctypes releases the GIL for the length of a call."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ._lib import worker_contexts
+
+    ctxs = worker_contexts()
+    key = tuple(id(c) for c in ctxs)
+    if key not in _block_pools:
+        _block_pools[key] = [ThreadPoolExecutor(max_workers=1, thread_name_prefix=f"xsdba-amd-w{i}-dev{c.device}") for i, c in enumerate(ctxs)]
+    return ctxs, _block_pools[key]
 
 
 def _isel_block(ds, dim, sl):
@@ -471,24 +495,52 @@ def map_blocks(reduces=None, **out_vars):
                 if dim not in kwargs and dim not in in_dims:
                     raise ValueError(f"This function adds the {dim} dimension, its coordinate must be provided as a keyword argument.")
             try:
-                plan = _plan_blocks(ds, base_dims, keep_whole=(group.dim,) if group is not None else ("time",))
+                from ._lib import use_context, worker_devices
+
+                n_workers = len(worker_devices())
+                plan = _plan_blocks(ds, base_dims, keep_whole=(group.dim,) if group is not None else ("time",), n_workers=n_workers)
                 if plan is None:
                     out = as_dataset(func(ds, **kwargs))
                 else:
-                    # inputs larger than the block budget: the non-reduced dimension is cut in blocks, every block is one
-                    # call (uploaded through page-locked pieces, computed, its results brought back), like dask chunks
+                    # inputs larger than the block budget, or several devices to share them: the non-reduced dimension is cut in
+                    # blocks, every block is one call (uploaded through page-locked pieces, computed, its results brought back), like
+                    # dask chunks — dealt round-robin over one context per device (XSDBA_AMD_DEVICES), each driven by its own thread
                     from .labeled import to_device_if_large
 
                     bdim, step = plan
                     n = (ds.sizes if isinstance(ds, Dataset) else ds.sizes)[bdim]
-                    outs = []
-                    for i0 in range(0, n, step):
-                        blk = _isel_block(ds, bdim, slice(i0, min(n, i0 + step)))
-                        blk = (Dataset({k: to_device_if_large(v) for k, v in blk.data_vars.items()}, attrs=blk.attrs)
-                               if isinstance(blk, Dataset) else to_device_if_large(blk))
-                        o = as_dataset(func(blk, **kwargs))
-                        outs.append(Dataset({k: DataArray(np.asarray(v.values), v.dims, v.coords, v.attrs, v.name)
-                                             for k, v in o.data_vars.items()}, attrs=o.attrs))
+
+                    import threading
+
+                    seeds = {"lock": threading.Lock(), "base": None}  # (processing._draw_seed: one base for all blocks)
+
+                    def one_block(i0, ctx=None):
+                        def body():
+                            blk = _isel_block(ds, bdim, slice(i0, min(n, i0 + step)))
+                            blk = (Dataset({k: to_device_if_large(v) for k, v in blk.data_vars.items()}, attrs=blk.attrs)
+                                   if isinstance(blk, Dataset) else to_device_if_large(blk))
+                            o = as_dataset(func(blk, **kwargs))
+                            return Dataset({k: DataArray(np.asarray(v.values), v.dims, v.coords, v.attrs, v.name)
+                                            for k, v in o.data_vars.items()}, attrs=o.attrs)
+
+                        if ctx is None:
+                            return body()
+                        from ._lib import _tls
+
+                        with use_context(ctx):
+                            _tls.seeds = {"shared": seeds, "block": i0 // step, "k": 0}
+                            try:
+                                return body()
+                            finally:
+                                _tls.seeds = None
+
+                    starts = list(range(0, n, step))
+                    if n_workers > 1:
+                        ctxs, pools = _block_workers()
+                        futs = [pools[b % len(pools)].submit(one_block, i0, ctxs[b % len(ctxs)]) for b, i0 in enumerate(starts)]
+                        outs = [f.result() for f in futs]
+                    else:
+                        outs = [one_block(i0) for i0 in starts]
                     out = _concat_blocks(outs, bdim)
                 def _ordered(v):
                     # the template order of the reference (base.py:696-700), for device-resident results too: their transpose is a

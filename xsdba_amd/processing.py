@@ -17,7 +17,24 @@ __all__ = ["adapt_freq", "jitter", "jitter_over_thresh", "jitter_under_thresh"]
 
 
 def _draw_seed() -> int:
-    return int(np.random.randint(0, 2**31 - 1)) * 2654435761 + int(np.random.randint(0, 2**31 - 1))
+    """One seed for the device's counter-based generator, from numpy's global generator.  Inside a block worker of
+    ``map_blocks`` (several devices) the blocks run in threads whose order is not fixed: there ONE base is drawn — by whichever
+    block asks first — and a block's k-th seed is a function of (base, block number, k), so that ``np.random.seed(...)`` still
+    fixes every draw."""
+    from ._lib import _tls
+
+    st = getattr(_tls, "seeds", None)
+    if st is None:
+        return int(np.random.randint(0, 2**31 - 1)) * 2654435761 + int(np.random.randint(0, 2**31 - 1))
+    shared, block = st["shared"], st["block"]
+    with shared["lock"]:
+        if shared["base"] is None:
+            shared["base"] = int(np.random.randint(0, 2**31 - 1)) * 2654435761 + int(np.random.randint(0, 2**31 - 1))
+    k = st["k"]
+    st["k"] = k + 1
+    x = (shared["base"] ^ (block * 0x9E3779B97F4A7C15) ^ (k * 0xC2B2AE3D27D4EB4F)) & 0xFFFFFFFFFFFFFFFF
+    x ^= x >> 33; x = (x * 0xFF51AFD7ED558CCD) & 0xFFFFFFFFFFFFFFFF; x ^= x >> 33   # (a bijective mix: distinct (block, k) -> distinct seeds)
+    return int(x >> 1)
 
 
 def quantity_to_float(q, like: DataArray | None = None, name: str = "threshold") -> float | None:
