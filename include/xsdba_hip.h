@@ -67,12 +67,18 @@ int xsdba_hip_abi_version(void);
 int xsdba_hip_device_count(int *count);
 int xsdba_hip_create(int device, xsdba_hip_ctx **ctx);
 int xsdba_hip_destroy(xsdba_hip_ctx *ctx);
+/* The per-cell sort kernels (train_cell.hpp: stable counting passes on wave-private counter rows) rely on ONE undocumented
+ * hardware property: a returning LDS atomic serves the lanes of an instruction that hit the same word in ascending lane order.
+ * xsdba_hip_create probes it (< 1 ms, csrc/order_probe.hpp; XSDBA_HIP_ATOMIC_ORDER = probe | assume | broken); *ordered = 0
+ * means the probe failed and this context computes everything those kernels would have served with the generic ones
+ * (k_train_rows / k_qdm_adjust: same results, slower) — never a wrong quantile. */
+int xsdba_hip_lane_ordered_atomics(xsdba_hip_ctx *ctx, int *ordered);
 int xsdba_hip_last_error(char *buf, size_t buflen);
 int xsdba_hip_synchronize(xsdba_hip_ctx *ctx);
 /* the hipStream_t every kernel of this context is launched on (for event timing / stream ordering) */
 int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream);
 /* Device buffers owned by the context.  A buffer of >= 1 MiB given back with xsdba_hip_free is parked in a per-context pool
- * (at most XSDBA_HIP_POOL_MB MiB — default: a quarter of the device's memory, at least 16384 —; 0 = hipFree at once) and serves
+ * (at most XSDBA_HIP_POOL_MB MiB — default: a quarter of THIS context's device memory, read at xsdba_hip_create —; 0 = hipFree at once) and serves
  * the next xsdba_hip_malloc of exactly that size without a hipMalloc / stream synchronisation: a train + adjust loop asks for the same tables and series every pass.
  * Reuse is ordered on the context's stream, like everything else the library does with the buffer; work that OTHER streams
  * queued on it must have been waited for before the free (that was already so when free synchronised this stream only).

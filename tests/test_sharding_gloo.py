@@ -96,3 +96,24 @@ def test_token_file_rendezvous_ignores_clocks_and_other_jobs(tmp_path):
     assert got["t"] == other
     with pytest.raises(TimeoutError):
         sh._token_through_file(b"", 1, f, sh._job_nonce("job-c"), 0.2)
+
+
+def test_token_file_rendezvous_needs_a_per_job_id(monkeypatch):
+    """a rendezvous address is not a per-job secret (consecutive jobs share the default port), torchrun's default run id is the
+    constant "none": neither may key the token file — a stale token of a crashed job would be accepted"""
+    from xsdba_amd import sharding as sh
+
+    for var in ("XSDBA_AMD_JOB_ID", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    with pytest.raises(ValueError, match="per-job id"):
+        sh._job_nonce(None)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "none")
+    with pytest.raises(ValueError):
+        sh._job_nonce(None)
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "6f1c0c2e-77aa")
+    a = sh._job_nonce(None)
+    monkeypatch.setenv("XSDBA_AMD_JOB_ID", "slurm-4711")
+    b = sh._job_nonce(None)
+    assert a != b and b == sh._job_nonce("slurm-4711") and len(a) == 16

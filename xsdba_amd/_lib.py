@@ -26,7 +26,7 @@ EXTRAP = {"constant": 0, "nan": 1}
 # every symbol include/xsdba_hip.h declares (checked by tests/test_cabi_symbols.py against the header)
 SYMBOLS = [
     "xsdba_hip_abi_version", "xsdba_hip_device_count", "xsdba_hip_create", "xsdba_hip_destroy",
-    "xsdba_hip_last_error", "xsdba_hip_synchronize", "xsdba_hip_get_stream", "xsdba_hip_malloc", "xsdba_hip_free",
+    "xsdba_hip_last_error", "xsdba_hip_lane_ordered_atomics", "xsdba_hip_synchronize", "xsdba_hip_get_stream", "xsdba_hip_malloc", "xsdba_hip_free",
     "xsdba_hip_memcpy_h2d", "xsdba_hip_memcpy_d2h", "xsdba_hip_memset", "xsdba_hip_host_register",
     "xsdba_hip_host_unregister", "xsdba_hip_memcpy_async", "xsdba_hip_event_record", "xsdba_hip_stream_wait_event", "xsdba_hip_event_synchronize", "xsdba_hip_shard_plan", "xsdba_hip_comm_unique_id", "xsdba_hip_comm_init", "xsdba_hip_comm_info", "xsdba_hip_gather", "xsdba_hip_comm_destroy", "xsdba_hip_profile_enable",
     "xsdba_hip_profile_read", "xsdba_hip_timer_start", "xsdba_hip_timer_stop", "xsdba_hip_quantile_groups",
@@ -263,6 +263,14 @@ class Context:
 
     def synchronize(self):
         check(load().xsdba_hip_synchronize(self.handle), "synchronize")
+
+    @property
+    def lane_ordered_atomics(self) -> bool:
+        """False when the probe of ``xsdba_hip_create`` found returning LDS atomics out of lane order on this device: the
+        per-cell sort kernels are then bypassed (include/xsdba_hip.h)."""
+        v = C.c_int(0)
+        check(load().xsdba_hip_lane_ordered_atomics(self.handle, C.byref(v)), "lane_ordered_atomics")
+        return bool(v.value)
 
     def stream(self) -> int:
         p = C.c_void_p()

@@ -111,7 +111,17 @@ __global__ __launch_bounds__(TM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X
     const int RS = tm_row_stride(Q);
     float *wbase = reinterpret_cast<float *>(smem) + (size_t)wv * tm_wave_floats(Q);  // this wave's strips, then its 64 row flags
     float *xrow = wbase + ((size_t)lane * 2) * RS, *yrow = xrow + RS;                  // this lane's strips
-    int *rowflag = reinterpret_cast<int *>(wbase + (size_t)64 * 2 * RS);
+    volatile int *rowflag = reinterpret_cast<volatile int *>(wbase + (size_t)64 * 2 * RS);
+    // Lanes hand data to OTHER lanes of their wave through the LDS here (a loader lane writes the strips and the flag of other
+    // cells' rows; the lane owning a row reads them).  The hardware serves a wave's LDS accesses in program order, but the
+    // compiler knows nothing of the other lanes: the flag is volatile, and a wave-level fence — every access issued, nothing
+    // moved across — stands between the writes of one side and the reads of the other.
+    auto wave_lds_fence = []() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     // the waves of a block take NEIGHBOURING tiles and the same run of groups: they walk the same time steps at about the same
     // time, so the block's loads of a (time, cell) row are TM_WAVES * 256 contiguous bytes, and neighbouring blocks continue the
     // row (a wave's 30 member rows lie 365 rows apart: locality inside DRAM pages only comes from the neighbours)
@@ -151,7 +161,9 @@ __global__ __launch_bounds__(TM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X
     auto stage = [&](int g) -> bool {  // registers (or global memory) -> the strips; true when this lane's row holds no NaN
         bool has_nan = false;
         if (vec) {
+            wave_lds_fence();  // (the previous group's reads of the strips are done before they are overwritten)
             rowflag[lane] = 0;
+            wave_lds_fence();
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const int slot = i * cpi + slot0;
@@ -168,7 +180,8 @@ __global__ __launch_bounds__(TM_WAVES * 64) __attribute__((amdgpu_waves_per_eu(X
                     if (bad) rowflag[slot] = 1;
                 }
             }
-            has_nan = rowflag[lane] != 0;  // (the LDS serves a wave's accesses in program order)
+            wave_lds_fence();  // (strips and flags of every lane are written before any lane reads its row)
+            has_nan = rowflag[lane] != 0;
         } else {
             for (int k = 0; k < Q; k++) {
                 const float xv = xq[(size_t)g * Q + k], yv = yq[(size_t)g * Q + k];

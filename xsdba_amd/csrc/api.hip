@@ -28,6 +28,7 @@
 #include "train_cell_f64.hpp"
 #include "train_select.hpp"
 #include "preproc.hpp"
+#include "order_probe.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -107,6 +108,10 @@ struct xsdba_hip_ctx {
     hipEvent_t user_ev[16] = {};  // event_record / stream_wait_event slots, created on first use
     int lds_limit = 160 * 1024;
     int n_cu = 256;
+    // the per-cell sorts' stability rests on lane-ordered returning LDS atomics (order_probe.hpp): probed at creation; false
+    // sends their work to the generic kernels
+    bool lane_ordered_atomics = true;
+    size_t pool_cap = 0;   // bytes the pool of freed buffers may hold (set at creation from THIS device's memory)
     void *comm = nullptr;  // ncclComm_t once xsdba_hip_comm_init has run
     int comm_rank = -1, comm_size = 0;
 };
@@ -637,7 +642,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
             return sync_if(ctx, oaf.copy_back || ohq.copy_back || osc.copy_back || !is_device_ptr(x0));
         }
-        fast = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
+        fast = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
         if (fast) {
             void *flags;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -721,7 +726,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         // 11 265 .. 22 528 time steps (e.g. 60 years daily): split sort + merge, train_long.hpp
         const char *force = getenv("XSDBA_HIP_TRAIN");
         const bool fast_long = !fast && mode != 3 && pl->simple && T > 11 * 1024 && T <= xs::LongCfg<11>::TPAD && G > 1 &&
-                               !(force && !strcmp(force, "rows"));
+                               !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
         if (fast_long) {
             void *flags, *scratch;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -761,7 +766,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         }
         // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
         const bool fast_xlong = !fast && mode != 3 && pl->simple && pl->d_xl_pos && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
-                                !(force && !strcmp(force, "rows"));
+                                !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
         if (fast_xlong) {
             void *flags, *scratch;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -806,7 +811,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     if constexpr (std::is_same<R, double>::value) {
         // float64 series: 31-bit range keys + tie repair, train_cell_f64.hpp
         const char *force = getenv("XSDBA_HIP_TRAIN");
-        const bool fast64 = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows"));
+        const bool fast64 = mode != 3 && pl->simple && T <= 11 * 1024 && T >= 64 && !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
         if (fast64) {
             void *flags;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -861,7 +866,7 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
         }
         // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
         const bool fast_xlong = !fast && mode != 3 && pl->simple && pl->d_xl_pos && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
-                                !(force && !strcmp(force, "rows"));
+                                !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
         if (fast_xlong) {
             void *flags, *scratch;
             if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
@@ -1368,7 +1373,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         // sort-based kernel (qdm_cell.hpp): any grouping at O(T log T) per cell instead of O(T * row length)
         const char *force = getenv("XSDBA_HIP_QDM");  // "count" pins the generic kernel (A/B runs, tests)
         fast = interp != XSDBA_INTERP_CUBIC && pl->simple && T <= 11 * 1024 && T >= 64 && G <= xs::QdmCfg<11>::GMAX && (ranks_only || Q <= xs::QdmCfg<11>::QMAX) &&
-               s.st == 1 && !(force && !strcmp(force, "count"));
+               s.st == 1 && !(force && !strcmp(force, "count")) && ctx->lane_ordered_atomics;
         // exact (non-windowed) ranking inside short windowed groups, e.g. 30 members per day of year: counting over
         // 30 values beats the sort (measured 6.8 vs 8.6 ms per 16384 cells); "cell" forces the sort kernel anyway
         if (fast && !(rw || W == 1) && pl->max_mem <= 48 && !(force && !strcmp(force, "cell"))) fast = false;
@@ -1768,7 +1773,43 @@ API int xsdba_hip_create(int device, xsdba_hip_ctx **out)
     if (e != hipSuccess) { delete ctx; return fail((int)e, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
     (void)hipEventCreate(&ctx->t0);
     (void)hipEventCreate(&ctx->t1);
+    {   // the pool of freed buffers: XSDBA_HIP_POOL_MB, else a quarter of THIS device's memory (two passes of a 129 600-cell
+        // shard keep 26 GB of tables and series alive at once; a fixed 16 GiB sent every pass back to hipMalloc / hipFree)
+        const char *e = getenv("XSDBA_HIP_POOL_MB");
+        if (e) {
+            double mb = atof(e);
+            if (!(mb >= 0.0)) mb = 0.0;  // negative or unparsable: no pool
+            if (mb > 1.0e9) mb = 1.0e9;
+            ctx->pool_cap = (size_t)mb << 20;
+        } else {
+            size_t fr = 0, tot = 0;
+            ctx->pool_cap = hipMemGetInfo(&fr, &tot) == hipSuccess ? tot / 4 : (size_t)4096 << 20;
+        }
+    }
+    {   // XSDBA_HIP_ATOMIC_ORDER = probe (default) | assume (skip the probe) | broken (behave as if it had failed: tests)
+        const char *m = getenv("XSDBA_HIP_ATOMIC_ORDER");
+        if (m && !strcmp(m, "broken")) ctx->lane_ordered_atomics = false;
+        else if (!(m && !strcmp(m, "assume"))) {
+            unsigned long long *dbad = nullptr, hbad = ~0ull;
+            if (hipMalloc((void **)&dbad, sizeof hbad) == hipSuccess && hipMemsetAsync(dbad, 0, sizeof hbad, ctx->stream) == hipSuccess) {
+                hipLaunchKernelGGL(xs::k_atomic_order_probe, dim3(16), dim3(1024), 0, ctx->stream, 24, dbad);
+                if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, dbad, sizeof hbad, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                    hipStreamSynchronize(ctx->stream) == hipSuccess)
+                    ctx->lane_ordered_atomics = hbad == 0;
+                else ctx->lane_ordered_atomics = false;
+            } else ctx->lane_ordered_atomics = false;
+            (void)hipGetLastError();
+            if (dbad) (void)hipFree(dbad);
+        }
+    }
     *out = ctx;
+    return 0;
+}
+
+API int xsdba_hip_lane_ordered_atomics(xsdba_hip_ctx *ctx, int *ordered)
+{
+    if (!ctx || !ordered) return fail(XSDBA_E_ARG, "null argument");
+    *ordered = ctx->lane_ordered_atomics ? 1 : 0;
     return 0;
 }
 
@@ -1812,27 +1853,6 @@ API int xsdba_hip_get_stream(xsdba_hip_ctx *ctx, void **stream)
 // next request of exactly that size: a train / adjust loop allocates the same tables and series every pass, and hipFree costs a
 // stream synchronisation each time.  Everything the library does with a buffer is ordered on the context's stream, so a pooled
 // buffer may be handed out again while earlier kernels that used it are still queued.
-static size_t pool_cap_bytes()
-{
-    const char *e = getenv("XSDBA_HIP_POOL_MB");
-    if (!e) {
-        // default: a quarter of the device's memory, at least 16 GiB — two passes of a 129 600-cell shard keep 26 GB of tables
-        // and series alive at once; with a fixed 16 GiB every pass fell back to hipMalloc / hipFree (the API leg of the bench
-        // at a third of the kernel rate)
-        static size_t dflt = 0;
-        if (!dflt) {
-            size_t fr = 0, tot = 0;
-            dflt = (size_t)16384 << 20;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && tot / 4 > dflt) dflt = tot / 4;
-        }
-        return dflt;
-    }
-    double mb = atof(e);
-    if (!(mb >= 0.0)) mb = 0.0;            // negative or unparsable: no pool
-    if (mb > 1.0e9) mb = 1.0e9;
-    return (size_t)mb << 20;
-}
-
 namespace {
 void pool_flush(xsdba_hip_ctx *ctx)
 {
@@ -1875,7 +1895,7 @@ API int xsdba_hip_free(xsdba_hip_ctx *ctx, void *dptr)
     const size_t idx = (size_t)(it - ctx->user_allocs.begin()), n = ctx->user_sizes[idx];
     ctx->user_allocs.erase(it);
     ctx->user_sizes.erase(ctx->user_sizes.begin() + (long)idx);
-    const size_t cap = pool_cap_bytes();
+    const size_t cap = ctx->pool_cap;
     if (n >= ((size_t)1 << 20) && n <= cap) {
         if (ctx->pool_bytes + n > cap) {  // full: the oldest entries make room (sizes that are no longer asked for age out)
             HIP_TRY(hipStreamSynchronize(ctx->stream));

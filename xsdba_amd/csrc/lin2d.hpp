@@ -277,6 +277,7 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
             for (int t = tid; t < ntri; t += NT) cur[t] = (uint16_t)t;  // (up / dn are dead: the link phase is behind a barrier)
             for (int w = tid; w < BW; w += NT) { bcur[w] = 0xFFFFFFFFu; bnxt[w] = 0u; }
             int ncur = ntri;
+            bool settled = false;  // (block-uniform) a round found no edge left to flip: the triangulation is Delaunay
             for (int r = 1; r <= maxr; r++) {
                 if (tid == 0) { sh[2] = 0; sh[3] = 0; }
                 __syncthreads();
@@ -307,7 +308,7 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
                 }
                 __syncthreads();
                 const int nc = min(sh[2], CAP);
-                if (nc == 0) break;  // (block-uniform)
+                if (nc == 0) { settled = true; break; }  // (block-uniform)
                 // (B) the flips that hold every triangle they write; their triangles (a loser: its first) go on the next list
                 for (int k = tid; k < nc; k += NT) {
                     const Lin2DCand cd = cand[k];
@@ -327,6 +328,19 @@ __global__ void k_lin2d_build_rows(const R *__restrict__ xq, const R *__restrict
                 { uint16_t *tl = cur; cur = nxt; nxt = tl; }
                 { uint32_t *tb = bcur; bcur = bnxt; bnxt = tb; }
                 __syncthreads();
+            }
+            if (!settled) {
+                // the rounds ran out with flips still wanted (never seen; a table far denser along its rows than they are apart
+                // could): the triangulation in hand is not known to be Delaunay — the one-thread sweep builds the cell from scratch
+                __syncthreads();
+                if (tid == 0) {
+                    uint16_t *ord = d.htri + N;
+                    if (NR <= 32) dt_sort_order(d, ord);
+                    else for (int i = 0; i < n; i++) ord[i] = (uint16_t)i;
+                    sh[1] = dt_build(d, ord);
+                }
+                __syncthreads();
+                ntri = sh[1];
             }
         }
         __syncthreads();

@@ -50,17 +50,22 @@ def shard_cells(x: np.ndarray, world: int, rank: int, cell_axis: int = 0) -> np.
 
 
 def _job_nonce(job_id) -> bytes:
-    """16 bytes every rank of ONE job derives alike and another job does not: from `job_id`, else from what the launcher
-    shares with all its ranks (XSDBA_AMD_JOB_ID, torchrun's run id, MASTER_ADDR:MASTER_PORT); zeros when nothing is shared"""
+    """16 bytes every rank of ONE job derives alike and NO other job does: from `job_id`, else from XSDBA_AMD_JOB_ID, else from
+    the launcher's run id (TORCHELASTIC_RUN_ID, unless it is torchrun's constant default "none").  Nothing else will do: a
+    rendezvous address (MASTER_ADDR:MASTER_PORT) is the same for consecutive jobs on the default port, and a rank that starts
+    polling before rank 0 has removed a crashed earlier job's file would take that job's dead token and hang in comm_init —
+    so without a per-job id the file path is refused (ValueError) rather than guessed."""
     import hashlib
 
     if job_id is None:
         env = os.environ
-        job_id = env.get("XSDBA_AMD_JOB_ID") or env.get("TORCHELASTIC_RUN_ID")
-        if job_id is None and env.get("MASTER_PORT"):
-            job_id = f"{env.get('MASTER_ADDR', '')}:{env['MASTER_PORT']}"
-    if job_id is None:
-        return bytes(16)
+        job_id = env.get("XSDBA_AMD_JOB_ID")
+        if not job_id:
+            rid = env.get("TORCHELASTIC_RUN_ID")
+            job_id = rid if rid and rid.lower() != "none" else None
+    if job_id is None or str(job_id) == "":
+        raise ValueError("the token-file rendezvous needs a per-job id shared by the ranks: pass job_id=..., or set XSDBA_AMD_JOB_ID "
+                         "(a launcher's unique run id works too), or initialise torch.distributed and let the token travel there")
     return hashlib.sha256(str(job_id).encode()).digest()[:16]
 
 
