@@ -54,7 +54,8 @@ enum { XSDBA_TREND_GIVEN = -1, XSDBA_TREND_GIVEN_ADD = -2, XSDBA_TREND_GIVEN_MUL
 enum {
     XSDBA_E_ARG = -1,          /* bad argument (null pointer, size, dtype, kind, group index out of range) */
     XSDBA_E_NOMEM = -2,        /* host allocation failed */
-    XSDBA_E_UNSUPPORTED = -3,  /* e.g. grouped interp="linear"/"cubic" (Qhull in the reference, utils.py:391-396) */
+    XSDBA_E_UNSUPPORTED = -3,  /* an option this entry point does not serve, e.g. interp = LINEAR on a grouped table through
+                                * xsdba_hip_qm_adjust (the griddata interpolants have their own entries: _qm_adjust_linear2d / _cubic2d) */
     XSDBA_E_DEGREE = -4,       /* PolyDetrend degree outside 0..6 */
     XSDBA_E_ROW_TOO_LONG = -5, /* a group row does not fit the LDS sort (see DESIGN.md limits) */
     XSDBA_E_NO_DEVICE = -6     /* no usable gfx950 device / kernel image */

@@ -676,7 +676,7 @@ def test_errors(hip):
     q = _nodes(5)
     with pytest.raises(XsdbaHipError):  # group index out of range
         hip.quantile_groups(x, np.full(100, 7, np.int32), 4, 1, q)
-    with pytest.raises(XsdbaHipError):  # grouped linear interpolation is not implemented
+    with pytest.raises(XsdbaHipError):  # a grouped table with interp="linear" is xsdba_hip_qm_adjust_linear2d's, not this entry's
         hip.qm_adjust(x, np.zeros((2, 4, 5), np.float32), np.zeros((2, 4, 5), np.float32), np.zeros(100, np.int32), "linear")
     with pytest.raises(TypeError):
         hip.quantile_groups(x.astype(np.int32), None, 1, 1, q)

@@ -173,3 +173,49 @@ def test_adapt_freq_doy_window(cls):
     # about half of sim's dry days were given a wet value before the mapping: the dry-day frequency moved towards ref's
     assert 0.2 < (v < 1).mean() < 0.42
     assert "adapt_freq_thresh='1 mm d-1'" in adj.ds.attrs["adj_params"]
+
+
+@pytest.mark.parametrize("gname,window", [("time.month", 1), ("time.dayofyear", 31)])
+def test_adapt_freq_add_dims_pools_the_members(gname, window):
+    """Grouper(add_dims=["member"]) (reference base.py:413: the extra dimension joins every group's sample; processing.py:46-122
+    run through it): dP0 and pth are ONE value per (cell, group) from the pooled sample, sim_ad keeps the members.  Expected dP0
+    from explicitly gathered pooled blocks (each member's windows, NaN past the ends of ITS series, never a neighbour's)."""
+    rng = np.random.default_rng(3)
+    T, L, M = 4 * 365, 2, 3
+    pr = rng.integers(0, 100, size=(T, L, M)).astype(np.float64)
+    sim_v, ref_v = np.where(pr < 20, pr / 20, pr), np.where(pr < 10, pr / 20, pr)
+    crd = {"time": xs.date_range("2001-01-01", T, "noleap").values, "lat": np.arange(L), "member": np.arange(M)}
+    sim = DataArray(sim_v, ("time", "lat", "member"), crd, {"units": "mm d-1"})
+    ref = DataArray(ref_v, ("time", "lat", "member"), crd, {"units": "mm d-1"})
+    gr = xs.Grouper(gname, window=window, add_dims=["member"])
+    sim_ad, pth, dP0 = adapt_freq(ref, sim, thresh="1 mm d-1", group=gr)
+    assert sim_ad.dims == sim.dims and sim_ad.shape == sim.shape
+    assert pth.dims == ("lat", gr.prop) and dP0.dims == ("lat", gr.prop)
+    month = np.asarray(gr.group_index(sim)[0])
+    h = window // 2
+
+    def pooled_block(x, lat, g):  # every member's windows of the group's days
+        vals = []
+        for m in range(M):
+            for t in np.nonzero(month == g)[0]:
+                for j in range(window):
+                    tt = t + j - h
+                    if 0 <= tt < T:
+                        vals.append(x[tt, lat, m])
+        return np.asarray(vals)
+
+    for lat in range(L):
+        for g in (0, 5, int(month.max())):
+            bs, br = pooled_block(sim_v, lat, g), pooled_block(ref_v, lat, g)
+            p0s, p0r = (bs < 1.0).mean(), (br < 1.0).mean()
+            np.testing.assert_allclose(dP0.values[lat, g], (p0s - p0r) / p0s, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(pth.values, 20, rtol=0.12 if window == 1 else 0.3)
+    keep = sim_v > 20.5 if window == 1 else sim_v > 27
+    np.testing.assert_array_equal(sim_ad.values[keep], sim_v[keep])
+    changed = (sim_ad.values != sim_v)
+    assert changed.any() and (sim_v[changed] <= 1).all() and ((sim_ad.values[changed] > 1) & (sim_ad.values[changed] < (20.1 if window == 1 else 27))).all()
+    # every member takes part: about half of each member's dry days are filled
+    frac = [changed[:, :, m].sum() / (sim_v[:, :, m] <= 1).sum() for m in range(M)]
+    assert min(frac) > 0.3 and max(frac) < 0.7, frac
+    with pytest.raises(NotImplementedError):
+        adapt_freq(ref.isel(member=0), sim, thresh="1 mm d-1", group=gr)

@@ -3,8 +3,9 @@
 qdm_adjust :783-886).  Each is declared through ``map_groups`` / ``map_blocks`` like the reference, but its
 body is ONE call into the HIP library that covers every group of every cell of the block.
 
-Not on the device path (raises NotImplementedError instead of running anything on the CPU): DQM with a grouped
-``interp="cubic"``; the few option combinations refused below say so in their message.
+Nothing here computes on the CPU: the few option combinations that are not on the device path raise NotImplementedError and
+say so in their message (grouped ``interp="linear"`` / ``"cubic"`` ARE on it — utils._interp_on_quantiles_2d's griddata
+interpolants, ``xsdba_hip_qm_adjust_linear2d`` / ``_cubic2d``, for EQM, DQM and QDM alike).
 
 ``Grouper(add_dims=...)`` (base.py:413: the extra dimensions are pooled into every group's sample at training, and into
 the windowed ranks / the detrending fit at adjustment) needs no kernel of its own: the P pooled members of a cell are

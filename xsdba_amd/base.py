@@ -254,15 +254,21 @@ class Grouper(Parametrizable):
             out = np.moveaxis(out, -2, ax)
             return DataArray(out, v.dims + ("window",), v.coords, v.attrs, v.name)
 
+        # the rolling-construct array (W copies of the data) is built ONCE, the groups index into it (it used to be rebuilt for
+        # every group: 365 full copies for a day-of-year grouping)
+        if one is not None:
+            one_w = windows(one)
+        else:
+            ds_w = {k: (windows(v) if self.dim in v.dims else v) for k, v in ds.data_vars.items()}
         pieces, sels = [], []
         for g in range(G):
             sel = np.nonzero(gidx == g)[0]
             if sel.size == 0:
                 continue
             if one is not None:
-                blk = windows(one).isel({self.dim: sel})
+                blk = one_w.isel({self.dim: sel})
             else:
-                blk = Dataset({k: (windows(v).isel({self.dim: sel}) if self.dim in v.dims else v) for k, v in ds.data_vars.items()})
+                blk = Dataset({k: (v.isel({self.dim: sel}) if self.dim in v.dims else v) for k, v in ds_w.items()})
             if isinstance(func, str):
                 res = getattr(blk, func)(dim=dims, **kwargs)
             else:

@@ -94,18 +94,44 @@ def adapt_freq(ref, sim, *, group: Grouper | str, thresh="0 mm d-1"):
     """Adapt frequency of values under thresh of `sim`, in order to match ref (processing.py:46-122, Themeßl et al. 2012).
     Returns (sim_ad, pth, dP0)."""
     ref, sim = as_dataarray(ref), as_dataarray(sim)
-    if group.add_dims:
-        raise NotImplementedError("Grouper(add_dims=...) is not implemented on the HIP path yet")
     th = quantity_to_float(thresh, ref, "thresh")
     dt = np.result_type(ref.dtype, sim.dtype, np.float32)
-    s2, r2, cell_dims, cell_shape = cell_time_pair(sim.astype(dt) if sim.dtype != dt else sim,
-                                                   ref.astype(dt) if ref.dtype != dt else ref, group.dim)
     gidx, G = group.group_index(sim)
-    sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
+    pooled = None
+    if group.add_dims:
+        # base.py:413: the extra dimensions are pooled into every group's sample.  Pure layout (like the training path,
+        # _adjustment._prep_train): the P pooled members of a cell are laid end to end as ONE series, the gaps NaN and in no
+        # group, so that a window never reaches from one member into the next; sim_ad is cut back into members afterwards,
+        # pth and dP0 have no pooled dimension (the reference reduces them with the grouping dimension).
+        from ._adjustment import _Members, _unfold
+
+        ms = _Members(sim.astype(dt) if sim.dtype != dt else sim, group, dt)
+        if not ms.pooled:
+            raise ValueError("`add_dims` argument needs to be a dimension in one of the input datasets.")
+        r_ = ref.astype(dt) if ref.dtype != dt else ref
+        if set(r_.dims) != set(ms.da.dims):
+            raise NotImplementedError("adapt_freq with `add_dims` present in only one of ref / sim is not implemented on the HIP "
+                                      "path (the kernel walks sim and ref on one time axis)")
+        mr = _Members(r_.transpose(*ms.da.dims), group, dt)
+        if mr.x3.shape != ms.x3.shape:
+            raise ValueError("ref and sim must have the same sizes along the pooled and the cell dimensions")
+        s2, g2 = ms.folded(gidx, group.window)
+        r2, _ = mr.folded(gidx, group.window)
+        sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, g2, G, group.window, th, seed=_draw_seed())
+        cell_dims, cell_shape = ms.cell_dims, ms.cell_shape
+        pooled = ms
+    else:
+        s2, r2, cell_dims, cell_shape = cell_time_pair(sim.astype(dt) if sim.dtype != dt else sim,
+                                                       ref.astype(dt) if ref.dtype != dt else ref, group.dim)
+        sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
     attrs = dict(sim.attrs)
     attrs["references"] = ("Themeßl et al. (2012), Empirical-statistical downscaling and error correction of regional climate "
                            "models and its impact on the climate change signal, Climatic Change, DOI 10.1007/s10584-011-0224-4.")
-    out = _series(sim, sim_ad, cell_dims, cell_shape, group.dim, attrs)
+    if pooled is not None:
+        full = np.asarray(_unfold(np.asarray(sim_ad), pooled.P, pooled.T)).reshape(pooled.cell_shape + pooled.pool_shape + (pooled.T,))
+        out = DataArray(full, pooled.da.dims, pooled.da.coords, attrs, sim.name).transpose(*sim.dims)
+    else:
+        out = _series(sim, sim_ad, cell_dims, cell_shape, group.dim, attrs)
     prop = group.prop
     crd = group.get_coordinate(sim)
     coords = {k: c for k, c in sim.coords.items() if k in cell_dims}
