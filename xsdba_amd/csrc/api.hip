@@ -29,6 +29,7 @@
 #include "train_select.hpp"
 #include "preproc.hpp"
 #include "order_probe.hpp"
+#include "train_bigrows.hpp"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -581,11 +582,58 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
     if ((rc = stage_out(ctx, S_TAB2, scaling, (size_t)C * G * sizeof(R), &osc))) return rc;
 
     // generic (cell, group)-row kernel; `cells` (device list of n_list cell ids) restricts it to a subset
+    // rows that do not fit the LDS sort (hourly series under group="time": 262 800 values): the same pipeline on rows kept in
+    // global memory, a batch of rows at a time (train_bigrows.hpp)
+    auto launch_rows_big = [&](int P) -> int {
+        const int64_t nrows = mode == 3 ? C : (int64_t)C * G;
+        const size_t row_bytes = (size_t)P * sizeof(U);
+        const int tiles = P / xs::BIG_TILE;
+        int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / row_bytes));
+        batch = std::min<int64_t>({batch, nrows, (int64_t)((1ll << 30) / tiles)});
+        const size_t off_nv = ((size_t)batch * row_bytes + 255) & ~(size_t)255;
+        const size_t off_mu = (off_nv + (size_t)batch * sizeof(int) + 255) & ~(size_t)255;
+        const size_t off_rq = (off_mu + 2 * (size_t)batch * sizeof(R) + 255) & ~(size_t)255;
+        void *scr;
+        int rc2;
+        if ((rc2 = ensure(ctx, S_SCR, off_rq + (size_t)batch * Q * sizeof(R), &scr))) return rc2;
+        U *keys = (U *)scr;
+        int *nvd = (int *)((unsigned char *)scr + off_nv);
+        R *mu_ref = (R *)((unsigned char *)scr + off_mu), *mu_hist = mu_ref + batch;
+        R *refq = (R *)((unsigned char *)scr + off_rq);
+        const size_t lds_tile = (size_t)xs::BIG_TILE * sizeof(U);
+        if ((rc2 = set_lds(xs::k_big_local<U>, lds_tile, ctx, "a tile of the row sort"))) return rc2;
+        const int npass = (mode == 0 || mode == 3) ? 1 : 2;
+        for (int64_t row0 = 0; row0 < nrows; row0 += batch) {
+            const int64_t nb = std::min<int64_t>(batch, nrows - row0);
+            for (int pass = 0; pass < npass; pass++) {
+                const SeriesIn &sx = pass == 0 ? s0 : s1;
+                LaunchScope ls(ctx, "k_train_rows_big");
+                hipLaunchKernelGGL(xs::k_big_fill<R>, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, (const R *)sx.dev, sx.st, sx.sc, pl->d_row_ptr,
+                                   pl->d_row_idx, mode == 3 ? 1 : G, row0, P, (int)kind, mode == 2 ? 1 : 0, keys, nvd, pass == 0 ? mu_ref : mu_hist);
+                hipLaunchKernelGGL(xs::k_big_local<U>, dim3((unsigned)(nb * tiles)), dim3(1024), lds_tile, ctx->stream, keys, P, 0);
+                const int64_t npairs = nb * (int64_t)(P / 2);
+                for (int k = 2 * xs::BIG_TILE; k <= P && k > 0; k <<= 1) {
+                    for (int j = k >> 1; j >= xs::BIG_TILE; j >>= 1)
+                        hipLaunchKernelGGL(xs::k_big_step<U>, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, keys, P, k, j, npairs);
+                    hipLaunchKernelGGL(xs::k_big_local<U>, dim3((unsigned)(nb * tiles)), dim3(1024), lds_tile, ctx->stream, keys, P, k);
+                }
+                hipLaunchKernelGGL(xs::k_big_quant<R>, dim3((unsigned)nb), dim3(64), 0, ctx->stream, (const U *)keys, (const int *)nvd, P,
+                                   mode == 3 ? 1 : G, row0, (const R *)dq, Q, (int)kind, mode, pass, (R *)oaf.dev, (R *)ohq.dev, (R *)osc.dev, refq,
+                                   (const R *)mu_ref, (const R *)mu_hist);
+                if ((rc2 = check_launch("k_train_rows_big"))) return rc2;
+            }
+        }
+        return 0;
+    };
     auto launch_rows = [&](const int *cells, const int *n_cells_dev, int64_t n_blocks_or_cells) -> int {
         int P = 2;
         while (P < pl->max_row) P <<= 1;
         int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
         size_t lds = sizeof(double) * (2 * (size_t)(NT / 64) + 2) + (size_t)P * sizeof(U) + (size_t)Q * sizeof(R);
+        if (lds > (size_t)ctx->lds_limit && P >= 2 * xs::BIG_TILE) {
+            if (cells) return fail(XSDBA_E_UNSUPPORTED, "internal: a per-cell kernel flagged cells of a grouping whose rows exceed the LDS");
+            return launch_rows_big(P);
+        }
         int rc2;
         if ((rc2 = set_lds(xs::k_train_rows<R>, lds, ctx, "the row sort"))) return rc2;
         LaunchScope ls(ctx, "k_train_rows");
@@ -1152,7 +1200,24 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     int rc;
     // regression layout: a lane per group when there are many short groups (day-of-year), else a half-wave per group
     const int lane_per_group = (pl->G >= 128 && pl->max_mem <= 256) ? 1 : 0;
-    if (m_lds && lds2 <= (size_t)ctx->lds_limit) {
+    if (lds1 > (size_t)ctx->lds_limit) {
+        // the series does not fit the LDS (hourly data): the kernel reads it from global memory (k_group_trend<XG>), the window
+        // means go through the trend buffer
+        if (!trend_cm) return fail(XSDBA_E_ARG, "internal: the long-series trend kernel needs the trend buffer");
+        const bool mt64 = !pl->d_mem_t32 && pl->d_mem_t64;
+        const size_t ldsx = lds1 - (size_t)T * sizeof(R) + (size_t)pl->G * sizeof(R) + 16;
+        auto launch = [&](auto kernel) -> int {
+            int rc2;
+            if ((rc2 = set_lds(kernel, ldsx, ctx, "the detrending coefficients"))) return rc2;
+            LaunchScope ls(ctx, "k_group_trend");
+            hipLaunchKernelGGL(kernel, dim3((unsigned)C), dim3(1024), ldsx, ctx->stream,
+                               (const R *)s.dev, T, s.st, s.sc, scaling, pl->G, (int)kind, pl->d_gidx, pl->W, pl->d_mem_ptr,
+                               pl->d_mem_idx, d_tnum, degree, trend_cm, lane_per_group, preserve_mean, min_periods, tn_affine, tn0, tnd,
+                               mt64 ? pl->d_mem_t64 : pl->d_mem_t32, coef_out);
+            return 0;
+        };
+        if ((rc = mt64 ? launch(xs::k_group_trend<R, false, true, true>) : launch(xs::k_group_trend<R, false, false, true>))) return rc;
+    } else if (m_lds && lds2 <= (size_t)ctx->lds_limit) {
         if ((rc = set_lds(xs::k_group_trend<R, true>, lds2, ctx, "the detrending series"))) return rc;
         LaunchScope ls(ctx, "k_group_trend");
         hipLaunchKernelGGL((xs::k_group_trend<R, true>), dim3((unsigned)C), dim3(nthr), lds2, ctx->stream,
@@ -1213,7 +1278,8 @@ int dqm_adjust_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, i
         const size_t tab_c = ((xs::tab_lds_bytes<R>(G, Q) + 15) & ~(size_t)15) + (size_t)3 * G * sizeof(double) + (((size_t)G * sizeof(float) + 15) & ~(size_t)15);
         // (series long enough for the trend kernel to park its window means in the trend buffer keep the array)
         const unsigned tthr = (!getenv("XSDBA_HIP_TREND_THREADS") && T > xs::TREND_CH * 512 && T <= xs::TREND_CH * 1024) ? 1024u : trend_threads();  // as launch_trend
-        const bool means_in_regs = pl->W == 1 || T <= (int64_t)xs::TREND_CH * tthr;
+        const bool means_in_regs = (pl->W == 1 || T <= (int64_t)xs::TREND_CH * tthr) &&
+                                   (size_t)T * sizeof(R) + 16384 < (size_t)ctx->lds_limit;  // (a series beyond the LDS: the trend kernel needs the buffer)
         if (!trend && degree <= 1 && means_in_regs && tab_c <= (size_t)ctx->lds_limit && !getenv("XSDBA_HIP_TREND_ARRAY")) {
             void *cbuf;
             if ((rc = ensure(ctx, S_CM2, (size_t)C * G * 3 * sizeof(double), &cbuf))) return rc;
@@ -1303,12 +1369,14 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
     // short ranking rows (exact day-of-year groups) are sorted once per cell instead of counted per element
     const int max_rank_row = rw ? pl->max_row : pl->max_mem;
     int sort_w = getenv("XSDBA_HIP_QDM_NOSORT") ? 0 : (max_rank_row <= 32 ? 32 : (max_rank_row <= 64 ? 64 : 0));
-    auto base_bytes = [&](int sw) {
-        return ((sizeof(double) * 3 * (size_t)G + 15) & ~(size_t)15) + (((size_t)T * sizeof(R) + 15) & ~(size_t)15) +
+    auto base_bytes = [&](int sw, bool xg_) {
+        return ((sizeof(double) * 3 * (size_t)G + 15) & ~(size_t)15) + (xg_ ? 0 : (((size_t)T * sizeof(R) + 15) & ~(size_t)15)) +
                (sw ? (size_t)G * (sw + 1) * sizeof(typename xs::KeyOf<R>::U) : 0);
     };
-    if (sort_w && base_bytes(sort_w) > (size_t)ctx->lds_limit) sort_w = 0;  // the sorted rows do not fit next to the series
-    const size_t base = base_bytes(sort_w);
+    // a series beyond the LDS (hourly data): the generic kernel reads it from global memory in place (k_qdm_adjust<XG>)
+    const bool xg = base_bytes(0, false) > (size_t)ctx->lds_limit;
+    if (sort_w && base_bytes(sort_w, xg) > (size_t)ctx->lds_limit) sort_w = 0;  // the sorted rows do not fit next to the series
+    const size_t base = base_bytes(sort_w, xg);
     // generic kernel; `cells`: only the listed cells, count read on the device.  Every block owns a slice of global
     // scratch for a full-layout table (cells with NaN factors; all cells when the LDS cannot hold the table).
     auto launch_generic = [&](const int *cells, const int *n_cells_dev, int64_t n_blocks) -> int {
@@ -1316,21 +1384,21 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
         const unsigned nblk = (unsigned)std::min<int64_t>(n_blocks, 1024);
         void *scratch = nullptr;
         if (tab && (rc2 = ensure(ctx, S_SCR, tab * nblk, &scratch))) return rc2;
-        if (base + tab_sh <= (size_t)ctx->lds_limit) {
-            if ((rc2 = set_lds(xs::k_qdm_adjust<R, true>, base + tab_sh, ctx, "the ranking series + factor table"))) return rc2;
+        auto go = [&](auto kernel, size_t lds, const char *what) -> int {
+            int rc3;
+            if ((rc3 = set_lds(kernel, lds, ctx, what))) return rc3;
             LaunchScope ls(ctx, "k_qdm_adjust");
-            hipLaunchKernelGGL((xs::k_qdm_adjust<R, true>), dim3(nblk), dim3(qdm_threads()), base + tab_sh, ctx->stream,
+            hipLaunchKernelGGL(kernel, dim3(nblk), dim3(qdm_threads()), lds, ctx->stream,
                                (const R *)s.dev, T, C, s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp,
                                extrap, (int)kind, (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T,
                                (unsigned char *)scratch, tab, cells, n_cells_dev, sort_w);
-        } else {
-            if ((rc2 = set_lds(xs::k_qdm_adjust<R, false>, base, ctx, "the ranking series"))) return rc2;
-            LaunchScope ls(ctx, "k_qdm_adjust");
-            hipLaunchKernelGGL((xs::k_qdm_adjust<R, false>), dim3(nblk), dim3(qdm_threads()), base, ctx->stream, (const R *)s.dev, T, C,
-                               s.st, s.sc, (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, gp, gi, interp, extrap, (int)kind,
-                               (R *)o.kernel_dst, (double *)oq.kernel_dst, (int64_t)1, T, (unsigned char *)scratch, tab, cells,
-                               n_cells_dev, sort_w);
-        }
+            return 0;
+        };
+        if (base + tab_sh <= (size_t)ctx->lds_limit)
+            rc2 = xg ? go(xs::k_qdm_adjust<R, true, true>, base + tab_sh, "the factor table") : go(xs::k_qdm_adjust<R, true, false>, base + tab_sh, "the ranking series + factor table");
+        else
+            rc2 = xg ? go(xs::k_qdm_adjust<R, false, true>, base, "the group statistics") : go(xs::k_qdm_adjust<R, false, false>, base, "the ranking series");
+        if (rc2) return rc2;
         return check_launch("k_qdm_adjust");
     };
     bool fast = false;

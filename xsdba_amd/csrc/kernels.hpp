@@ -511,7 +511,10 @@ __device__ __forceinline__ void poly_solve(const double *S, const double *B, int
 // normal case for float32; float64 series that do not fit keep them in global memory.
 // MT64: the packed member table has 32 words per group (groups of 33 .. 64 members: 60 years of a day of the year) instead of 16 —
 // an instantiation of its own, so that its 32 more registers do not cost the usual one (<= 32 members) its third block per CU
-template <typename R, bool M_LDS, bool MT64 = false>
+// XG (series too long for the LDS: hourly data): nothing of size T lives on chip — the (scaled) series is read from global
+// memory wherever the LDS copy would be (its window sums re-derive the scaling per element), the window means go to the trend
+// buffer; requires the trend buffer (trend_cm) even when only the coefficients are asked for.
+template <typename R, bool M_LDS, bool MT64 = false, bool XG = false>
 __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, int64_t sc,
                               const R *__restrict__ scaling, int G, int kind, const int *__restrict__ gidx, int W,
                               const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,
@@ -536,20 +539,36 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     // (the scratch exists only when half-waves share groups — 2 G <= half-waves per block, the host sizes the LDS by the same rule —:
     //  1.3 KB more would cost the day-of-year case its third block per CU)
     double *rcp = part + (2 * G <= (int)(blockDim.x >> 5) ? TREND_SCRATCH_D : 0);  // [W+1] correctly rounded reciprocals of the possible window counts
-    R *xs = reinterpret_cast<R *>(rcp + W + 1);
+    R *xs_l = reinterpret_cast<R *>(rcp + W + 1);
     const int64_t c = blockIdx.x;
     const R *x = sim + c * sc;
     R *tr_out = trend_cm + (size_t)c * T;
     for (int i = threadIdx.x; i <= W; i += blockDim.x) rcp[i] = i ? 1.0 / (double)i : 0.0;
-    R *m = M_LDS ? xs + T : tr_out;
+    R *m = M_LDS ? xs_l + T : tr_out;
+    // the cell's scaling factors wait in LDS; XG: behind the coefficient area (they are needed for as long as the series is read)
+    R *scl_x = reinterpret_cast<R *>(rcp + W + 1);
+    // the scaled series: the LDS copy, or (XG) straight from global memory
+    struct XsView {
+        R *l; const R *x; const R *scl; const int *gidx; int64_t st; int kind;
+        __device__ __forceinline__ R operator[](int64_t t) const
+        {
+            if constexpr (!XG) return l[t];
+            else {
+                R w = x[t * st];
+                if (scl) { const int g = gidx[t]; w = apply_corr<R>(w, g >= 0 ? scl[g] : nan_of<R>(), kind); }
+                return w;
+            }
+        }
+    };
+    const XsView xs{xs_l, x, (XG && scaling) ? scl_x : nullptr, gidx, st, kind};
     // the cell's scaling factors wait in LDS (in the coefficient area, which is written much later): the load below then has one
     // global round trip per batch — value and group — instead of a dependent second one for the factor of that group
-    R *scl = reinterpret_cast<R *>(coef);
+    R *scl = XG ? scl_x : reinterpret_cast<R *>(coef);
     if (scaling) {
         for (int i = threadIdx.x; i < G; i += blockDim.x) scl[i] = scaling[(size_t)c * G + i];
         __syncthreads();
     }
-    {
+    if constexpr (!XG) {
         constexpr int NB = 8;  // NB series values (and their groups) are requested before the first is consumed
         for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
             R v[NB];
@@ -566,7 +585,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
                 if (t < T) {
                     R w = v[k];
                     if (scaling) w = apply_corr<R>(w, gg[k] >= 0 ? scl[gg[k]] : nan_of<R>(), kind);
-                    xs[t] = w;
+                    xs_l[t] = w;
                 }
             }
         }
@@ -580,7 +599,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     // thread the means are held in registers and written back over the series in place (no second array, no
     // global round trip); longer series park them in the trend buffer.
     constexpr int CH = TREND_CH;  // (odd: the threads of a wave read their chunks CH dwords apart — 24 put eight lanes on every LDS bank)
-    const bool inplace = !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
+    const bool inplace = !XG && !M_LDS && W > 1 && T <= (int64_t)CH * blockDim.x;
     auto mean_of = [&](double s, int n) {
         double mv = __builtin_nan("");
         if (n && n >= min_periods) {
@@ -610,7 +629,10 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         }
     };
     if (W == 1) {
-        m = xs;  // the "window mean" is the series itself
+        if constexpr (XG) {  // the "window mean" is the series itself: written out where the regression will read it
+            for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = xs[t];
+            m = tr_out;
+        } else m = xs_l;
     } else if (inplace) {
         const int64_t t0 = (int64_t)threadIdx.x * CH;
         R mreg[CH];
@@ -622,8 +644,8 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
         }
         __syncthreads();  // every window has been read: the series can be overwritten by its window means
 #pragma unroll
-        for (int k = 0; k < CH; k++) if (t0 + k < T) xs[t0 + k] = mreg[k];
-        m = xs;
+        for (int k = 0; k < CH; k++) if (t0 + k < T) xs_l[t0 + k] = mreg[k];
+        m = xs_l;
     } else {
         const int64_t chunk = (T + blockDim.x - 1) / blockDim.x;
         const int64_t t0 = (int64_t)threadIdx.x * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
@@ -632,7 +654,7 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
     }
     __syncthreads();
     if (min_periods > 0) {
-        if (W == 1) { for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = xs[t]; }  // a window of one step
+        if (W == 1) { if (m != tr_out) for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = xs[t]; }  // a window of one step
         else if (m != tr_out) { for (int64_t t = threadIdx.x; t < T; t += blockDim.x) tr_out[t] = m[t]; }
         return;
     }
@@ -869,7 +891,9 @@ __global__ void k_group_trend(const R *__restrict__ sim, int64_t T, int64_t st, 
 // one row per sort_w lanes, bitonic network on the cross-lane path — and every element then finds its rank by two
 // bisections in its row; sort_w == 0 ranks by counting over the row (any length).
 // ---------------------------------------------------------------------------------------------
-template <typename R, bool TAB_LDS>
+// XG (series too long for the LDS): the ranking series is read from global memory in place (cell-major input, st == 1: the
+// host lays anything else out first); nothing of size T lives on chip.
+template <typename R, bool TAB_LDS, bool XG = false>
 __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, int64_t st, int64_t sc,
                              const R *__restrict__ af, const R *__restrict__ quantiles, int G, int Q,
                              const int *__restrict__ gidx, const int *__restrict__ grp_ptr,
@@ -891,7 +915,7 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
     double *gstat = reinterpret_cast<double *>(p);  // per group: N valid, pmin, pmax of the percent-rank rescaling
     p += ((sizeof(double) * 3 * (size_t)G) + 15) & ~(size_t)15;
     R *xs = reinterpret_cast<R *>(p);
-    p += (((size_t)T * sizeof(R)) + 15) & ~(size_t)15;
+    if (!XG) p += (((size_t)T * sizeof(R)) + 15) & ~(size_t)15;
     U *gs = reinterpret_cast<U *>(p);  // sorted keys of every ranking row, row stride sort_w + 1 (odd: no bank conflicts)
     const int gstr = sort_w + 1;
   // cell_list (device list of *n_list_dev cell ids): redo only those cells (the fallback of k_qdm_cell)
@@ -909,7 +933,8 @@ __global__ void k_qdm_adjust(const R *__restrict__ sim, int64_t T, int64_t C, in
         if (tab_global) { ctg = tab_stage<R>(tlg, quantiles, 0, af + (size_t)c * G * Q, G, Q); tab_spline<R>(ctg, tlg, interp); }
     }
     const R *x = sim + c * sc;
-    {
+    if constexpr (XG) xs = const_cast<R *>(x);  // (read-only from here on)
+    else {
         constexpr int NB = 8;  // the whole series is requested in batches of NB loads per thread
         for (int64_t t0 = threadIdx.x; t0 < T; t0 += (int64_t)NB * blockDim.x) {
             R v[NB];
