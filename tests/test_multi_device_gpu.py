@@ -87,6 +87,17 @@ def test_two_contexts_equal_one(monkeypatch, clsname, train_kw, kind, adj_kw, di
     assert {i for i, _, _ in seen} == {id(c) for c in ctxs}, seen              # both contexts worked ...
     assert len({t for _, _, t in seen}) == 2 and threading.current_thread().name not in {t for _, _, t in seen}  # ... each on its own thread
     assert len(seen) >= 8                                                       # two blocks per context for train, and for adjust
+    if min_mb == "0" and dims[-1] == "time":  # (blocks of a (time, lat, lon) cube are strided host slices: they take the plain path)
+        # the blocks' results stay on the device that computed them: the trained tables are sharded over the two contexts, and
+        # every block of the adjustment ran on the context that holds its tables
+        from xsdba_amd.labeled import ShardedDataArray
+
+        af = obj2.ds["af"]
+        assert isinstance(af, ShardedDataArray) and af.part_dim == "lat" and len(af.parts) == 4
+        owners = [p.device_data.ctx for _, _, p in af.parts]
+        assert {id(c) for c in owners} == {id(c) for c in ctxs}
+        adj_calls = seen[len(af.parts):][:len(af.parts)]
+        assert [i for i, _, _ in adj_calls] == [id(c) for c in owners], (adj_calls, owners)
     for name in obj1.ds.data_vars:
         a, b = obj1.ds[name], obj2.ds[name]
         assert a.dims == b.dims

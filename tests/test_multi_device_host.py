@@ -43,17 +43,39 @@ def test_plan_blocks_shares_cells_over_workers(monkeypatch, dims, shape):
     monkeypatch.setenv("XSDBA_AMD_MULTI_MIN_MB", "0")
     ds = Dataset({"ref": _cube(shape, dims), "hist": _cube(shape, dims)})
     assert base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=1) is None
-    dim, step = base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=4)
-    assert dim == "lat" and -(-40 // step) >= 8               # never the grouping dimension; two blocks per device
-    assert sum(min(step, 40 - i0) for i0 in range(0, 40, step)) == 40
+    dim, bounds, ctxs, keep = base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=4)
+    assert dim == "lat" and len(bounds) >= 8                   # never the grouping dimension; two blocks per device
+    assert bounds[0][0] == 0 and bounds[-1][1] == 40 and all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+    assert ctxs is None and keep                               # dealt round-robin; the results stay on their devices
     # too small to be worth a second device
     monkeypatch.setenv("XSDBA_AMD_MULTI_MIN_MB", "64")
     assert base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=4) is None
     # a budget smaller than a device's share still rules
     monkeypatch.setenv("XSDBA_AMD_MULTI_MIN_MB", "0")
     monkeypatch.setenv("XSDBA_AMD_BLOCK_MAX_MB", str(2 * 40 * 30 * 365 * 4 / 2 ** 20 / 20))
-    dim, step = base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=2)
-    assert dim == "lat" and step == 2
+    dim, bounds, ctxs, keep = base._plan_blocks(ds, ["lat", "lon", "time"], keep_whole=("time",), n_workers=2)
+    assert dim == "lat" and bounds[0] == (0, 2) and len(bounds) == 20 and not keep   # (over the budget: results come back to the host)
+
+
+def test_sharded_array_is_lazy_and_plans_its_own_blocks():
+    """labeled.ShardedDataArray: per-block parts laid end to end; `values` gathers, one part is handed over untouched, relabelling
+    is lazy; a dataset holding one is cut along ITS parts."""
+    from xsdba_amd.labeled import ShardedDataArray
+
+    a = np.arange(40 * 6, dtype=np.float32).reshape(40, 6)
+    parts = [DataArray(a[i:j], ("lat", "q"), {"lat": np.arange(i, j)}) for i, j in ((0, 16), (16, 30), (30, 40))]
+    sh = ShardedDataArray(parts, "lat", name="af")
+    assert sh.shape == (40, 6) and sh.dtype == np.float32 and sh.device_data is None
+    assert sh.isel(lat=slice(16, 30)).values.base is parts[1].values.base or np.shares_memory(sh.isel(lat=slice(16, 30)).values, a)
+    np.testing.assert_array_equal(sh.coords["lat"].values, np.arange(40))
+    np.testing.assert_array_equal(sh.transpose("q", "lat").values, a.T)
+    assert sh.rename({"lat": "y"}).part_dim == "y"
+    np.testing.assert_array_equal(sh.isel(lat=slice(3, 20)).values, a[3:20])     # not a part: from the gathered copy
+    np.testing.assert_array_equal(sh.values, a)
+    ds = Dataset({"af": ShardedDataArray(parts, "lat", name="af"), "sim": _cube((40, 365), ("lat", "time"))})
+    assert isinstance(ds["af"], ShardedDataArray)
+    # parts without a device behind them are no reason to pin blocks to contexts: the ordinary plan applies
+    assert base._plan_blocks(ds, ["lat", "time"], keep_whole=("time",), n_workers=1) is None
 
 
 def test_block_seeds_do_not_depend_on_thread_order():

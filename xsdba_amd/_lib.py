@@ -221,9 +221,12 @@ class DeviceArray:
                                           C.c_size_t(self.nbytes)), "memcpy_h2d")
         return self
 
-    def download(self) -> np.ndarray:
-        shape = getattr(self, "logical_shape", None)
-        out = np.empty(self.shape, self.dtype)
+    def download(self, out: np.ndarray | None = None) -> np.ndarray:
+        """the buffer on the host; into `out` (C-contiguous, same shape and dtype: e.g. a slice of a larger array) when given"""
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        elif out.shape != tuple(self.shape) or out.dtype != self.dtype or not out.flags.c_contiguous:
+            raise ValueError("download(out=...): a C-contiguous array of the buffer's shape and dtype")
         if not (self.nbytes >= self._PIN_MIN and self._blocked_copy(out, False)):
             check(load().xsdba_hip_memcpy_d2h(self.ctx.handle, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
                                               C.c_size_t(self.nbytes)), "memcpy_d2h")

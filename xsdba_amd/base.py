@@ -390,25 +390,45 @@ def block_budget_bytes() -> float:
     return float(os.environ.get("XSDBA_AMD_BLOCK_MAX_MB", "65536")) * 2 ** 20
 
 
+def _nbytes(v) -> int:
+    return int(np.prod(v.shape, dtype=np.int64)) * np.dtype(v.dtype).itemsize  # (never `.values.nbytes`: that would gather a sharded array)
+
+
 def _plan_blocks(ds, base_dims, keep_whole=(), n_workers=1):
-    """(dim, step) when the host-backed variables of `ds` are to be cut along a dimension the block function neither reduces nor
-    creates — never the grouping dimension (`keep_whole`: ranks, trends and windows need the whole series) —: because they
-    exceed the block budget, or because several devices are there to share them (`n_workers` > 1 and at least
-    ``XSDBA_AMD_MULTI_MIN_MB``, default 64, of series: two blocks per device, so that a device's next upload runs under another
-    one's kernels).  None otherwise (device-resident inputs are already where they are used)."""
+    """(dim, bounds, contexts, keep) when the variables of `ds` are to be cut along a dimension the block function neither
+    reduces nor creates — never the grouping dimension (`keep_whole`: ranks, trends and windows need the whole series) —, else
+    None (device-resident inputs are already where they are used):
+      * a variable that is ALREADY sharded over the devices (a table trained by a multi-device call: labeled.ShardedDataArray)
+        dictates the cut — its parts' bounds — and where every block runs: on the context that holds its part;
+      * host-backed variables beyond the block budget are cut to fit it (results are brought back to the host: keep = False);
+      * with several devices to share them (`n_workers` > 1 and at least ``XSDBA_AMD_MULTI_MIN_MB``, default 64, of series) into
+        two blocks per device, so that a device's next upload runs under another one's kernels; the results stay on the device
+        that computed them (keep = True) and come back as sharded arrays."""
     import os
+
+    from .labeled import ShardedDataArray
 
     base_dims = [d for d in base_dims if d not in keep_whole]
     variables = list(ds.data_vars.values()) if isinstance(ds, Dataset) else [ds]
     if any(getattr(v, "device_data", None) is not None for v in variables):
         return None
+    sharded = [v for v in variables if isinstance(v, ShardedDataArray) and v.part_dim in base_dims and getattr(v, "_host", None) is None]
+    if sharded:
+        lead = sharded[0]
+        bounds = [(a, b_) for a, b_, _ in lead.parts]
+        ctxs = [getattr(getattr(p, "device_data", None), "ctx", None) for _, _, p in lead.parts]
+        same = all(v.part_dim == lead.part_dim and [(a, b_) for a, b_, _ in v.parts] == bounds for v in sharded)
+        sizes_ok = all(v.sizes[lead.part_dim] == lead.sizes[lead.part_dim] for v in variables if lead.part_dim in v.dims)
+        if same and sizes_ok and all(c is not None for c in ctxs):
+            return lead.part_dim, bounds, ctxs, True
+        # (parts that do not line up, or no longer on a device: gathered on the host and planned afresh below)
     cut = [v for v in variables if any(d in base_dims and v.sizes[d] > 1 for d in v.dims)]
-    total = sum(v.values.nbytes for v in cut)
+    total = sum(_nbytes(v) for v in cut)
     budget = block_budget_bytes()
     share = n_workers > 1 and total >= float(os.environ.get("XSDBA_AMD_MULTI_MIN_MB", "64")) * 2 ** 20
     if not cut or (total <= budget and not share):
         return None
-    big = max(cut, key=lambda v: v.values.nbytes)
+    big = max(cut, key=_nbytes)
     cands = [d for d in big.dims if d in base_dims and big.sizes[d] > 1]
     # the outermost such dimension: its blocks are contiguous pieces of a C-ordered cube
     dim = cands[0]
@@ -416,7 +436,10 @@ def _plan_blocks(ds, base_dims, keep_whole=(), n_workers=1):
     step = max(1, int(n * budget // total)) if total > budget else n
     if share:
         step = min(step, -(-n // (2 * n_workers)))
-    return (dim, step) if step < n else None
+    if step >= n:
+        return None
+    bounds = [(i0, min(n, i0 + step)) for i0 in range(0, n, step)]
+    return dim, bounds, None, share and total <= budget
 
 
 _block_pools: dict = {}
@@ -446,20 +469,27 @@ def _isel_block(ds, dim, sl):
 
 
 def _concat_blocks(outs, dim):
+    """the blocks' results as one Dataset: host arrays are concatenated; results that stayed on their devices become
+    labeled.ShardedDataArray (nothing moves until somebody asks for `values`)"""
+    from .labeled import ShardedDataArray
+
     first = outs[0]
     merged = {}
     for name, v0 in first.data_vars.items():
         if dim not in v0.dims:
             merged[name] = v0
             continue
+        parts = [o.data_vars[name] for o in outs]
+        if any(getattr(p, "device_data", None) is not None and getattr(p, "_host", None) is None for p in parts):
+            merged[name] = ShardedDataArray(parts, dim, v0.attrs, name)
+            continue
         ax = v0.dims.index(dim)
-        parts = [np.asarray(o.data_vars[name].transpose(*v0.dims).values) for o in outs]
+        host = [np.asarray(p.transpose(*v0.dims).values) for p in parts]
         coords = OrderedDict(v0.coords)
         if dim in v0.coords:
-            coords[dim] = Coordinate(dim, np.concatenate([np.asarray(o.data_vars[name].coords[dim].values) for o in outs]), v0.coords[dim].attrs)
-        merged[name] = DataArray(np.concatenate(parts, axis=ax), v0.dims, coords, v0.attrs, name)
+            coords[dim] = Coordinate(dim, np.concatenate([np.asarray(p.coords[dim].values) for p in parts]), v0.coords[dim].attrs)
+        merged[name] = DataArray(np.concatenate(host, axis=ax), v0.dims, coords, v0.attrs, name)
     return Dataset(merged, attrs=first.attrs)
-
 
 
 def map_blocks(reduces=None, **out_vars):
@@ -509,44 +539,50 @@ def map_blocks(reduces=None, **out_vars):
                     out = as_dataset(func(ds, **kwargs))
                 else:
                     # inputs larger than the block budget, or several devices to share them: the non-reduced dimension is cut in
-                    # blocks, every block is one call (uploaded through page-locked pieces, computed, its results brought back), like
-                    # dask chunks — dealt round-robin over one context per device (XSDBA_AMD_DEVICES), each driven by its own thread
-                    from .labeled import to_device_if_large
-
-                    bdim, step = plan
-                    n = (ds.sizes if isinstance(ds, Dataset) else ds.sizes)[bdim]
-
+                    # blocks, every block is one call (uploaded through page-locked pieces, computed), like dask chunks — dealt
+                    # round-robin over one context per device (XSDBA_AMD_DEVICES), each driven by its own thread; a block whose
+                    # tables already sit on a device runs there
                     import threading
 
+                    from ._lib import _tls
+                    from .labeled import to_device_if_large
+
+                    bdim, bounds, part_ctxs, keep = plan
                     seeds = {"lock": threading.Lock(), "base": None}  # (processing._draw_seed: one base for all blocks)
 
-                    def one_block(i0, ctx=None):
+                    def one_block(b, ctx=None):
                         def body():
-                            blk = _isel_block(ds, bdim, slice(i0, min(n, i0 + step)))
+                            blk = _isel_block(ds, bdim, slice(*bounds[b]))
                             blk = (Dataset({k: to_device_if_large(v) for k, v in blk.data_vars.items()}, attrs=blk.attrs)
                                    if isinstance(blk, Dataset) else to_device_if_large(blk))
                             o = as_dataset(func(blk, **kwargs))
+                            if keep:
+                                return o  # (the block's results stay on its device: _concat_blocks makes sharded arrays of them)
                             return Dataset({k: DataArray(np.asarray(v.values), v.dims, v.coords, v.attrs, v.name)
                                             for k, v in o.data_vars.items()}, attrs=o.attrs)
 
                         if ctx is None:
                             return body()
-                        from ._lib import _tls
-
                         with use_context(ctx):
-                            _tls.seeds = {"shared": seeds, "block": i0 // step, "k": 0}
+                            _tls.seeds = {"shared": seeds, "block": b, "k": 0}
                             try:
                                 return body()
                             finally:
                                 _tls.seeds = None
 
-                    starts = list(range(0, n, step))
-                    if n_workers > 1:
+                    if n_workers > 1 or part_ctxs is not None:
                         ctxs, pools = _block_workers()
-                        futs = [pools[b % len(pools)].submit(one_block, i0, ctxs[b % len(ctxs)]) for b, i0 in enumerate(starts)]
-                        outs = [f.result() for f in futs]
+                        by_ctx = {id(c): i for i, c in enumerate(ctxs)}
+                        if part_ctxs is not None and not all(id(c) in by_ctx for c in part_ctxs):
+                            # tables sharded over contexts that are no longer the workers': run every block where its part lives,
+                            # one after the other
+                            outs = [one_block(b, part_ctxs[b]) for b in range(len(bounds))]
+                        else:
+                            slot = [by_ctx[id(part_ctxs[b])] if part_ctxs is not None else b % len(pools) for b in range(len(bounds))]
+                            futs = [pools[slot[b]].submit(one_block, b, ctxs[slot[b]]) for b in range(len(bounds))]
+                            outs = [f.result() for f in futs]
                     else:
-                        outs = [one_block(i0) for i0 in starts]
+                        outs = [one_block(b) for b in range(len(bounds))]
                     out = _concat_blocks(outs, bdim)
                 def _ordered(v):
                     # the template order of the reference (base.py:696-700), for device-resident results too: their transpose is a

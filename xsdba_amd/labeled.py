@@ -430,6 +430,129 @@ _KEEP_ATTRS = [True]
 
 
 
+
+class ShardedDataArray(DataArray):
+    """A labelled array whose data are PER-BLOCK arrays laid end to end along `part_dim` — what ``map_blocks`` returns when it
+    dealt the blocks of a call over several devices (base.py): every part stays on the device that computed it (a trained
+    table is then used by the adjustment of the same cells on the same device, nothing crosses PCIe twice), ``values``
+    gathers the parts into one host array when — if ever — somebody asks.  ``isel`` of exactly one part along `part_dim` hands
+    that part over untouched; relabelling (``rename``, ``transpose``, ``assign_*``) is lazy like a device array's; everything
+    else works on the gathered host copy."""
+
+    def __init__(self, parts, part_dim, attrs=None, name=None):
+        first = parts[0]
+        self._parts = [p if tuple(p.dims) == tuple(first.dims) else p.transpose(*first.dims) for p in parts]
+        self._part_dim = part_dim
+        self._dev, self._host, self._dev_dims = None, None, None
+        self.dims = tuple(first.dims)
+        ax = self.dims.index(part_dim)
+        n = [p.shape[ax] for p in self._parts]
+        self._bounds = [(int(sum(n[:i])), int(sum(n[:i + 1]))) for i in range(len(n))]
+        self._shape = tuple(first.shape[:ax]) + (int(sum(n)),) + tuple(first.shape[ax + 1:])
+        self.coords = OrderedDict(first.coords)
+        if part_dim in first.coords and all(part_dim in p.coords for p in self._parts):
+            self.coords[part_dim] = Coordinate(part_dim, np.concatenate([np.asarray(p.coords[part_dim].values) for p in self._parts]),
+                                               first.coords[part_dim].attrs)
+        self.attrs = dict(first.attrs if attrs is None else attrs)
+        self.name = first.name if name is None else name
+
+    @property
+    def parts(self):
+        """[(start, stop, DataArray)] along `part_dim`"""
+        return [(a, b, p) for (a, b), p in zip(self._bounds, self._parts)]
+
+    @property
+    def part_dim(self):
+        return self._part_dim
+
+    @property
+    def shape(self):
+        return self._shape if self._host is None else self._host.shape
+
+    @property
+    def dtype(self):
+        return self._parts[0].dtype if self._host is None else self._host.dtype
+
+    @property
+    def device_data(self):
+        return None  # (no single buffer: the parts carry theirs)
+
+    @property
+    def values(self):
+        if self._host is None:
+            ax = self.dims.index(self._part_dim)
+            out = np.empty(self._shape, self._parts[0].dtype)
+            for (a, b), p in zip(self._bounds, self._parts):
+                dev = getattr(p, "device_data", None)
+                dst = out[(slice(None),) * ax + (slice(a, b),)]
+                if dev is not None and getattr(p, "_host", None) is None and tuple(p.device_dims) == tuple(self.dims) and dst.flags.c_contiguous \
+                        and getattr(dev, "logical_shape", None) is None:
+                    dev.download(out=dst.reshape(dev.shape))  # straight into its place: no second copy
+                else:
+                    dst[...] = p.values
+            self._host = out
+        return self._host
+
+    @values.setter
+    def values(self, v):
+        self._host = np.asarray(v)
+
+    def _plain(self):
+        return DataArray(self.values, self.dims, self.coords, self.attrs, self.name)
+
+    def _rebuild(self, parts, part_dim, coords=None, attrs=None, name=None):
+        out = ShardedDataArray(parts, part_dim, self.attrs if attrs is None else attrs, self.name if name is None else name)
+        if coords is not None:
+            out.coords = OrderedDict(coords)
+        out._host = None if self._host is None or tuple(out.dims) != tuple(self.dims) else self._host
+        return out
+
+    def _like(self, dims=None, coords=None, attrs=None, name=None):
+        if dims is not None and tuple(dims) != tuple(self.dims):
+            return self._plain()._like(dims=dims, coords=coords, attrs=attrs, name=name)
+        return self._rebuild(self._parts, self._part_dim, coords=self.coords if coords is None else coords, attrs=attrs, name=name)
+
+    def rename(self, name=None):
+        if isinstance(name, dict):
+            return self._rebuild([p.rename(name) for p in self._parts], name.get(self._part_dim, self._part_dim))
+        out = self._like()
+        out.name = name
+        return out
+
+    def transpose(self, *dims):
+        if not dims:
+            dims = self.dims[::-1]
+        if Ellipsis in dims:
+            i = dims.index(Ellipsis)
+            rest = [d for d in self.dims if d not in dims]
+            dims = tuple(dims[:i]) + tuple(rest) + tuple(dims[i + 1:])
+        if set(dims) != set(self.dims):
+            raise ValueError(f"{dims} is not a permutation of {self.dims}")
+        if tuple(dims) == tuple(self.dims):
+            return self._like()
+        out = self._rebuild([p.transpose(*dims) for p in self._parts], self._part_dim)
+        out.coords = OrderedDict(self.coords)
+        return out
+
+    def astype(self, dtype):
+        return self._like() if np.dtype(dtype) == self.dtype else self._plain().astype(dtype)
+
+    def copy(self, data=None):
+        return self._like() if data is None else self._plain().copy(data)
+
+    def isel(self, indexers=None, drop=False, **kw):
+        idx = dict(indexers or {})
+        idx.update(kw)
+        if set(idx) == {self._part_dim} and isinstance(idx[self._part_dim], slice) and self._host is None:
+            sl = idx[self._part_dim]
+            a, b, step = sl.indices(self.sizes[self._part_dim])
+            if step == 1:
+                for (pa, pb), p in zip(self._bounds, self._parts):
+                    if (pa, pb) == (a, b):
+                        return p._like(attrs=self.attrs, name=self.name)
+        return self._plain().isel(idx, drop=drop)
+
+
 def to_device_if_large(da):
     """Large host series are moved to the GPU ONCE (blocks page-locked on the fly, DMA at the PCIe rate): everything
     downstream — trained tables included — then stays on the device, and a result is downloaded only when its ``values`` are
