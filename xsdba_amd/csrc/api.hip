@@ -1201,7 +1201,8 @@ int launch_trend(xsdba_hip_ctx *ctx, const SeriesIn &s, int64_t T, int64_t C, co
     // regression layout: a lane per group when there are many short groups (day-of-year), else a half-wave per group
     const int lane_per_group = (pl->G >= 128 && pl->max_mem <= 256) ? 1 : 0;
     if (lds1 > (size_t)ctx->lds_limit) {
-        // the series does not fit the LDS (hourly data): the kernel reads it from global memory (k_group_trend<XG>), the window
+        // the series does not fit the LDS (hourly data; 4 x slower per step than the LDS kernel where both apply: 17.5 against
+        // 4.4 ms per 32 400 cells x 21 900 days): the kernel reads it from global memory (k_group_trend<XG>), the window
         // means go through the trend buffer
         if (!trend_cm) return fail(XSDBA_E_ARG, "internal: the long-series trend kernel needs the trend buffer");
         const bool mt64 = !pl->d_mem_t32 && pl->d_mem_t64;

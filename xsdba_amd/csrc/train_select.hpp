@@ -173,6 +173,16 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
     }
     const bool ungrouped = __syncthreads_or(ung) != 0;  // some time step belongs to no group
 
+#ifdef XS_SEL_STAGGER
+    // (experiment builds of scripts/ubench/sel_bench.hip: the blocks start XS_SEL_STAGGER clocks apart at most, by a hash of their
+    //  number — do blocks that stay in step with each other load, count and select at the same time?)
+    if (XS_SEL_STAGGER > 0) {
+        uint32_t h = (uint32_t)blockIdx.x * 2654435761u;
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+        const uint64_t wait = (uint64_t)(h % (uint32_t)XS_SEL_STAGGER), t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+#endif
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
         bool flag_cell = false;
         const int npass_arr = mode == 0 ? 1 : 2;
