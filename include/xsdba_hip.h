@@ -70,7 +70,7 @@ int xsdba_hip_create(int device, xsdba_hip_ctx **ctx);
 int xsdba_hip_destroy(xsdba_hip_ctx *ctx);
 /* The per-cell sort kernels (train_cell.hpp: stable counting passes on wave-private counter rows) rely on ONE undocumented
  * hardware property: a returning LDS atomic serves the lanes of an instruction that hit the same word in ascending lane order.
- * xsdba_hip_create probes it (< 1 ms, csrc/order_probe.hpp; XSDBA_HIP_ATOMIC_ORDER = probe | assume | broken); *ordered = 0
+ * xsdba_hip_create probes it (~0.5 ms, csrc/order_probe.hpp; XSDBA_HIP_ATOMIC_ORDER = probe | assume | broken); *ordered = 0
  * means the probe failed and this context computes everything those kernels would have served with the generic ones
  * (k_train_rows / k_qdm_adjust: same results, slower) — never a wrong quantile. */
 int xsdba_hip_lane_ordered_atomics(xsdba_hip_ctx *ctx, int *ordered);

@@ -1861,7 +1861,7 @@ API int xsdba_hip_create(int device, xsdba_hip_ctx **out)
         else if (!(m && !strcmp(m, "assume"))) {
             unsigned long long *dbad = nullptr, hbad = ~0ull;
             if (hipMalloc((void **)&dbad, sizeof hbad) == hipSuccess && hipMemsetAsync(dbad, 0, sizeof hbad, ctx->stream) == hipSuccess) {
-                hipLaunchKernelGGL(xs::k_atomic_order_probe, dim3(16), dim3(1024), 0, ctx->stream, 24, dbad);
+                hipLaunchKernelGGL(xs::k_atomic_order_probe, dim3(16), dim3(1024), 0, ctx->stream, 8, dbad);
                 if (hipGetLastError() == hipSuccess && hipMemcpyAsync(&hbad, dbad, sizeof hbad, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
                     hipStreamSynchronize(ctx->stream) == hipSuccess)
                     ctx->lane_ordered_atomics = hbad == 0;

@@ -3,7 +3,7 @@
 // wave's instructions in program order), so that `old` = counter before + number of lower lanes with the same digit — which is
 // what makes the counting passes on wave-private counter rows stable.  Measured offline over 1.4e11 atomics
 // (scripts/ubench/atomic_order.hip -> profiles/r04_atomic_order.txt); a firmware or silicon revision that changed it would give
-// silently wrong quantiles, so every context probes it once at creation (< 1 ms): lane -> digit maps that are uniform, skewed,
+// silently wrong quantiles, so every context probes it once at creation (~0.5 ms; 3.7 million atomics): lane -> digit maps that are uniform, skewed,
 // in runs, mirrored, descending, with a hot bin and strided, on plain and on packed 16-bit counters, sixteen waves of a block
 // hammering their own rows at once.  A context whose probe fails takes the generic kernels (k_train_rows / k_qdm_adjust: bitonic
 // sorts and counting, no such assumption) for everything the per-cell sorts would have served.
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void k_atomic_order_probe(int rounds, unsigne
     unsigned long long nbad = 0;
     for (int packed = 0; packed < 2; packed++)
         for (int p = 0; p < 7; p++)
-            for (uint32_t nd = 16; nd <= (uint32_t)PROBE_ND; nd *= 4) {
+            for (uint32_t nd = 16; nd <= (uint32_t)PROBE_ND; nd *= 16) {  // 16 digits (long same-word runs) and 256 (the sorts' widest rows)
                 for (uint32_t i = lane; i < (uint32_t)PROBE_ND + 8; i += 64) mine[i] = 0u;
                 __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 for (int it = 0; it < rounds; it++) {
