@@ -1452,7 +1452,9 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
             int *flag_count = (int *)flags, *flag_list = flag_count + 1;
             HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
             const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
-            const int use_tog = (rw || W == 1) ? 1 : 0;
+            // bit 1: un-windowed groups, at most 64 of them: ranks by a group-keyed stable pass of the sorted order instead of the
+            // bit-vector walk (XSDBA_HIP_QDM_WALK=1 keeps the walk: A/B runs, tests)
+            const int use_tog = ((rw || W == 1) ? 1 : 0) | ((W == 1 && G > 1 && G <= 64 && !pl->has_ungrouped && !getenv("XSDBA_HIP_QDM_WALK")) ? 2 : 0);
             auto go = [&](auto cfg) -> int {
                 constexpr int EPT = decltype(cfg)::value;
                 const size_t lds = xs::QdmCfg<EPT>::lds_bytes;
@@ -1461,8 +1463,8 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
                 LaunchScope ls(ctx, "k_qdm_cell");
                 hipLaunchKernelGGL((xs::k_qdm_cell<EPT, R>), dim3(nblk), dim3(1024), lds, ctx->stream, (const R *)s.dev, T, C, s.sc,
-                                   (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, use_tog ? pl->d_row_ptr : pl->d_mem_ptr,
-                                   use_tog ? pl->d_row_sorted : pl->d_mem_idx, pl->d_mem_ptr, pl->d_mem_idx, pl->d_tog_ptr,
+                                   (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, (use_tog & 1) ? pl->d_row_ptr : pl->d_mem_ptr,
+                                   (use_tog & 1) ? pl->d_row_sorted : pl->d_mem_idx, pl->d_mem_ptr, pl->d_mem_idx, pl->d_tog_ptr,
                                    pl->d_tog_idx, pl->d_tog64, use_tog, interp, extrap, (int)kind, (R *)o.kernel_dst,
                                    (double *)oq.kernel_dst, flag_count, flag_list, pl->max_mem, pl->d_mem_t32);
                 return check_launch("k_qdm_cell");

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     const int *__restrict__ grp_ptr, const int *__restrict__ grp_idx,  // ranking rows (windowed rows or exact groups)
     const int *__restrict__ mem_ptr, const int *__restrict__ mem_idx,  // exact groups: the elements each row ranks
     const int *__restrict__ tog_ptr, const int *__restrict__ tog_idx, const int *__restrict__ tog64,
-    int use_tog,  // consecutive ranking rows differ by the toggle lists; 0: rows are the (disjoint) exact groups
+    int use_tog,  // bit 0: consecutive ranking rows differ by the toggle lists (0: rows are the (disjoint) exact groups);
+                  // bit 1: the ranking rows ARE the exact groups (no window), at most 64 of them: ranks by the group-keyed pass (C3)
     int interp, int extrap, int kind, R *__restrict__ scen, double *__restrict__ sim_q,
     int *__restrict__ flag_count, int *__restrict__ flag_list, int max_mem /* most elements any row ranks */,
     const int *__restrict__ mem_t32 /* [16][G] member slots, two 16-bit time steps per word (0xFFFF: none), or null */)
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         // and a row ranks at most 30 elements (30 years of a day-of-year window): the second stream's vectors take the place of the
         // keys, which are dead once the tie bits are formed — what still needs a value reads the series itself
         const bool have_tb = (size_t)(TPAD / 8) <= (size_t)(QC::GMAX - G) * 24;
-        const bool two = have_tb && G >= NWAVE && use_tog && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
+        const bool two = have_tb && G >= NWAVE && (use_tog & 1) && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
         const QdmSeries<R> ser{sim + c * sc, keys, sorted, two}, ser_lds{sim + c * sc, keys, sorted, false};
         // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):
         // first rank in [0, r] whose value equals the one at r ...
@@ -219,6 +220,155 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             }
             if (tid == 0 && nvalid) {
                 put_stats(0, nvalid, run_end(0), nvalid - run_begin(nvalid - 1));
+            }
+        } else if (nvalid && (use_tog & 2)) {
+            // ---------------- C3. un-windowed groups (time.month, time.season, ...): a group-keyed stable pass ----------------
+            // The ranking rows are the groups themselves and every valid step belongs to one: ONE more stable counting pass of the
+            // sorted order, keyed by the group, lays the ranks out group by group in value order — an element's place in its
+            // group's segment IS the number of members below it.  No bit-vector is built or walked (the walk built 912-member
+            // vectors per wave and ranked by prefix popcounts: 4.8 of 14.2 ms per 64 800 monthly cells).  Ties: a run of equal
+            // values inside a segment is a run of unflagged places, a place being flagged when a segment starts there or its
+            // value differs from its predecessor's; run start / run end of every place by a forward max-scan / backward
+            // min-scan of the flagged places over the block, the segment start the same way.
+            constexpr int RND = TPAD / NT, GS = 72;
+            // (LDS: behind rank[], where the walks keep their vectors and prefix tables and the sort kept its histogram — all dead here)
+            static_assert(QC::off_bits + (size_t)TPAD * 2 + (size_t)(NWAVE * GS + TPAD / 32 + 72) * 4 <= QC::off_gstat, "ranks by place, counters, flags, segment starts");
+            uint16_t *GR = reinterpret_cast<uint16_t *>(smem + QC::off_bits);   // [place] -> global rank
+            uint32_t *wc = reinterpret_cast<uint32_t *>(GR + TPAD);             // [NWAVE][GS] wave-private counters -> base places
+            uint32_t *SB = wc + NWAVE * GS;                                     // [TPAD / 32] a segment starts at this place
+            int *seg = reinterpret_cast<int *>(SB + TPAD / 32);                 // [G + 1] first place of every group's segment
+            for (int i = tid; i < NWAVE * GS + TPAD / 32; i += NT) wc[i] = 0u;
+            __syncthreads();
+            uint32_t *wrow = wc + wid * GS;
+            int gq[RND];
+            uint32_t od[RND];
+#pragma unroll
+            for (int j = 0; j < RND; j++) {
+                const int r = wid * (64 * RND) + 64 * j + lane;
+                gq[j] = r < nvalid ? gidx[sorted[r]] : -1;
+            }
+            // (a wave's returning atomics are served in program order, the lanes of one instruction that hit the same word in
+            //  ascending lane order — train_cell.hpp: the pass is stable)
+#pragma unroll
+            for (int j = 0; j < RND; j++) od[j] = gq[j] >= 0 ? atomicAdd(&wrow[gq[j]], 1u) : 0u;
+            __syncthreads();
+            {   // exclusive scan of the counters in (group, wave) order: thread i owns counter (group i >> 4, wave i & 15)
+                const bool own = tid < NWAVE * G;
+                const uint32_t cv = own ? wc[(tid & 15) * GS + (tid >> 4)] : 0u;
+                const int incl = wave_incl_scan((int)cv);
+                if (lane == 63) red[wid] = (uint32_t)incl;
+                __syncthreads();
+                const int pre = waves_before(red, lane, wid) + incl - (int)cv;
+                if (own) {
+                    wc[(tid & 15) * GS + (tid >> 4)] = (uint32_t)pre;
+                    if ((tid & 15) == 0) { seg[tid >> 4] = pre; atomicOr(&SB[pre >> 5], 1u << (pre & 31)); }
+                    if (tid == NWAVE * G - 1) { seg[G] = pre + (int)cv; atomicOr(&SB[(pre + (int)cv) >> 5], 1u << ((pre + (int)cv) & 31)); }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < RND; j++)
+                if (gq[j] >= 0) GR[wrow[gq[j]] + od[j]] = (uint16_t)(wid * (64 * RND) + 64 * j + lane);
+            __syncthreads();
+            const int ntot = seg[G];  // the ranked steps (valid and in a group)
+            // a thread owns RND consecutive places
+            const int p0 = tid * RND;
+            int rr[RND];
+            uint32_t fl = 0u, sbm = 0u;  // bit j: place p0 + j is flagged / starts a segment
+            {
+                int rprev = (p0 > 0 && p0 <= ntot) ? (int)GR[p0 - 1] : -1;
+#pragma unroll
+                for (int j = 0; j < RND; j++) {
+                    const int p = p0 + j;
+                    rr[j] = p < ntot ? (int)GR[p] : -1;
+                    const bool sb = p <= ntot && ((SB[p >> 5] >> (p & 31)) & 1u);
+                    bool f = sb || p == ntot;
+                    if (!f && p < ntot) f = !ser_lds.eq_ranks(rprev, rr[j]);
+                    fl |= (uint32_t)f << j;
+                    sbm |= (uint32_t)sb << j;
+                    rprev = rr[j];
+                }
+            }
+            // block-wide scans of "the last flagged place at or before" (max, forward) and "the first flagged place behind" (min,
+            // backward): per thread over its places, per wave on the DPP path (values + 1 so that 0 is "none"), across the waves
+            // through `red`
+            auto wave_max_scan = [&](int v) {  // inclusive, v >= 0
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+                return v;
+            };
+            auto block_excl_max = [&](int mine, uint32_t *scr) {  // max of `mine` (>= 0) over the threads before this one
+                const int incl = wave_max_scan(mine);
+                int ex = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, incl);
+                ex = lane ? ex : 0;
+                if (lane == 63) scr[wid] = (uint32_t)incl;
+                __syncthreads();
+                int carry = 0;
+                for (int w = 0; w < NWAVE; w++) carry = w < wid ? max(carry, (int)scr[w]) : carry;
+                __syncthreads();
+                return max(ex, carry);
+            };
+            int lastf = 0, lasts = 0;  // (place + 1) of the last flagged place / segment start among this thread's, 0: none
+#pragma unroll
+            for (int j = 0; j < RND; j++) {
+                if ((fl >> j) & 1u) lastf = p0 + j + 1;
+                if ((sbm >> j) & 1u) lasts = p0 + j + 1;
+            }
+            const int carf = block_excl_max(lastf, red), cars = block_excl_max(lasts, red);
+            // backward: the first flagged place of this thread's (as BIG - place so that the max machinery serves), mirrored lanes
+            constexpr int BIG = 1 << 20;
+            int firstf = 0;
+#pragma unroll
+            for (int j = RND - 1; j >= 0; j--)
+                if ((fl >> j) & 1u) firstf = BIG - (p0 + j);
+            int nextf;  // the first flagged place behind this thread's places
+            {
+                const int mir = __builtin_amdgcn_ds_bpermute((63 - lane) * 4, firstf);
+                const int inclm = wave_max_scan(mir);                       // lane l: max over mirrored lanes <= l = original lanes >= 63 - l
+                int exm = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, inclm);
+                exm = lane ? exm : 0;                                       // mirrored lane l: original lanes > 63 - l
+                const int ex = __builtin_amdgcn_ds_bpermute((63 - lane) * 4, exm);
+                const int wtot = __builtin_amdgcn_readlane(inclm, 63);
+                if (lane == 0) red[wid] = (uint32_t)wtot;
+                __syncthreads();
+                int carry = 0;
+                for (int w = 0; w < NWAVE; w++) carry = w > wid ? max(carry, (int)red[w]) : carry;
+                __syncthreads();
+                const int best = max(ex, carry);
+                nextf = best ? BIG - best : ntot;
+            }
+            {
+                int curf = carf, curs = cars, rs[RND], sg[RND];
+#pragma unroll
+                for (int j = 0; j < RND; j++) {
+                    if ((fl >> j) & 1u) curf = p0 + j + 1;
+                    if ((sbm >> j) & 1u) curs = p0 + j + 1;
+                    rs[j] = curf - 1; sg[j] = curs - 1;
+                }
+                int nx = nextf;
+#pragma unroll
+                for (int j = RND - 1; j >= 0; j--) {
+                    const int p = p0 + j;
+                    if (p < ntot) {
+                        const int re = nx;  // the run of place p ends where the next flagged place is
+                        const int t = (int)sorted[rr[j]];
+                        r2buf[t] = (uint16_t)((rs[j] - sg[j]) + (re - sg[j]) + 1);
+                        const bool first = (sbm >> j) & 1u, lastp = (SB[(p + 1) >> 5] >> ((p + 1) & 31)) & 1u;
+                        if (first || lastp) {
+                            // the group of this place: the last one whose segment starts at or before it
+                            int lo = 0, hi = G - 1;
+                            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (seg[mid] <= p) lo = mid; else hi = mid - 1; }
+                            int *gi = reinterpret_cast<int *>(gstat + 3 * lo);
+                            if (first) { gi[0] = seg[lo + 1] - seg[lo]; gi[2] = re - p; }
+                            if (lastp) gi[4] = p + 1 - rs[j];
+                        }
+                    }
+                    if ((fl >> j) & 1u) nx = p;
+                }
             }
         } else if (nvalid && two) {
             // ---------------- C2. the walk of C with TWO group streams per wave ----------------
@@ -378,7 +528,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             };
             for (int g = g0; g < g1; g++) {
                 if (g == g0) flip_list(grp_idx + grp_ptr[g], grp_ptr[g + 1] - grp_ptr[g]);
-                else if (use_tog) {
+                else if (use_tog & 1) {
                     if (tog64) {
                         const int t = tog64[(size_t)g * 64 + lane];
                         const int r = t >= 0 ? (int)rank[t] : 0x7FFFFFFF;
