@@ -67,6 +67,7 @@ struct Plan {
     int max_row = 0, max_mem = 0;
     std::vector<int> row_ptr, row_idx, mem_ptr, mem_idx;
     std::vector<int> g_host;  // the group of every time step (compared on a hash hit)
+    unsigned char *d_gidx8 = nullptr;  // the group of every time step in a byte (255: none) when there are at most 254 groups
     int *d_gidx = nullptr, *d_row_ptr = nullptr, *d_row_idx = nullptr, *d_mem_ptr = nullptr, *d_mem_idx = nullptr;
     // fast train path (train_cell.hpp): rows as sorted sets, toggle lists between consecutive groups
     bool simple = false;  // no time index occurs twice in one group row
@@ -82,6 +83,15 @@ struct Plan {
     int *d_mem_t32 = nullptr;  // [16][G] member slots -> time indexes, two 16-bit indexes per word, when every group has <= 32 members (k_qdm_lanes)
     int *d_mem_t64 = nullptr;  // [32][G] the same for groups of 33 .. 64 members (the regression of k_group_trend on 60-year series)
     bool has_ungrouped = false;  // some time step belongs to no group
+    // k_qdm_node_tables (qdm_cell.hpp): one table per distinct length of the ranking rows ([0]: the groups' members, [1]: the
+    // windowed rows), made on first use
+    struct GroupTabs {
+        bool made = false;
+        int K = 0, max_n = 0;  // classes (0: no tables), the longest row among them
+        size_t bytes = 0;      // of all tables
+        std::vector<int> cls_N, cls_off;  // (host: they travel to k_qdm_cell by value)
+        int *d_cls_N = nullptr, *d_cls_off = nullptr;
+    } gt[2];
 };
 
 struct ProfEntry {
@@ -261,6 +271,48 @@ void free_plan(Plan *p)
     if (p->d_tog128) (void)hipFree(p->d_tog128);
     if (p->d_mem_t32) (void)hipFree(p->d_mem_t32);
     if (p->d_mem_t64) (void)hipFree(p->d_mem_t64);
+    if (p->d_gidx8) (void)hipFree(p->d_gidx8);
+    for (auto &t : p->gt) {
+        if (t.d_cls_N) (void)hipFree(t.d_cls_N);
+        if (t.d_cls_off) (void)hipFree(t.d_cls_off);
+    }
+}
+
+// The classes of k_qdm_node_tables for the plan's ranking rows: their distinct lengths (at most 16, tables of at most 1 MB
+// together — the offsets travel as 16-bit counts of 16 bytes), the most frequent first.
+int make_group_tabs(xsdba_hip_ctx *ctx, Plan *pl, bool rows)
+{
+    Plan::GroupTabs &t = pl->gt[rows ? 1 : 0];
+    if (t.made) return 0;
+    const std::vector<int> &ptr = rows ? pl->row_ptr : pl->mem_ptr;
+    std::vector<std::pair<int, int>> cnt;  // (groups of this length, length)
+    for (int g = 0; g < pl->G; g++) {
+        const int n = ptr[g + 1] - ptr[g];
+        if (n <= 0) continue;
+        size_t k = 0;
+        while (k < cnt.size() && cnt[k].second != n) k++;
+        if (k == cnt.size()) cnt.push_back({0, n});
+        cnt[k].first++;
+    }
+    std::stable_sort(cnt.begin(), cnt.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.first > b.first; });
+    size_t bytes = 0;
+    for (const auto &c : cnt) {
+        const size_t len = ((size_t)2 * c.second + 2 + 15) & ~(size_t)15;
+        if (t.cls_N.size() >= 16 || bytes + len > (size_t)65535 * 16) break;
+        t.cls_N.push_back(c.second);
+        t.cls_off.push_back((int)bytes);
+        bytes += len;
+        t.max_n = std::max(t.max_n, c.second);
+    }
+    int rc;
+    if (!t.cls_N.empty()) {
+        if ((rc = upload_ints(ctx, t.cls_N, &t.d_cls_N)) || (rc = upload_ints(ctx, t.cls_off, &t.d_cls_off))) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    t.K = (int)t.cls_N.size();
+    t.bytes = bytes;
+    t.made = true;
+    return 0;
 }
 
 // base.py:232-272 — rolling(center=True, window).construct puts x[t' + j - window/2] in slot j of centre t';
@@ -426,6 +478,16 @@ int get_plan(xsdba_hip_ctx *ctx, const int32_t *group_of_time, int64_t T, int G,
     if ((rc = upload_ints(ctx, tog_ptr, &pl->d_tog_ptr))) return rc;
     if ((rc = upload_ints(ctx, tog_idx, &pl->d_tog_idx))) return rc;
     if ((rc = upload_ints(ctx, g, &pl->d_gidx))) return rc;
+    std::vector<int> g8;  // (declared here: alive until the synchronisation below)
+    if (G <= 254) {
+        // the group of every time step in a byte (255: none): a gather through it stays in a CU's vector cache
+        g8.assign(((size_t)T + 3) / 4, -1);
+        unsigned char *b = reinterpret_cast<unsigned char *>(g8.data());
+        for (int64_t t = 0; t < T; t++) b[t] = g[t] >= 0 ? (unsigned char)g[t] : (unsigned char)255;
+        int *d8 = nullptr;
+        if ((rc = upload_ints(ctx, g8, &d8))) return rc;
+        pl->d_gidx8 = reinterpret_cast<unsigned char *>(d8);
+    }
     if ((rc = upload_ints(ctx, pl->row_ptr, &pl->d_row_ptr))) return rc;
     if ((rc = upload_ints(ctx, pl->row_idx, &pl->d_row_idx))) return rc;
     if ((rc = upload_ints(ctx, pl->mem_ptr, &pl->d_mem_ptr))) return rc;
@@ -1454,23 +1516,51 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
             const int ept = T <= 4 * 1024 ? 4 : (T <= 8 * 1024 ? 8 : 11);
             // bit 1: un-windowed groups, at most 64 of them: ranks by a group-keyed stable pass of the sorted order instead of the
             // bit-vector walk (XSDBA_HIP_QDM_WALK=1 keeps the walk: A/B runs, tests)
-            const int use_tog = ((rw || W == 1) ? 1 : 0) | ((W == 1 && G > 1 && G <= 64 && !pl->has_ungrouped && !getenv("XSDBA_HIP_QDM_WALK")) ? 2 : 0);
-            auto go = [&](auto cfg) -> int {
+            const bool walk = getenv("XSDBA_HIP_QDM_WALK") != nullptr;
+            const int use_tog = ((rw || W == 1) ? 1 : 0) | ((W == 1 && G > 1 && G <= 64 && !pl->has_ungrouped && !walk) ? 2 : 0);
+            // the kernel without the walks: those groups, or a single group holding every time step (the sorted order is the ranking)
+            const bool pass = (use_tog & 2) || (G == 1 && !pl->has_ungrouped && !walk);
+            // the node tables of pass D for rows without NaNs and without ties at their extremes, once per launch (XSDBA_HIP_QDM_TABLES=0:
+            // every cell builds its own as before — A/B runs, tests)
+            const unsigned char *gtab = (const unsigned char *)flag_count;  // (a readable address when there are no tables)
+            xs::QdmTabs gt;
+            const char *tabenv = getenv("XSDBA_HIP_QDM_TABLES");
+            if (!ranks_only && !sim_q && G > 1 && Q <= 63 && !(tabenv && !strcmp(tabenv, "0"))) {
+                if ((rc = make_group_tabs(ctx, pl, (use_tog & 1) != 0))) return rc;
+                const Plan::GroupTabs &t = pl->gt[(use_tog & 1) ? 1 : 0];
+                if (t.K) {
+                    void *tb;
+                    if ((rc = ensure(ctx, S_TAB1, t.bytes, &tb))) return rc;
+                    LaunchScope ls(ctx, "k_qdm_node_tables");
+                    hipLaunchKernelGGL(xs::k_qdm_node_tables<R>, dim3((unsigned)std::min(8, (2 * t.max_n + 2 + 255) / 256), (unsigned)t.K), dim3(256), 0,
+                                       ctx->stream, (const R *)dqn, Q, t.d_cls_N, t.d_cls_off, (unsigned char *)tb);
+                    if ((rc = check_launch("k_qdm_node_tables"))) return rc;
+                    gtab = (const unsigned char *)tb;
+                    gt.K = t.K; gt.bytes = (int)t.bytes;
+                    for (int k = 0; k < t.K; k++) { gt.N[k] = t.cls_N[k]; gt.off[k] = t.cls_off[k] / 16; }
+                    if (tabenv && !strcmp(tabenv, "global")) gt.bytes = 1 << 20;  // (A/B runs: the tables stay in global memory)
+                }
+            }
+            auto go = [&](auto cfg, auto pass_c) -> int {
                 constexpr int EPT = decltype(cfg)::value;
+                constexpr bool PASS = decltype(pass_c)::value;
                 const size_t lds = xs::QdmCfg<EPT>::lds_bytes;
                 int rc2;
-                if ((rc2 = set_lds((xs::k_qdm_cell<EPT, R>), lds, ctx, "the per-cell sort"))) return rc2;
+                if ((rc2 = set_lds((xs::k_qdm_cell<EPT, R, PASS>), lds, ctx, "the per-cell sort"))) return rc2;
                 const unsigned nblk = (unsigned)std::min<int64_t>(C, 4 * ctx->n_cu);
                 LaunchScope ls(ctx, "k_qdm_cell");
-                hipLaunchKernelGGL((xs::k_qdm_cell<EPT, R>), dim3(nblk), dim3(1024), lds, ctx->stream, (const R *)s.dev, T, C, s.sc,
+                hipLaunchKernelGGL((xs::k_qdm_cell<EPT, R, PASS>), dim3(nblk), dim3(1024), lds, ctx->stream, (const R *)s.dev, T, C, s.sc,
                                    (const R *)daf, (const R *)dqn, G, Q, pl->d_gidx, (use_tog & 1) ? pl->d_row_ptr : pl->d_mem_ptr,
                                    (use_tog & 1) ? pl->d_row_sorted : pl->d_mem_idx, pl->d_mem_ptr, pl->d_mem_idx, pl->d_tog_ptr,
                                    pl->d_tog_idx, pl->d_tog64, use_tog, interp, extrap, (int)kind, (R *)o.kernel_dst,
-                                   (double *)oq.kernel_dst, flag_count, flag_list, pl->max_mem, pl->d_mem_t32);
+                                   (double *)oq.kernel_dst, flag_count, flag_list, pl->max_mem, pl->d_mem_t32, gtab, gt, pl->d_gidx8);
                 return check_launch("k_qdm_cell");
             };
             using std::integral_constant;
-            rc = ept == 4 ? go(integral_constant<int, 4>{}) : ept == 8 ? go(integral_constant<int, 8>{}) : go(integral_constant<int, 11>{});
+            using std::true_type;
+            using std::false_type;
+            if (pass) rc = ept == 4 ? go(integral_constant<int, 4>{}, true_type{}) : ept == 8 ? go(integral_constant<int, 8>{}, true_type{}) : go(integral_constant<int, 11>{}, true_type{});
+            else rc = ept == 4 ? go(integral_constant<int, 4>{}, false_type{}) : ept == 8 ? go(integral_constant<int, 8>{}, false_type{}) : go(integral_constant<int, 11>{}, false_type{});
             if (rc) return rc;
             // cells the own-row shortcut could not serve (NaN factors) are redone by the generic kernel, device-side count
             if (!ranks_only && (rc = launch_generic(flag_list, flag_count, std::min<int64_t>(C, 256)))) return rc;

@@ -29,6 +29,16 @@
 #define XS_QDM_STOP 0
 #endif
 
+// experiment builds only (-DXS_QDM_CLK=1): wave 0 of block 0 accumulates the shader clock between phase boundaries and prints it
+#ifndef XS_QDM_CLK
+#define XS_QDM_CLK 0
+#endif
+#if XS_QDM_CLK
+#define XS_CLK(i) do { const long long now_ = clock64(); clk_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define XS_CLK(i) do { } while (0)
+#endif
+
 namespace xs {
 
 template <int EPT> struct QdmCfg {
@@ -79,7 +89,55 @@ template <> struct QdmSeries<double> {
     }
 };
 
-template <int EPT, typename R = float>
+// The node of the quantile axis a percent rank maps to, as pass D of k_qdm_cell codes it in a byte: 255: NaN; else
+// node | 0x40 below the first node | 0x80 above the last.  qn: the Q nodes (LDS).
+template <typename R>
+__device__ __forceinline__ int qdm_node_code(double sq, const R *qn, int Q)
+{
+    if (sq != sq) return 255;
+    if (sq < (double)qn[0]) return 0x40;
+    if (sq > (double)qn[Q - 1]) return (Q - 1) | 0x80;
+    int w;
+    (void)row_nearest<R, double>(sq, qn, Q, &w);
+    return w;
+}
+
+// The map 2 * rank -> node code of a group depends on the group's (N, ties at the minimum, ties at the maximum) only — not on
+// the cell.  For the triples (N, 1, 1) — a ranking row of N valid values with untied extremes: every row of a cell without NaNs
+// and without ties at its extremes — it is tabulated ONCE per launch, one table per distinct row length of the plan, with the
+// very expressions pass D evaluates per element (utils.rank :631-635 rescaling, two float64 divisions, a bisection).  A cell
+// whose groups all match reads these tables and builds none of its own (k_qdm_cell spent 1.9 K such evaluations per cell on
+// the middle group's table and ~150 instructions per element of every group with another triple: 5 of 12 months).
+// grid: (blocks, classes).
+template <typename R>
+__global__ __launch_bounds__(256) void k_qdm_node_tables(const R *__restrict__ quantiles, int Q, const int *__restrict__ cls_N,
+                                                         const int *__restrict__ cls_off, unsigned char *__restrict__ out)
+{
+    __shared__ R qn[64];
+    if ((int)threadIdx.x < Q) qn[threadIdx.x] = quantiles[threadIdx.x];
+    __syncthreads();
+    const int n = cls_N[blockIdx.y];
+    unsigned char *tab = out + cls_off[blockIdx.y];
+    const double N0 = (double)n, nmin = 1.0, nmax = 1.0;
+    const double pmin0 = ((nmin + 1.0) / 2.0) / N0, pmax0 = ((N0 - nmax) + (nmax + 1.0) / 2.0) / N0;  // (as k_qdm_cell parks them)
+    for (int r2 = blockIdx.x * blockDim.x + threadIdx.x; r2 < 2 * n + 2; r2 += gridDim.x * blockDim.x) {
+        const double r = (double)r2 / 2.0;
+        const double pr = r / N0;
+        tab[r2] = (unsigned char)(r2 ? qdm_node_code<R>(pmax0 * (pr - pmin0) / (pmax0 - pmin0), qn, Q) : 255);
+    }
+}
+
+// k_qdm_node_tables' classes as the cell kernel takes them (by value: scalar registers, no loads in the kernel): a group of N valid
+// values with untied extremes takes the table of the class with that N — whatever its row length is (a shorter month's table
+// serves a longer month that lost values to NaNs)
+struct QdmTabs {
+    int K = 0, bytes = 0;  // classes (0: no tables), bytes of all tables
+    int N[16] = {}, off[16] = {};  // the class's count of values, where its table starts in gtab (in units of 16 bytes)
+};
+
+// PASS: the ranking rows are the groups themselves (one group holding every step, or bit 1 of use_tog) — the kernel is instantiated
+// without the walks, which is worth 60 spilled registers to either half
+template <int EPT, typename R = float, bool PASS = false>
 __global__ __launch_bounds__(1024) void k_qdm_cell(
     const R *__restrict__ sim, int64_t T, int64_t C, int64_t sc, const R *__restrict__ af,
     const R *__restrict__ quantiles, int G, int Q, const int *__restrict__ gidx,
@@ -90,7 +148,9 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                   // bit 1: the ranking rows ARE the exact groups (no window), at most 64 of them: ranks by the group-keyed pass (C3)
     int interp, int extrap, int kind, R *__restrict__ scen, double *__restrict__ sim_q,
     int *__restrict__ flag_count, int *__restrict__ flag_list, int max_mem /* most elements any row ranks */,
-    const int *__restrict__ mem_t32 /* [16][G] member slots, two 16-bit time steps per word (0xFFFF: none), or null */)
+    const int *__restrict__ mem_t32 /* [16][G] member slots, two 16-bit time steps per word (0xFFFF: none), or null */,
+    const unsigned char *__restrict__ gtab /* k_qdm_node_tables' tables (never null: any readable address when there are none) */,
+    const QdmTabs gt, const unsigned char *__restrict__ gidx8 /* gidx in bytes (255: no group) when G <= 254, else null */)
 {
     using Cfg = CellCfg<EPT>;
     using QC = QdmCfg<EPT>;
@@ -107,11 +167,15 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
     int *tmeta = reinterpret_cast<int *>(tyfl + 2);     // [0] pairs, [3] bad nodes
     uint32_t *red = reinterpret_cast<uint32_t *>(smem + QC::off_red);
 
-    const int tid = threadIdx.x, wid = tid >> 6;
+    const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // (wave-uniform: what derives from it lives in scalar registers)
     uint32_t *bits = reinterpret_cast<uint32_t *>(smem + QC::off_bits) + wid * BITW;
     uint16_t *pw = reinterpret_cast<uint16_t *>(smem + QC::off_pw) + wid * BITW;
 
+#if XS_QDM_CLK
+    long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
     for (int64_t c = blockIdx.x; c < C; c += gridDim.x) {
+        XS_CLK(7);
         int lane = tid & 63;  // opaque per cell: lane-derived addresses are recomputed, not spilled across the sort
         __asm__ volatile("" : "+v"(lane));
         int nvalid;
@@ -121,13 +185,26 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             sorted = cell_load_sort<EPT>(sim + c * sc, T, smem, red, 0, nvalid, NoLoadHook(), -1, true);
             if (!sorted) sorted = idx1;  // (no valid value: not sorted; nothing below reads the order when nvalid == 0)
         }
+        XS_CLK(0);
         if constexpr (XS_QDM_STOP == 1) { if (sorted[0] == 0xFFFF && tid == 0) flag_count[1] = 1; __syncthreads(); continue; }
         uint16_t *r2buf = (sorted == idx1) ? idx0 : idx1;  // 2 * average rank per time step, 0 = no rank
+        // PASS over several groups: the groups of the elements at this thread's ranks (rank (wid * RND + j) * 64 + lane), requested
+        // here, cross the tie bits / tables phase in flight.  The gather goes through the BYTE copy of gidx: 11 KB stay in the CU's
+        // vector cache, whereas 11 264 scattered reads of the 44 KB of ints pulled a 64-byte sector each from L2 (1.05 of the pass's
+        // 2.8 ms per 64 800 cells).  The order beyond nvalid holds the NaN steps: read, not used.
+        constexpr int RND = TPAD / NT;
+        int gq[PASS ? RND : 1];
+        if constexpr (PASS) {
+            if (use_tog & 2) {
+#pragma unroll
+                for (int j = 0; j < RND; j++) gq[j] = (int)gidx8[min((int)sorted[(((wid * RND) << 6) | lane) + 64 * j], (int)T - 1)];
+            }
+        }
         // two group streams per wave (see C2 below) when the rows walk by the padded toggle table, every wave has groups of its own
         // and a row ranks at most 30 elements (30 years of a day-of-year window): the second stream's vectors take the place of the
         // keys, which are dead once the tie bits are formed — what still needs a value reads the series itself
         const bool have_tb = (size_t)(TPAD / 8) <= (size_t)(QC::GMAX - G) * 24;
-        const bool two = have_tb && G >= NWAVE && (use_tog & 1) && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
+        const bool two = !PASS && have_tb && G >= NWAVE && (use_tog & 1) && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
         const QdmSeries<R> ser{sim + c * sc, keys, sorted, two}, ser_lds{sim + c * sc, keys, sorted, false};
         // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):
         // first rank in [0, r] whose value equals the one at r ...
@@ -175,15 +252,18 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         }
         if (have_tb) {
             // all the index -> key reads of a thread's places first (independent), then the ballots and the stores
+            // (PASS: the thread index rebuilt from the per-cell opaque lane, so that the RND addresses derived from it are formed
+            //  here instead of being kept — spilled — across the whole cell loop)
+            const int tidb = (wid << 6) | lane;
             uint32_t eqm = 0u;
 #pragma unroll
             for (int j = 0; j < TPAD / NT; j++) {
-                const int r = j * NT + tid;
+                const int r = j * NT + tidb;
                 eqm |= (uint32_t)(r > 0 && r < nvalid && ser_lds.eq_ranks(r - 1, r)) << j;
             }
 #pragma unroll
             for (int j = 0; j < TPAD / NT; j++) {
-                const int r = j * NT + tid;
+                const int r = j * NT + tidb;
                 const unsigned long long b = __ballot((eqm >> j) & 1u);
                 if (lane == 0) { tieb[r >> 5] = (uint32_t)b; tieb[(r >> 5) + 1] = (uint32_t)(b >> 32); }
             }
@@ -209,86 +289,128 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         }
         __syncthreads();
 
+        XS_CLK(1);
         if constexpr (XS_QDM_STOP == 2) { if (r2buf[5] == 0xFFFF && tid == 0) flag_count[1] = 1; __syncthreads(); continue; }
         const bool all_time = G == 1 && grp_ptr[1] - grp_ptr[0] == (int)T && mem_ptr[1] - mem_ptr[0] == (int)T;
-        if (all_time) {
-            // ---------------- C0. one group holding every time step: the sorted order is the ranking ----------------
-            for (int r = tid; r < nvalid; r += NT) {
-                int rs, re;
-                tie_run(r, rs, re);
-                r2buf[sorted[r]] = (uint16_t)(rs + re + 1);
+        if constexpr (PASS) {
+            // ---------------- C0 / C3. the ranking rows are the groups themselves: ranks straight from the sorted order ----------------
+            // (one group holding every time step; or a few un-windowed groups — time.month, time.season, ... — with every step in
+            //  one: bit 1 of use_tog)
+            // C3: ONE more stable counting pass of the sorted order, keyed by the group, lays the elements out group by group in
+            // value order — an element's place in its group's segment IS the number of members below it.  No bit-vector is built
+            // or walked (the walk built 912-member vectors per wave and ranked by prefix popcounts: 4.8 of 14.2 ms per 64 800
+            // monthly cells).  C0: the sorted order is the only segment.
+            // Ties: a place is flagged where a segment starts or its value differs from its predecessor's; run start / run end
+            // of every place by a forward max-scan / backward min-scan of the flagged places over the block, the segment start
+            // the same way.  "Differs": C0 reads the tie bits; C3 scatters, with the time step of an element, the index of its
+            // run of equal values in the whole series (its rank minus the tie bits below it) — equal in a segment means equal label.
+            // A thread's places are consecutive (its reads of PK are contiguous); every load of a stage is unconditional and in
+            // flight together (a branch per element made each a round trip of its own: 4.3 ms for this pass instead of 2.8).
+            constexpr int SBW = TPAD / 32 + 2;
+            // (LDS: rank[] and what lies behind it — the walks' vectors and prefix tables, the sort's histogram — all dead here)
+            static_assert(Cfg::off_rank + (size_t)TPAD * 4 + (size_t)(1024 + SBW + 66) * 4 + (size_t)(TPAD / 32) * 2 <= QC::off_gstat,
+                          "elements by place, counters, segment bits, segment starts, tie prefix");
+            uint32_t *PK = reinterpret_cast<uint32_t *>(smem + Cfg::off_rank);   // [place] -> time step | run label << 16
+            uint32_t *wc = PK + TPAD;                                            // [wave][64] counters -> base places
+            uint32_t *SB = wc + 1024;                                            // [SBW] a segment starts at this place
+            int *seg = reinterpret_cast<int *>(SB + SBW);                        // [G + 1] first place of every group's segment
+            uint16_t *TP = reinterpret_cast<uint16_t *>(seg + 66);               // [TPAD / 32] tie bits in the words before this one
+            if (nvalid) {
+            const int tq = (wid << 6) | lane;  // (lane is opaque per cell: what derives from it is recomputed here, not kept across the sort)
+            const bool direct = !(use_tog & 2);  // (the host sends a single all-time group here: all_time holds)
+            wc[tq] = 0u;
+            for (int i = tq; i < SBW; i += NT) SB[i] = 0u;
+            int tp = 0, tincl = 0;
+            if (!direct) {
+                tp = tq < TPAD / 32 ? __popc(tieb[tq]) : 0;
+                tincl = wave_incl_scan(tp);
+                if (lane == 63) red[32 + wid] = (uint32_t)tincl;
             }
-            if (tid == 0 && nvalid) {
-                put_stats(0, nvalid, run_end(0), nvalid - run_begin(nvalid - 1));
-            }
-        } else if (nvalid && (use_tog & 2)) {
-            // ---------------- C3. un-windowed groups (time.month, time.season, ...): a group-keyed stable pass ----------------
-            // The ranking rows are the groups themselves and every valid step belongs to one: ONE more stable counting pass of the
-            // sorted order, keyed by the group, lays the ranks out group by group in value order — an element's place in its
-            // group's segment IS the number of members below it.  No bit-vector is built or walked (the walk built 912-member
-            // vectors per wave and ranked by prefix popcounts: 4.8 of 14.2 ms per 64 800 monthly cells).  Ties: a run of equal
-            // values inside a segment is a run of unflagged places, a place being flagged when a segment starts there or its
-            // value differs from its predecessor's; run start / run end of every place by a forward max-scan / backward
-            // min-scan of the flagged places over the block, the segment start the same way.
-            constexpr int RND = TPAD / NT, GS = 72;
-            // (LDS: behind rank[], where the walks keep their vectors and prefix tables and the sort kept its histogram — all dead here)
-            static_assert(QC::off_bits + (size_t)TPAD * 2 + (size_t)(NWAVE * GS + TPAD / 32 + 72) * 4 <= QC::off_gstat, "ranks by place, counters, flags, segment starts");
-            uint16_t *GR = reinterpret_cast<uint16_t *>(smem + QC::off_bits);   // [place] -> global rank
-            uint32_t *wc = reinterpret_cast<uint32_t *>(GR + TPAD);             // [NWAVE][GS] wave-private counters -> base places
-            uint32_t *SB = wc + NWAVE * GS;                                     // [TPAD / 32] a segment starts at this place
-            int *seg = reinterpret_cast<int *>(SB + TPAD / 32);                 // [G + 1] first place of every group's segment
-            for (int i = tid; i < NWAVE * GS + TPAD / 32; i += NT) wc[i] = 0u;
             __syncthreads();
-            uint32_t *wrow = wc + wid * GS;
-            int gq[RND];
-            uint32_t od[RND];
-#pragma unroll
-            for (int j = 0; j < RND; j++) {
-                const int r = wid * (64 * RND) + 64 * j + lane;
-                gq[j] = r < nvalid ? gidx[sorted[r]] : -1;
-            }
-            // (a wave's returning atomics are served in program order, the lanes of one instruction that hit the same word in
-            //  ascending lane order — train_cell.hpp: the pass is stable)
-#pragma unroll
-            for (int j = 0; j < RND; j++) od[j] = gq[j] >= 0 ? atomicAdd(&wrow[gq[j]], 1u) : 0u;
-            __syncthreads();
-            {   // exclusive scan of the counters in (group, wave) order: thread i owns counter (group i >> 4, wave i & 15)
-                const bool own = tid < NWAVE * G;
-                const uint32_t cv = own ? wc[(tid & 15) * GS + (tid >> 4)] : 0u;
-                const int incl = wave_incl_scan((int)cv);
-                if (lane == 63) red[wid] = (uint32_t)incl;
-                __syncthreads();
-                const int pre = waves_before(red, lane, wid) + incl - (int)cv;
-                if (own) {
-                    wc[(tid & 15) * GS + (tid >> 4)] = (uint32_t)pre;
-                    if ((tid & 15) == 0) { seg[tid >> 4] = pre; atomicOr(&SB[pre >> 5], 1u << (pre & 31)); }
-                    if (tid == NWAVE * G - 1) { seg[G] = pre + (int)cv; atomicOr(&SB[(pre + (int)cv) >> 5], 1u << ((pre + (int)cv) & 31)); }
+            int tt[RND];       // the time step of the element at place p0 + j (a thread owns RND consecutive places)
+            uint32_t fl = 0u;  // bit j: place p0 + j is flagged
+            const int p0 = tq * RND;
+            if (direct) {
+                if (tq == 0) {
+                    seg[0] = 0; seg[1] = nvalid;
+                    atomicOr(&SB[0], 1u);
+                    atomicOr(&SB[nvalid >> 5], 1u << (nvalid & 31));
                 }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int j = 0; j < RND; j++)
-                if (gq[j] >= 0) GR[wrow[gq[j]] + od[j]] = (uint16_t)(wid * (64 * RND) + 64 * j + lane);
-            __syncthreads();
-            const int ntot = seg[G];  // the ranked steps (valid and in a group)
-            // a thread owns RND consecutive places
-            const int p0 = tid * RND;
-            int rr[RND];
-            uint32_t fl = 0u, sbm = 0u;  // bit j: place p0 + j is flagged / starts a segment
-            {
-                int rprev = (p0 > 0 && p0 <= ntot) ? (int)GR[p0 - 1] : -1;
+                const unsigned long long tw = (((unsigned long long)tieb[(p0 >> 5) + 1] << 32) | tieb[p0 >> 5]) >> (p0 & 31);
 #pragma unroll
                 for (int j = 0; j < RND; j++) {
                     const int p = p0 + j;
-                    rr[j] = p < ntot ? (int)GR[p] : -1;
-                    const bool sb = p <= ntot && ((SB[p >> 5] >> (p & 31)) & 1u);
-                    bool f = sb || p == ntot;
-                    if (!f && p < ntot) f = !ser_lds.eq_ranks(rprev, rr[j]);
-                    fl |= (uint32_t)f << j;
-                    sbm |= (uint32_t)sb << j;
-                    rprev = rr[j];
+                    tt[j] = (int)sorted[p];
+                    fl |= (uint32_t)(p < nvalid && !((tw >> j) & 1ull)) << j;
+                }
+                __syncthreads();
+            } else {
+                const int tbefore = waves_before(red + 32, lane, wid);  // (whole waves: cross-lane reads)
+                if (tq < TPAD / 32) TP[tq] = (uint16_t)(tbefore + tincl - tp);
+                // (counters private to sub-waves of 16 lanes — fewer lanes on one counter — measured: no gain)
+                const int rb = ((wid * RND) << 6) | lane;  // this thread's ranks: rb + 64 j
+                uint32_t *wrow = wc + (wid << 6);
+                uint32_t od[RND];
+                // (every load of a stage unconditional and in flight together — a branch per element made each of them a round trip
+                //  of its own)
+#pragma unroll
+                for (int j = 0; j < RND; j++) tt[j] = (int)sorted[rb + 64 * j];
+#pragma unroll
+                for (int j = 0; j < RND; j++) gq[j] = rb + 64 * j < nvalid ? gq[j] : -1;
+                // (a wave's returning atomics are served in program order, the lanes of one instruction that hit the same word in
+                //  ascending lane order — train_cell.hpp: the pass is stable)
+#pragma unroll
+                for (int j = 0; j < RND; j++) od[j] = gq[j] >= 0 ? atomicAdd(&wrow[gq[j]], 1u) : 0u;
+                __syncthreads();
+                {   // exclusive scan of the counters in (group, wave) order
+                    const bool own = tq < (G << 4);
+                    const int cg = tq >> 4, cs = tq & 15;
+                    const int ca = (cs << 6) + cg;
+                    const int cv = own ? (int)wc[ca] : 0;
+                    const int incl = wave_incl_scan(cv);
+                    if (lane == 63) red[wid] = (uint32_t)incl;
+                    __syncthreads();
+                    const int pre = waves_before(red, lane, wid) + incl - cv;
+                    if (own) {
+                        wc[ca] = (uint32_t)pre;
+                        if (cs == 0) { seg[cg] = pre; atomicOr(&SB[pre >> 5], 1u << (pre & 31)); }
+                        if (tq == (G << 4) - 1) { seg[G] = pre + cv; atomicOr(&SB[(pre + cv) >> 5], 1u << ((pre + cv) & 31)); }
+                    }
+                }
+                __syncthreads();
+                {
+                    uint32_t bs[RND], twd[RND], tpv[RND];
+#pragma unroll
+                    for (int j = 0; j < RND; j++) {
+                        const int r = rb + 64 * j;
+                        bs[j] = wrow[max(gq[j], 0)];
+                        twd[j] = tieb[r >> 5];
+                        tpv[j] = TP[r >> 5];
+                    }
+#pragma unroll
+                    for (int j = 0; j < RND; j++) {
+                        const int r = rb + 64 * j;
+                        const int ties = (int)tpv[j] + __popc(twd[j] & (0xFFFFFFFFu >> (31 - (r & 31))));
+                        if (gq[j] >= 0) PK[bs[j] + od[j]] = (uint32_t)tt[j] | ((uint32_t)(r - ties) << 16);
+                    }
+                }
+                __syncthreads();
+                const int ntot_ = seg[G];
+                uint32_t pk[RND + 1];  // (places beyond ntot hold stale words: read, masked by the comparison below)
+                pk[0] = PK[max(p0 - 1, 0)];
+#pragma unroll
+                for (int j = 0; j < RND; j++) pk[j + 1] = PK[p0 + j];
+#pragma unroll
+                for (int j = 0; j < RND; j++) {
+                    tt[j] = (int)(pk[j + 1] & 0xFFFFu);
+                    fl |= (uint32_t)(p0 + j < ntot_ && (pk[j + 1] >> 16) != (pk[j] >> 16)) << j;
                 }
             }
+            const int ntot = seg[G];  // the ranked steps (valid and in a group)
+            // bit j: place p0 + j starts a segment (bit RND: the first place of the next thread does); a segment start is flagged,
+            // and so is the place behind the last one
+            const uint32_t sbm = (uint32_t)(((((unsigned long long)SB[(p0 >> 5) + 1] << 32) | SB[p0 >> 5]) >> (p0 & 31)) & ((2ull << RND) - 1ull));
+            fl |= sbm & ((1u << RND) - 1u);
             // block-wide scans of "the last flagged place at or before" (max, forward) and "the first flagged place behind" (min,
             // backward): per thread over its places, per wave on the DPP path (values + 1 so that 0 is "none"), across the waves
             // through `red`
@@ -301,44 +423,39 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
                 return v;
             };
-            auto block_excl_max = [&](int mine, uint32_t *scr) {  // max of `mine` (>= 0) over the threads before this one
-                const int incl = wave_max_scan(mine);
-                int ex = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, incl);
-                ex = lane ? ex : 0;
-                if (lane == 63) scr[wid] = (uint32_t)incl;
-                __syncthreads();
-                int carry = 0;
-                for (int w = 0; w < NWAVE; w++) carry = w < wid ? max(carry, (int)scr[w]) : carry;
-                __syncthreads();
-                return max(ex, carry);
-            };
             int lastf = 0, lasts = 0;  // (place + 1) of the last flagged place / segment start among this thread's, 0: none
 #pragma unroll
             for (int j = 0; j < RND; j++) {
                 if ((fl >> j) & 1u) lastf = p0 + j + 1;
                 if ((sbm >> j) & 1u) lasts = p0 + j + 1;
             }
-            const int carf = block_excl_max(lastf, red), cars = block_excl_max(lasts, red);
             // backward: the first flagged place of this thread's (as BIG - place so that the max machinery serves), mirrored lanes
             constexpr int BIG = 1 << 20;
             int firstf = 0;
 #pragma unroll
             for (int j = RND - 1; j >= 0; j--)
                 if ((fl >> j) & 1u) firstf = BIG - (p0 + j);
-            int nextf;  // the first flagged place behind this thread's places
+            int carf, cars, nextf;
             {
+                const int inf_ = wave_max_scan(lastf), ins_ = wave_max_scan(lasts);
+                int exf = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, inf_), exs = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, ins_);
+                exf = lane ? exf : 0; exs = lane ? exs : 0;
                 const int mir = __builtin_amdgcn_ds_bpermute((63 - lane) * 4, firstf);
                 const int inclm = wave_max_scan(mir);                       // lane l: max over mirrored lanes <= l = original lanes >= 63 - l
                 int exm = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, inclm);
                 exm = lane ? exm : 0;                                       // mirrored lane l: original lanes > 63 - l
-                const int ex = __builtin_amdgcn_ds_bpermute((63 - lane) * 4, exm);
-                const int wtot = __builtin_amdgcn_readlane(inclm, 63);
-                if (lane == 0) red[wid] = (uint32_t)wtot;
+                const int exb = __builtin_amdgcn_ds_bpermute((63 - lane) * 4, exm);
+                if (lane == 63) { red[wid] = (uint32_t)inf_; red[16 + wid] = (uint32_t)ins_; red[32 + wid] = (uint32_t)inclm; }
                 __syncthreads();
-                int carry = 0;
-                for (int w = 0; w < NWAVE; w++) carry = w > wid ? max(carry, (int)red[w]) : carry;
-                __syncthreads();
-                const int best = max(ex, carry);
+                int cf = 0, cs_ = 0, cb = 0;
+#pragma unroll
+                for (int w = 0; w < NWAVE; w++) {
+                    cf = w < wid ? max(cf, (int)red[w]) : cf;
+                    cs_ = w < wid ? max(cs_, (int)red[16 + w]) : cs_;
+                    cb = w > wid ? max(cb, (int)red[32 + w]) : cb;
+                }
+                carf = max(exf, cf); cars = max(exs, cs_);
+                const int best = max(exb, cb);
                 nextf = best ? BIG - best : ntot;
             }
             {
@@ -355,9 +472,8 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     const int p = p0 + j;
                     if (p < ntot) {
                         const int re = nx;  // the run of place p ends where the next flagged place is
-                        const int t = (int)sorted[rr[j]];
-                        r2buf[t] = (uint16_t)((rs[j] - sg[j]) + (re - sg[j]) + 1);
-                        const bool first = (sbm >> j) & 1u, lastp = (SB[(p + 1) >> 5] >> ((p + 1) & 31)) & 1u;
+                        r2buf[tt[j]] = (uint16_t)((rs[j] - sg[j]) + (re - sg[j]) + 1);
+                        const bool first = (sbm >> j) & 1u, lastp = (sbm >> (j + 1)) & 1u;
                         if (first || lastp) {
                             // the group of this place: the last one whose segment starts at or before it
                             int lo = 0, hi = G - 1;
@@ -369,6 +485,17 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                     }
                     if ((fl >> j) & 1u) nx = p;
                 }
+            }
+            }  // (nvalid)
+        } else if (all_time) {
+            // ---------------- C0 by bisection (not reached from the host, which takes the pass for such a group) ----------------
+            for (int r = tid; r < nvalid; r += NT) {
+                int rs, re;
+                tie_run(r, rs, re);
+                r2buf[sorted[r]] = (uint16_t)(rs + re + 1);
+            }
+            if (tid == 0 && nvalid) {
+                put_stats(0, nvalid, run_end(0), nvalid - run_begin(nvalid - 1));
             }
         } else if (nvalid && two) {
             // ---------------- C2. the walk of C with TWO group streams per wave ----------------
@@ -629,105 +756,159 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             }
         }
         __syncthreads();
+        XS_CLK(2);
         if constexpr (XS_QDM_STOP == 3) { if (r2buf[5] == 0xFFFF && tid == 0) flag_count[1] = 1; __syncthreads(); continue; }
-        for (int g = tid; g < G; g += NT) {
-            const int *gi = reinterpret_cast<const int *>(gstat + 3 * g);
-            const double N = (double)gi[0], nmin = (double)gi[2], nmax = (double)gi[4];
-            gstat[3 * g] = N;
-            gstat[3 * g + 1] = ((nmin + 1.0) / 2.0) / N;
-            gstat[3 * g + 2] = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
+        // Grouped tables, no sim_q wanted: the node a percent rank maps to depends on (2r, N, pmin, pmax) only.  A group of N valid
+        // values with untied extremes takes the table k_qdm_node_tables made for its row length (mode 2: nothing is built here);
+        // of the others, those that share the middle group's triple take a table built for this cell (mode 1) with the very
+        // expressions evaluated per element below (two float64 divisions and a bisection each); the rest go element by element
+        // (mode 0).  Modes, table offsets and the cell's table live in the unused tail of gstat (groups beyond G).
+        const int tidd = (wid << 6) | lane;  // (the thread index from the per-cell opaque lane: what derives from it is formed here, not kept — spilled — across the cell loop)
+        const bool bad_nodes = af && G > 1 && tmeta[3];
+        const int Gp = (G + 15) & ~15;
+        unsigned char *gmode = reinterpret_cast<unsigned char *>(gstat + 3 * G);   // bits 0-1: 0 / 1 (table in LDS) / 2 (in gtab); bit 2: the launch's
+        uint16_t *goff = reinterpret_cast<uint16_t *>(gmode + Gp);                  // where the group's table starts, in units of 16 bytes
+        unsigned char *tabL = gmode + 3 * Gp;                                       // (8-byte aligned)
+        const size_t room = (size_t)(QC::GMAX - G) * 24;
+        const bool tabs = af && G > 1 && !sim_q && !bad_nodes && Q <= 63 && (size_t)(3 * Gp) <= room;
+        const R *afc = af ? af + (size_t)c * G * Q : nullptr;
+        // The launch's tables are copied into the LDS when they fit (12 monthly groups: 5.6 KB; a day-of-year row: 1.9 KB), and so
+        // is the cell's factor table (12 x 20 factors; not 365 x 20): a table byte or a factor fetched from global memory costs a
+        // divergent 64-lane gather each, and the two of them in sequence were most of this pass.  Requested here, stored before the
+        // barrier that ends the conversion below: their latency lies under it.
+        const int cp_bytes = (tabs && gt.K > 0 && (size_t)(3 * Gp) + (size_t)gt.bytes <= room) ? gt.bytes : 0;
+        const int af_bytes = (G * Q * (int)sizeof(R) + 15) & ~15;
+        const bool af_l = tabs && (size_t)(3 * Gp) + (size_t)cp_bytes + (size_t)af_bytes <= room;
+        R *afL = reinterpret_cast<R *>(tabL + cp_bytes);
+        const int loc_off = cp_bytes + (af_l ? af_bytes : 0);
+        // (room <= 12 KB: at most two 8-byte pieces of the tables and three factors per thread; loaded here, stored behind the
+        //  conversion)
+        uint2 cpv[2];
+        R afv[3];
+#pragma unroll
+        for (int i = 0; i < 2; i++) cpv[i] = tidd + i * NT < cp_bytes / 8 ? reinterpret_cast<const uint2 *>(gtab)[tidd + i * NT] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int i = 0; i < 3; i++) afv[i] = (af_l && tidd + i * NT < G * Q) ? afc[tidd + i * NT] : (R)0;
+        // the groups of this thread's time steps (tidd + j * NT), for the element pass below: requested here, they cross the conversion
+        int ggA[RND];
+        if (tabs) {
+#pragma unroll
+            for (int u = 0; u < RND; u++) ggA[u] = gidx[min(tidd + u * NT, (int)T - 1)];
         }
-        __syncthreads();
+        int kinds = 0;  // bit 0: a group with values that the launch's tables do not serve, bit 1: one that they do
+        for (int g = tidd; g < G; g += NT) {
+            const int *gi = reinterpret_cast<const int *>(gstat + 3 * g);
+            const int ni = gi[0], nmini = gi[2], nmaxi = gi[4];
+            int cls_off = -1;  // the launch's table for (ni, 1, 1), if there is one
+            if (tabs && ni > 0 && nmini == 1 && nmaxi == 1)
+                for (int k = 0; k < gt.K; k++) cls_off = gt.N[k] == ni ? gt.off[k] : cls_off;
+            if (tabs) {
+                gmode[g] = cls_off >= 0 ? (cp_bytes ? 5 : 6) : 0;
+                goff[g] = (uint16_t)max(cls_off, 0);
+                kinds |= ni > 0 ? (cls_off >= 0 ? 2 : 1) : 0;
+            }
+            // (the float64 triple only where something reads it: element by element, or the cell's own table)
+            const double N = (double)ni, nmin = (double)nmini, nmax = (double)nmaxi;
+            gstat[3 * g] = N;
+            if (cls_off < 0) {
+                gstat[3 * g + 1] = ((nmin + 1.0) / 2.0) / N;
+                gstat[3 * g + 2] = ((N - nmax) + (nmax + 1.0) / 2.0) / N;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+            if (tidd + i * NT < cp_bytes / 8) reinterpret_cast<uint2 *>(tabL)[tidd + i * NT] = cpv[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            if (af_l && tidd + i * NT < G * Q) afL[tidd + i * NT] = afv[i];
+        kinds = (__syncthreads_or(kinds & 1) ? 1 : 0) | (__syncthreads_or(kinds & 2) ? 2 : 0);  // (the barrier's OR is of predicates, not of bits)
+        XS_CLK(3);
 
         // ---------------- D. percent ranks, interpolation on the quantile axis, apply (coalesced) ----------------
         bool flag_cell = false;
         const int tab_n = tmeta[0];
         const R tab_yf = tyfl[0], tab_yl = tyfl[1];
-        const bool bad_nodes = af && G > 1 && tmeta[3];
-        const R *afc = af ? af + (size_t)c * G * Q : nullptr;
-        // Grouped tables, no sim_q wanted: the node a percent rank maps to depends on (2r, N, pmin, pmax) only, and most groups
-        // share the middle group's triple (full windows, untied extremes).  Its map 2r -> node is tabulated once per cell with
-        // the very expressions evaluated per element below (two float64 divisions and a bisection each); an element of such a
-        // group costs one table byte.  The table lives in the unused tail of gstat (groups beyond G).
-        unsigned char *tabD = reinterpret_cast<unsigned char *>(gstat + 3 * G);
         const double N0 = gstat[3 * (G / 2)], pmin0 = gstat[3 * (G / 2) + 1], pmax0 = gstat[3 * (G / 2) + 2];
         const int n0 = (int)N0;
         const int tab_len = (2 * n0 + 2 + 15) & ~15;
-        const bool use_tab = af && G > 1 && !sim_q && !bad_nodes && n0 > 0 && (size_t)(tab_len + G) <= (size_t)(QC::GMAX - G) * 24 && Q <= 63;
-        unsigned char *gsame = tabD + tab_len;  // per group: its (N, pmin, pmax) is the middle group's — its elements take the table
-        auto node_code = [&](double sq) -> int {  // 255: NaN; else node | 0x40 below the first node | 0x80 above the last
-            if (sq != sq) return 255;
-            if (sq < (double)qn[0]) return 0x40;
-            if (sq > (double)qn[Q - 1]) return (Q - 1) | 0x80;
-            int w;
-            (void)row_nearest<R, double>(sq, qn, Q, &w);
-            return w;
-        };
-        if (use_tab) {
-            for (int r2 = tid; r2 < 2 * n0 + 2; r2 += NT) {
+        const bool use_loc = tabs && (kinds & 1) && n0 > 0 && (size_t)(3 * Gp + loc_off + tab_len) <= room && !(gmode[G / 2] & 4);
+        const bool use_tab = tabs && (use_loc || (kinds & 2));
+        auto node_code = [&](double sq) -> int { return qdm_node_code<R>(sq, qn, Q); };
+        if (use_loc) {
+            unsigned char *tabD = tabL + loc_off;
+            for (int r2 = tidd; r2 < 2 * n0 + 2; r2 += NT) {
                 const double r = (double)r2 / 2.0;
                 const double pr = r / N0;
                 tabD[r2] = (unsigned char)(r2 ? node_code(pmax0 * (pr - pmin0) / (pmax0 - pmin0)) : 255);
             }
-            for (int g = tid; g < G; g += NT) gsame[g] = (unsigned char)(gstat[3 * g] == N0 && gstat[3 * g + 1] == pmin0 && gstat[3 * g + 2] == pmax0);
+            for (int g = tidd; g < G; g += NT)
+                if (!(gmode[g] & 4)) {
+                    gmode[g] = (unsigned char)(gstat[3 * g] == N0 && gstat[3 * g + 1] == pmin0 && gstat[3 * g + 2] == pmax0);
+                    goff[g] = (uint16_t)(loc_off / 16);
+                }
             __syncthreads();
         }
+        XS_CLK(4);
         if (af && use_tab) {
-            // NB elements per thread and round, every load of a stage in flight together: element by element the pass is a chain of
-            // dependent round trips (group index -> group triple -> table byte -> factor -> store) and took 4.7 of the kernel's 18.5 ms;
-            // four at a time 4.2 ms; all eleven at once spill (19.3 ms for the kernel)
-            constexpr int NB = 8;
-            for (int t0 = tid; t0 < (int)T; t0 += NB * NT) {
-                int gg[NB], rr[NB], code[NB];
-                bool in[NB];
-                R vv[NB], aa[NB];
+            // All of a thread's (at most RND) elements at once, stage by stage, every load of a stage in flight together: element by
+            // element the pass is a chain of dependent round trips (group index -> mode -> table byte -> factor -> store) that all
+            // sixteen waves of the block walk in lock-step behind the barrier above — nobody computes while anybody waits.  The
+            // group indexes were requested before the conversion (ggA).
+            // Free of branches in the common case (the pass was ~100 instructions per element, 40 of them scalar control flow
+            // around guards): a time step beyond the series repeats the last one and is not stored; an element without a rank or a
+            // group is code 255 at once; the tables and the factors are read through FLAT pointers (LDS copy or global memory,
+            // lane by lane for the tables); the float64 evaluation runs only in a wave that holds an element of a mode-0 group.
+            R *const scen_c = scen + (size_t)c * T;
+            const R *const ap = af_l ? (const R *)afL : afc;
+            const unsigned char *const tl = tabL;
+            int rr[RND], code[RND], mb[RND], go[RND];
+            R vv[RND], aa[RND];
 #pragma unroll
-                for (int u = 0; u < NB; u++) {
-                    const int t = t0 + u * NT;
-                    in[u] = t < (int)T;
-                    const int tc = in[u] ? t : 0;
-                    gg[u] = gidx ? gidx[tc] : 0;
-                    rr[u] = r2buf[tc];
-                    vv[u] = ser.at_time(tc);
-                }
+            for (int u = 0; u < RND; u++) {
+                const int tc = min(tidd + u * NT, (int)T - 1);
+                rr[u] = r2buf[tc];
+                vv[u] = ser.at_time(tc);
+            }
 #pragma unroll
-                for (int u = 0; u < NB; u++) {
-                    const bool same = gsame[max(gg[u], 0)] != 0;
-                    const int cd = tabD[rr[u]];
-                    code[u] = (rr[u] && gg[u] >= 0 && same) ? cd : -1;
-                }
+            for (int u = 0; u < RND; u++) {
+                const int gc = max(ggA[u], 0);
+                mb[u] = gmode[gc] & 3;
+                go[u] = (int)goff[gc] * 16 + rr[u];
+            }
 #pragma unroll
-                for (int u = 0; u < NB; u++)
-                    if (in[u] && code[u] < 0) {  // (rare: a group whose triple differs, an element without a rank or a group)
-                        double sq = __builtin_nan("");
-                        const int g = gg[u];
-                        if (rr[u] && g >= 0) {
-                            const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
-                            const double r = (double)rr[u] / 2.0;
-                            const double pr = r / N;
-                            sq = pmax * (pr - pmin) / (pmax - pmin);
-                        }
-                        code[u] = g >= 0 ? node_code(sq) : 255;
+            for (int u = 0; u < RND; u++) code[u] = *((mb[u] == 2 ? gtab : tl) + (mb[u] ? go[u] : 0));
+            bool slow = false;
+#pragma unroll
+            for (int u = 0; u < RND; u++) {
+                const bool ranked = rr[u] != 0 && ggA[u] >= 0;
+                code[u] = ranked ? (mb[u] ? code[u] : -1) : 255;
+                slow |= code[u] < 0;
+            }
+            if (__any(slow)) {  // (a group whose triple is neither the launch's nor the middle group's)
+#pragma unroll
+                for (int u = 0; u < RND; u++)
+                    if (code[u] < 0) {
+                        const int g = ggA[u];
+                        const double N = gstat[3 * g], pmin = gstat[3 * g + 1], pmax = gstat[3 * g + 2];
+                        const double r = (double)rr[u] / 2.0;
+                        const double pr = r / N;
+                        code[u] = node_code(pmax * (pr - pmin) / (pmax - pmin));
                     }
+            }
 #pragma unroll
-                for (int u = 0; u < NB; u++) {
-                    const bool have = in[u] && code[u] != 255;
-                    aa[u] = have ? afc[(size_t)gg[u] * Q + (code[u] & 0x3F)] : nan_of<R>();
-                }
+            for (int u = 0; u < RND; u++) aa[u] = ap[code[u] != 255 ? max(ggA[u], 0) * Q + (code[u] & 0x3F) : 0];
 #pragma unroll
-                for (int u = 0; u < NB; u++) {
-                    R a = aa[u];
-                    if (in[u] && code[u] != 255) {
-                        flag_cell |= a != a;
-                        if ((code[u] & 0xC0) && extrap != 0) a = nan_of<R>();
-                    }
-                    // (streaming store: the result must not push this CU's series out of the L2 before pass D has read it again —
-                    //  the keys have left the LDS in the two-stream walk)
-                    if (in[u]) __builtin_nontemporal_store(apply_corr<R>(vv[u], a, kind), &scen[(size_t)c * T + (t0 + u * NT)]);
-                }
+            for (int u = 0; u < RND; u++) {
+                const bool have = code[u] != 255;
+                R a = have ? aa[u] : nan_of<R>();
+                flag_cell |= have && a != a;
+                if (have && (code[u] & 0xC0) && extrap != 0) a = nan_of<R>();
+                // (streaming store: the result must not push this CU's series out of the L2 before pass D has read it again —
+                //  the keys have left the LDS in the two-stream walk)
+                if (tidd + u * NT < (int)T) __builtin_nontemporal_store(apply_corr<R>(vv[u], a, kind), &scen_c[(unsigned)(tidd + u * NT)]);
             }
         } else  // (sim_q wanted, a single group, or no room for the table: element by element)
-        for (int t = tid; t < (int)T; t += NT) {
+        for (int t = tidd; t < (int)T; t += NT) {
             const int g = gidx ? gidx[t] : 0;
             const int r2 = r2buf[t];
             const R v = ser.at_time(t);
@@ -760,12 +941,19 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             }
         }
         // cells whose own-row shortcut does not hold are queued for the generic kernel
+        XS_CLK(5);
         const int any = __syncthreads_or((flag_cell || bad_nodes) ? 1 : 0);
+        XS_CLK(6);
         if (any && tid == 0) {
             const int slot = atomicAdd(flag_count, 1);
             flag_list[slot] = (int)c;
         }
     }
+#if XS_QDM_CLK
+    if (blockIdx.x == 0 && tid == 0)
+        printf("k_qdm_cell clocks: sort %lld  tiebits %lld  ranks %lld  convert %lld  table %lld  elements %lld  endbar %lld  looptop %lld\n", clk_[0], clk_[1], clk_[2],
+               clk_[3], clk_[4], clk_[5], clk_[6], clk_[7]);
+#endif
 }
 
 }  // namespace xs
