@@ -40,6 +40,7 @@ WORKLOADS = {
     "dqm_doy31": ("dqm", "dayofyear", 31, "+", 0),
     "qdm_doy31": ("qdm", "dayofyear", 31, "*", 1),
     "qdm_doy31_rw": ("qdm", "dayofyear", 31, "*", 1),  # BASELINE configs[3], second mode: rank_window=True
+    "qdm_month": ("qdm", "month", 1, "*", 1),  # QDM over un-windowed groups (ranks straight from the sorted order)
     # BASELINE configs[4]: 60 years daily, 30 % of the cells all-NaN ("ocean") + 1 % i.i.d. NaN elsewhere (run it with
     # --days 21900; cells per GPU as memory allows)
     "dqm_doy31_nan": ("dqm", "dayofyear", 31, "+", 0),
@@ -142,7 +143,7 @@ def main():
     gidx, G = group_index(group, T)
     q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
     tnum = (np.arange(T, dtype=np.float64) + 10950.0) * 86400e9
-    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3, "qdm_doy31_rw": 3, "dqm_doy31_nan": 4}.get(args.workload, 1)
+    seed = {"eqm_time": 0, "eqm_month": 1, "dqm_doy31": 2, "qdm_doy31": 3, "qdm_doy31_rw": 3, "dqm_doy31_nan": 4, "qdm_month": 5}.get(args.workload, 1)
     cell0 = rank * C
     ncf, nif = NAN_MASK.get(args.workload, (0.0, 0.0))
     ref = ctx.synth((C, T), np.float32, gen, 0, seed, cell0, ncf, nif, time_major=args.time_major)
