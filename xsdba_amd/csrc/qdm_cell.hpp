@@ -206,27 +206,47 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         const bool have_tb = (size_t)(TPAD / 8) <= (size_t)(QC::GMAX - G) * 24;
         const bool two = !PASS && have_tb && G >= NWAVE && (use_tog & 1) && tog64 != nullptr && max_mem <= 30 && mem_t32 != nullptr;
         const QdmSeries<R> ser{sim + c * sc, keys, sorted, two}, ser_lds{sim + c * sc, keys, sorted, false};
+        // tie bits: bit r set when the values at ranks r - 1 and r are equal — formed once per cell, in parallel, in the unused
+        // tail of gstat (shared with pass D's node table, which is built later): a tie test in the group walk is then one LDS
+        // read instead of two dependent index -> key round trips per side (the walk waits on LDS latency, not on issue)
+        uint32_t *tieb = reinterpret_cast<uint32_t *>(gstat + 3 * G);
+        auto tbit = [&](int r) { return (tieb[r >> 5] >> (r & 31)) & 1u; };
+        // ... and, per word of tie bits, where the run that reaches into the word from below starts (WS) and where the run that
+        // leaves it at the top ends (WE): the run of any rank is then two bit scans in its own word, or one of the two entries —
+        // no search.  (Round 5: the runs were found by BISECTION over index -> value reads, 14 dependent steps — global loads once
+        // the keys have left the LDS in the two-stream walk — in whichever lanes met a tie: measured data are full of ties (values
+        // rounded to 0.01: the day-of-year rank_window kernel took 1.8 x its time on continuous values, zero-inflated: 2.2 x).)
+        const bool have_runs = !PASS && have_tb && (size_t)(TPAD / 8) + (size_t)(TPAD / 32) * 4 + 16 <= (size_t)(QC::GMAX - G) * 24;
+        uint16_t *WS = reinterpret_cast<uint16_t *>(tieb + TPAD / 32 + 2), *WE = WS + TPAD / 32;
         // the run of equal values around rank r (the order is non-decreasing, so equality with r is monotone on each side):
         // first rank in [0, r] whose value equals the one at r ...
         auto run_begin = [&](int r) {
+            if (have_runs) {
+                const int w = r >> 5;
+                const uint32_t zl = ~tieb[w] & (0xFFFFFFFFu >> (31 - (r & 31)));  // run starts at or below r in its word
+                const int ws = (int)WS[w];
+                return zl ? (w << 5) + 31 - __clz((int)zl) : ws;
+            }
             int lo = 0, hi = r;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (ser.eq_ranks(mid, r)) hi = mid; else lo = mid + 1; }
             return lo;
         };
         // ... and first rank in (r, nvalid] whose value differs (nvalid if none)
         auto run_end = [&](int r) {
+            if (have_runs) {
+                const int w = r >> 5;
+                const uint32_t zh = ~tieb[w] & (0xFFFFFFFEu << (r & 31));  // run starts above r in its word (the bits past nvalid are clear)
+                const int we = (int)WE[w];
+                return zh ? (w << 5) + __ffs((int)zh) - 1 : we;
+            }
             int lo = r + 1, hi = nvalid;
             while (lo < hi) { int mid = (lo + hi) >> 1; if (ser.eq_ranks(mid, r)) lo = mid + 1; else hi = mid; }
             return lo;
         };
-        // tie bits: bit r set when the values at ranks r - 1 and r are equal — formed once per cell, in parallel, in the unused
-        // tail of gstat (shared with pass D's node table, which is built later): a tie test in the group walk is then one LDS
-        // read instead of two dependent index -> key round trips per side (the walk waits on LDS latency, not on issue)
-        uint32_t *tieb = reinterpret_cast<uint32_t *>(gstat + 3 * G);
-        auto tbit = [&](int r) { return (tieb[r >> 5] >> (r & 31)) & 1u; };
         auto tie_run = [&](int r, int &rs, int &re) {
             rs = r; re = r + 1;
-            if (have_tb) {
+            if (have_runs) { rs = run_begin(r); re = run_end(r); }
+            else if (have_tb) {
                 const bool tp = r > 0 && tbit(r), tn = re < nvalid && tbit(re);
                 if (tp) rs = run_begin(r);
                 if (tn) re = run_end(r);
@@ -288,6 +308,47 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             }
         }
         __syncthreads();
+        if (have_runs) {
+            // WS / WE from the finished tie words: an exclusive prefix maximum of "the highest run start in the word" (wave 0, the
+            // words in ascending order) and an exclusive suffix minimum of "the lowest one" (wave 1, descending: as a maximum of
+            // BIG - position), 64 words at a time on the DPP path, the carry in a scalar.  Positions + 1, 0 = none.
+            auto wave_max_scan = [&](int v) {  // inclusive, v >= 0
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));
+                v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));
+                return v;
+            };
+            constexpr int NW32 = TPAD / 32, BIG = 1 << 20;
+            if (wid == 0) {
+                int carry = 0;
+                for (int ch = 0; ch < NW32; ch += 64) {
+                    const int w = ch + lane;
+                    const uint32_t z = w < NW32 ? ~tieb[w] : 0u;
+                    const int v = z ? (w << 5) + 31 - __clz((int)z) + 1 : 0;
+                    const int incl = wave_max_scan(v);
+                    int ex = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, incl);
+                    ex = max(lane ? ex : 0, carry);
+                    if (w < NW32) WS[w] = (uint16_t)max(ex - 1, 0);
+                    carry = max(carry, __builtin_amdgcn_readlane(incl, 63));
+                }
+            } else if (wid == 1) {
+                int carry = 0;
+                for (int ch = ((NW32 - 1) / 64) * 64; ch >= 0; ch -= 64) {
+                    const int w = ch + 63 - lane;  // (descending with the lane)
+                    const uint32_t z = w < NW32 ? ~tieb[w] : 0u;
+                    const int v = z ? BIG - ((w << 5) + __ffs((int)z) - 1) : 0;
+                    const int incl = wave_max_scan(v);
+                    int ex = __builtin_amdgcn_ds_bpermute(((lane + 63) & 63) * 4, incl);
+                    ex = max(lane ? ex : 0, carry);
+                    if (w < NW32) WE[w] = (uint16_t)(ex ? min(BIG - ex, nvalid) : nvalid);
+                    carry = max(carry, __builtin_amdgcn_readlane(incl, 63));
+                }
+            }
+            __syncthreads();
+        }
 
         XS_CLK(1);
         if constexpr (XS_QDM_STOP == 2) { if (r2buf[5] == 0xFFFF && tid == 0) flag_count[1] = 1; __syncthreads(); continue; }
