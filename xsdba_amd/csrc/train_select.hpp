@@ -265,12 +265,39 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
             kmx1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kmx1);
             const bool any_valid = kmx1 != 0u;
             const uint32_t kmax = kmx1 - 1u;
-            const uint32_t range = any_valid ? kmax - kmin : 0u;
+            // Where the bins start.  A series whose minimum is an exact zero (zero-inflated precipitation: the zeros are counted
+            // apart anyway) starts them at its smallest value ABOVE zero: key(0) lies 2^30 keys below key(1e-3), so that a range
+            // from zero left ~60 of a group's 1024 bins to all the values between 1 and 100 — runs beyond the in-register sort,
+            // and the cell went to the generic kernel (EQM time.month on such data: 5 x the time).  One more block reduction,
+            // only for such series (block-uniform).
+            uint32_t kbase = kmin;
+            if (any_valid && kmin == 0x80000000u) {
+                uint32_t k2 = MAXK;
+#pragma unroll
+                for (int e = 0; e < NE; e++) k2 = min(k2, key[e] > kmin ? key[e] : MAXK);
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x111, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x112, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x114, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x118, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x142, 0xa, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k2, 0x143, 0xc, 0xf, false));
+                __syncthreads();  // (everyone has read the extremes)
+                if (lane == 63) red[16 + wid] = k2;
+                __syncthreads();
+                k2 = red[16 + (lane & 7)];
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp((int)k2, (int)k2, 0x124, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp((int)k2, (int)k2, 0x122, 0xf, 0xf, false));
+                k2 = min(k2, (uint32_t)__builtin_amdgcn_update_dpp((int)k2, (int)k2, 0x121, 0xf, 0xf, false));
+                k2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k2);
+                if (k2 < kmax) kbase = k2;  // (else: nothing lies strictly between the extremes, nothing is binned)
+            }
+            const uint32_t boff = kbase - kmin;
+            const uint32_t range = any_valid ? kmax - kbase : 0u;
             const int nbits = range ? 32 - __clz((int)range) : 0;
             const int shift = max(0, nbits - log2nb);
             // an element lies strictly between the extremes <=> (key - kmin) - 1 < hi (unsigned: kmin itself wraps around,
             // kmax and the missing values are >= hi)
-            const uint32_t hi = range ? range - 1u : 0u;
+            const uint32_t hi = (any_valid && kmax != kmin) ? (kmax - kmin) - 1u : 0u;
             if (XS_SEL_STOP == 1) { if (kmin == 12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
             // ---------------- B. counting pass ----------------
@@ -285,7 +312,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
                 const uint32_t rel = k - kmin;
                 if (rel - 1u < hi) {
-                    const uint32_t b = (g << log2nb) + (rel >> shift);
+                    const uint32_t b = (g << log2nb) + ((rel - boff) >> shift);
                     (void)__hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (k != MAXK) {
                     // the extreme values (plain atomics: long runs of them serialise on one LDS word — about twice the time
@@ -343,7 +370,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                     const uint32_t rel = k - kmin;
                     ret[e] = 0xFFFFFFFFu;
                     if (rel - 1u < hi) {
-                        const uint32_t b = (g << log2nb) + (rel >> shift);
+                        const uint32_t b = (g << log2nb) + ((rel - boff) >> shift);
                         const uint32_t old = __hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         ret[e] = (old >> ((b << 4) & 31u)) & 0xFFFFu;
                     }
@@ -417,8 +444,8 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                         const int pa = gstart + ((need0 ? od : o1) - nlo);  // the first position that has to be read
                         const int b = bin_of(pa);
                         if (!scattered) {
-                            const uint32_t kb = kmin + (uint32_t)b;
-                            if (need0) { k0 = kb; if (need1) k1 = kmin + (uint32_t)bin_of(pa + 1); }
+                            const uint32_t kb = kbase + (uint32_t)b;
+                            if (need0) { k0 = kb; if (need1) k1 = kbase + (uint32_t)bin_of(pa + 1); }
                             else k1 = kb;
                         } else {
                             const int s0 = b > 0 ? (int)tab[b - 1] : gstart, e0 = (int)tab[b];
