@@ -4,7 +4,7 @@
 // The reference sorts every group row to read 2*Q order statistics off it (nbutils.py:113-148: arr.sort(), then the
 // neighbours of Q virtual indexes).  Only those order statistics are needed, so the kernel
 //   A. brings the cell's series from HBM into REGISTERS (order-preserving keys, 2*EPT2 per thread), min / max;
-//   B. counts: hist[group][bin] (packed u16 LDS atomics), bin = (key - kmin) >> shift over the occupied key range
+//   B. counts: hist[group][bin] (packed u16 LDS atomics), bin = (key - kbase) >> shift over the occupied key range (kbase: the key above the minimum)
 //      (equal-width bins in key space); the values equal to kmin or kmax are counted apart per group (zero-inflated
 //      precipitation, capped humidity: they would be long runs of equal keys inside one bin);
 //   C. scans the histogram into absolute start positions (each thread a run of bins, block scan of the thread totals);
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
             // from zero left ~60 of a group's 1024 bins to all the values between 1 and 100 — runs beyond the in-register sort,
             // and the cell went to the generic kernel (EQM time.month on such data: 5 x the time).  One more block reduction,
             // only for such series (block-uniform).
-            uint32_t kbase = kmin;
+            uint32_t kbase = kmin + 1u;  // (the first key that is binned: the minimum itself is counted apart)
             if (any_valid && kmin == 0x80000000u) {
                 uint32_t k2 = MAXK;
 #pragma unroll
@@ -291,13 +291,11 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 k2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k2);
                 if (k2 < kmax) kbase = k2;  // (else: nothing lies strictly between the extremes, nothing is binned)
             }
-            const uint32_t boff = kbase - kmin;
-            const uint32_t range = any_valid ? kmax - kbase : 0u;
-            const int nbits = range ? 32 - __clz((int)range) : 0;
+            // an element lies strictly between the extremes <=> key - kbase < hi (unsigned: the minimum and whatever lies below
+            // kbase wrap around, kmax and the missing values are >= hi)
+            const uint32_t hi = (any_valid && kmax > kbase) ? kmax - kbase : 0u;
+            const int nbits = hi ? 32 - __clz((int)hi) : 0;
             const int shift = max(0, nbits - log2nb);
-            // an element lies strictly between the extremes <=> (key - kmin) - 1 < hi (unsigned: kmin itself wraps around,
-            // kmax and the missing values are >= hi)
-            const uint32_t hi = (any_valid && kmax != kmin) ? (kmax - kmin) - 1u : 0u;
             if (XS_SEL_STOP == 1) { if (kmin == 12345u) out_hq[0] = 0.f; __syncthreads(); continue; }
 
             // ---------------- B. counting pass ----------------
@@ -310,14 +308,14 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                 __asm__ volatile("" : "+v"(key[e]));  // (nothing derived from the keys stays live from pass to pass)
                 const uint32_t k = key[e];
                 const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
-                const uint32_t rel = k - kmin;
-                if (rel - 1u < hi) {
-                    const uint32_t b = (g << log2nb) + ((rel - boff) >> shift);
+                const uint32_t rel = k - kbase;
+                if (rel < hi) {
+                    const uint32_t b = (g << log2nb) + (rel >> shift);
                     (void)__hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else if (k != MAXK) {
                     // the extreme values (plain atomics: long runs of them serialise on one LDS word — about twice the time
                     // of a run-free cell on zero-inflated data, still several times faster than sorting)
-                    (void)__hip_atomic_fetch_add(&gmass[2 * g + (rel != 0u ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    (void)__hip_atomic_fetch_add(&gmass[2 * g + (k != kmin ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             __syncthreads();
@@ -367,10 +365,10 @@ __global__ __launch_bounds__(SEL_NT, (EPT2 <= 11 ? 4 : 2)) void k_train_sel(
                     __asm__ volatile("" : "+v"(key[e]));
                     const uint32_t k = key[e];
                     const uint32_t g = (gpk[e >> 2] >> (8 * (e & 3))) & 255u;
-                    const uint32_t rel = k - kmin;
+                    const uint32_t rel = k - kbase;
                     ret[e] = 0xFFFFFFFFu;
-                    if (rel - 1u < hi) {
-                        const uint32_t b = (g << log2nb) + ((rel - boff) >> shift);
+                    if (rel < hi) {
+                        const uint32_t b = (g << log2nb) + (rel >> shift);
                         const uint32_t old = __hip_atomic_fetch_add(&hist[b >> 1], 1u << ((b << 4) & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         ret[e] = (old >> ((b << 4) & 31u)) & 0xFFFFu;
                     }
