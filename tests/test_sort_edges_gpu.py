@@ -167,3 +167,45 @@ def test_partial_year_series_empty_middle_groups(hip):
     eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, 365, 31, q, "+")
     assert_close(sc, esc, rtol=2.4e-7, atol=1e-4, what="scaling with gaps")
     assert_close(hq, ehq, rtol=2.4e-7, atol=1e-4, what="dqm hist_q with gaps")
+
+
+@pytest.mark.parametrize("T", [3650, 7300, 10950])
+@pytest.mark.parametrize("kind", ["zero_half", "two_values", "zero_most_wide", "runs_of_64"])
+def test_heavily_tied_series_with_wide_keys(hip, kind, T):
+    """hundreds of equal keys in a series whose key range still needs the stable passes: whole waves of one digit take their 64
+    slots with one atomic (the sort's `heavy` path) — EQM / DQM tables and QDM ranks bit for bit against the oracle"""
+    rng = np.random.default_rng(len(kind) * 77 + T)
+    C = 3
+
+    def make():
+        a = rng.gamma(2.0, 8.0, (C, T)).astype(np.float32) + np.float32(1e-3)
+        if kind == "zero_half":
+            a[rng.random((C, T)) < 0.5] = 0.0
+        elif kind == "two_values":
+            a[rng.random((C, T)) < 0.45] = 0.0
+            a[rng.random((C, T)) < 0.45] = 7.5
+        elif kind == "zero_most_wide":   # 90 % zeros, the rest over 60 binades of both signs
+            w = (rng.standard_normal((C, T)) * np.exp2(rng.integers(-30, 30, (C, T)))).astype(np.float32)
+            a = np.where(rng.random((C, T)) < 0.9, np.float32(0.0), w)
+        elif kind == "runs_of_64":       # every value 64 .. 200 times
+            vals = rng.gamma(2.0, 8.0, 200).astype(np.float32)
+            a = vals[rng.integers(0, max(T // 100, 2), (C, T)) % 200]
+        return np.ascontiguousarray(a, np.float32)
+
+    ref, hist, sim = make(), make(), make()
+    gidx = _doy(T)
+    q = ((np.arange(20) + 0.5) / 20).astype(np.float32)
+    af, hq = hip.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+    eaf, ehq = oracle.eqm_train(ref, hist, gidx, 365, 31, q, "+")
+    assert_close(hq, ehq, rtol=0.0, what="hist_q")
+    assert_close(af, eaf, rtol=0.0, what="af")
+    for rw in (False, True):
+        scen, sim_q = hip.qdm_adjust(sim, eaf, q, gidx, 31, rw, "nearest", "constant", "+")
+        escen, esim_q = oracle.qdm_adjust(sim, eaf, q, gidx, 31, rw, "nearest", "constant", "+")
+        assert_close(sim_q, esim_q, rtol=0.0, what=f"sim_q rw={rw}")
+        assert_close(scen, escen, rtol=0.0, what=f"scen rw={rw}")
+    if kind != "zero_most_wide":  # (a group mean next to zero beside huge values: the guards hand such cells to the generic kernel anyway)
+        af2, hq2, sc2 = hip.dqm_train(ref + np.float32(5.0), hist + np.float32(5.0), gidx, 365, 31, q, "*")
+        eaf2, ehq2, esc2 = oracle.dqm_train(ref + np.float32(5.0), hist + np.float32(5.0), gidx, 365, 31, q, "*")
+        assert_close(sc2, esc2, rtol=2e-6, what="scaling")
+        assert_close(hq2, ehq2, rtol=2e-6, what="dqm hist_q")

@@ -211,13 +211,21 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
         __syncthreads();
     }
     if constexpr (XS_SORT_STOP == 1) return idx1;
+    // Heavily tied series (zero-inflated precipitation, coarsely rounded values): after pass 1 equal keys are neighbours, so that all
+    // 64 lanes of a stable pass's atomic hit ONE counter and are served one after the other — the sort of such a series took
+    // twice its time.  Detected from pass 1's histogram (block-uniform, for the price of one compare per bin); the stable passes
+    // then hand a wave whose 64 digits are equal its 64 slots with one atomic.
+    bool heavy = false;
     {
         constexpr int BPT = NB1 / NT;  // 16 bins = 8 dwords per thread
         uint32_t wv[BPT / 2];
         int run = 0;
+        uint32_t bigm = 0u;  // nonzero: one of this thread's bins holds 256 keys or more — a heavily tied series
 #pragma unroll
         for (int i = 0; i < BPT / 2; i++) {
             wv[i] = hist[tid * (BPT / 2) + i];
+            bigm |= wv[i] & 0xFF00FF00u;  // (the NaN / padding keys are not in yet when the histogram came with the load; else they may
+                                          //  switch the aggregation on, which is right for any series)
             // fused: the NaN / padding keys were not counted by the load (their digit needs the range): the owner of their bin adds them
             if (fused && (int)(d_nan >> 4) == tid && (int)((d_nan & 15u) >> 1) == i) wv[i] += (uint32_t)(TPAD - nvalid) << (16 * (d_nan & 1u));
             run += (int)(wv[i] & 0xFFFFu) + (int)(wv[i] >> 16);
@@ -225,8 +233,10 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
         int incl = wave_incl_scan(run);
         // (words 64.. of the scratch: with the histogram fused into the load no barrier lies between the all-reduce of
         //  cell_load_sort, which reads words 0 .. 47, and this store — a slow wave may still be reading them)
-        if (lane == 63) red[64 + wid] = (uint32_t)incl;
+        const bool wbig = __any(bigm != 0u);
+        if (lane == 63) { red[64 + wid] = (uint32_t)incl; red[80 + wid] = wbig ? 1u : 0u; }
         __syncthreads();
+        heavy = __any(red[80 + (lane & 15)] != 0u);
         const int woff = waves_before(red + 64, lane, wid);
         int pre = woff + incl - run;  // exclusive prefix of this thread's first bin
 #pragma unroll
@@ -275,8 +285,21 @@ __device__ __forceinline__ const uint16_t *radix_sort_indexes(unsigned char *sme
             const uint32_t *src = H + wid * (64 * EPT) + lane;
 #pragma unroll
             for (int j = 0; j < EPT; j++) hd[j] = src[64 * j];
+            if (heavy) {
 #pragma unroll
-            for (int j = 0; j < EPT; j++) od[j] = atomicAdd(&wrow[(hd[j] >> shift) & (uint32_t)(ND - 1)], 1u);
+                for (int j = 0; j < EPT; j++) {
+                    const uint32_t d = (hd[j] >> shift) & (uint32_t)(ND - 1);
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                    if (__all(d == d0)) {  // (the lanes in lane order, like the atomics of one instruction on one word)
+                        uint32_t b = 0u;
+                        if (lane == 0) b = atomicAdd(&wrow[d0], 64u);
+                        od[j] = (uint32_t)__builtin_amdgcn_readfirstlane((int)b) + (uint32_t)lane;
+                    } else od[j] = atomicAdd(&wrow[d], 1u);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < EPT; j++) od[j] = atomicAdd(&wrow[(hd[j] >> shift) & (uint32_t)(ND - 1)], 1u);
+            }
         }
         __syncthreads();
         if constexpr (XS_SORT_STOP == 4) { if (p == 0) return idx1; }
