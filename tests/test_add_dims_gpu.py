@@ -259,10 +259,10 @@ def test_scaling_and_loci_pool_members():
 
 
 @pytest.mark.parametrize("group", ["time", "time.month"])
-def test_adapt_freq_with_pooled_members(group):
-    """reference tests/test_adjustment.py:501-549: the frequency adaptation inside the training sees the pooled sample
-    (P0_ref, P0_hist over time x members), the one inside the adjustment works member by member (Grouper(group.name),
-    _adjustment.py:639-645)"""
+def test_adapt_freq_add_dims(group):
+    """reference tests/test_adjustment.py:500-549: `add_dims` are NOT pooled for the frequency adaptation (_processing.py:85-86) —
+    P0_ref / P0_hist / pth of the training keep the extra dimension, and dP0 of the training with add_dims=["point"] equals the
+    bare adapt_freq run point by point; the quantiles are pooled as ever."""
     rng = np.random.default_rng(11)
     P, T = 3, 4 * 365
     ref = rng.gamma(2.0, 3.0, (P, T)).astype(np.float32).clip(2, None)
@@ -272,26 +272,57 @@ def test_adapt_freq_with_pooled_members(group):
     ref[:, :5] = 0
     ref[2, :10] = 0
     dims = ("point", "time")
-    gr = xs.Grouper(group, add_dims=["point"])
     r, h = cube(ref, dims, "kg m-2 d-1"), cube(hist, dims, "kg m-2 d-1")
-    dqm = xs.DetrendedQuantileMapping.train(r, h, kind="*", group=gr, adapt_freq_thresh="1 kg m-2 d-1", nquantiles=10)
-    assert "point" not in dqm.ds.P0_ref.dims
-    gidx, G = gr.group_index(r)
-    rr, hh = pooled_rows(ref, gidx, G, 1), pooled_rows(hist, gidx, G, 1)
-    np.testing.assert_allclose(dqm.ds.P0_ref.values.ravel(), [np.mean(x < 1) for x in rr], rtol=1e-6)
-    np.testing.assert_allclose(dqm.ds.P0_hist.values.ravel(), [np.mean(x < 1) for x in hh], rtol=1e-6)
-    p = dqm.adjust(h).transpose(*dims).values
-    assert p.shape == (P, T) and np.isfinite(p).all()
-    # the same training through the oracle on the explicit pooled rows (one group each)
-    for g in range(G):
-        _, pth, _, p0r, p0h = oracle.adapt_freq(hh[g][None], rr[g][None], Z(hh[g]), 1, 1, 1.0, seed=0)
-        np.testing.assert_allclose(dqm.ds.pth.values.ravel()[g], pth.ravel()[0], rtol=1e-6, equal_nan=True)
+    adapted, _, dP0 = xs.processing.adapt_freq(r, h, thresh="1 kg m-2 d-1", group=group)   # bare: every point on its own
+    dqm = xs.DetrendedQuantileMapping.train(r, h, kind="*", group=xs.Grouper(group, add_dims=["point"]), adapt_freq_thresh="1 kg m-2 d-1", nquantiles=10)
+    assert "point" in dqm.ds.P0_ref.dims and "point" in dqm.ds.P0_hist.dims and "point" in dqm.ds.pth.dims
+    assert "point" not in dqm.ds.af.dims and "point" not in dqm.ds.hist_q.dims
+    P0_hist, P0_ref = dqm.ds.P0_hist.transpose("point", ...).values, dqm.ds.P0_ref.transpose("point", ...).values
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dP0_tr = np.where(P0_hist == 0, np.nan, (P0_hist - P0_ref) / P0_hist)
+    np.testing.assert_allclose(dP0_tr.reshape(P, -1), dP0.transpose("point", ...).values.reshape(P, -1), rtol=1e-6)
+    # the per-point statistics themselves, from the oracle on each member alone
+    gidx, G = xs.Grouper(group).group_index(r)
+    for p_ in range(P):
+        _, pth, _, p0r, p0h = oracle.adapt_freq(hist[p_][None], ref[p_][None], np.asarray(gidx, np.int32), G, 1, 1.0, seed=0)
+        np.testing.assert_allclose(dqm.ds.P0_ref.transpose("point", ...).values[p_].ravel(), p0r.ravel(), rtol=1e-6)
+        np.testing.assert_allclose(dqm.ds.P0_hist.transpose("point", ...).values[p_].ravel(), p0h.ravel(), rtol=1e-6)
+        np.testing.assert_allclose(dqm.ds.pth.transpose("point", ...).values[p_].ravel(), pth.ravel(), rtol=1e-6, equal_nan=True)
+    # no adjustment, just the frequency adaptation (the reference's check): what was to change changed, nothing else
+    dqm.ds["af"] = dqm.ds["af"] * 0 + 1
+    dqm.ds["scaling"] = dqm.ds["scaling"] * 0 + 1
+    only = dqm.adjust(h).transpose(*dims).values
+    ad = adapted.transpose(*dims).values
+    np.testing.assert_allclose(only[0], hist[0], rtol=1e-5)            # point 0: nothing below the threshold in hist
+    for p_, n_keep in ((1, 5), (2, 10)):
+        c1 = np.abs(ad[p_, it] - hist[p_, it]) < 1e-6
+        c2 = np.abs(only[p_, it] - hist[p_, it]) < 1e-6
+        np.testing.assert_array_equal(c1, c2)
+        np.testing.assert_allclose((ad[p_, it] - hist[p_, it])[:n_keep], 0)
 
 
-def test_adapt_freq_with_the_pooled_dim_in_one_dataset_only_is_refused():
+@pytest.mark.parametrize("typ", ["ref", "hist"])
+def test_add_dims_only_one_dataset(typ):
+    """reference tests/test_adjustment.py:551-582: the extra dimension in only one of ref / hist — the other is broadcast along
+    it for the frequency adaptation (_processing.py:104-106)"""
     rng = np.random.default_rng(12)
-    ref = cube(rng.gamma(2.0, 3.0, (2, 730)).astype(np.float32), ("point", "time"), "kg m-2 d-1")
-    hist = cube(rng.gamma(2.0, 3.0, 730).astype(np.float32), ("time",), "kg m-2 d-1")
-    with pytest.raises(ValueError, match="failed on block") as ei:  # re-wrapped like the reference does (base.py:698-703)
-        xs.DetrendedQuantileMapping.train(ref, hist, kind="*", group=xs.Grouper("time", add_dims=["point"]), adapt_freq_thresh="1 kg m-2 d-1")
-    assert isinstance(ei.value.__cause__, NotImplementedError) and "add_dims" in str(ei.value.__cause__)
+    T, P = 4 * 365, 3
+    ref = rng.gamma(2.0, 3.0, T).astype(np.float32).clip(2, None)
+    hist = rng.gamma(2.0, 3.0, T).astype(np.float32).clip(2, None)
+    it = np.arange(0, 30, 2)
+    hist[it] = np.arange(len(it)) / len(it)
+    ref[:5] = 0
+    r, h = cube(ref, ("time",), "kg m-2 d-1"), cube(hist, ("time",), "kg m-2 d-1")
+    rp = cube(np.tile(ref, (P, 1)), ("point", "time"), "kg m-2 d-1")
+    hp = cube(np.tile(hist, (P, 1)), ("point", "time"), "kg m-2 d-1")
+    a, b = (rp, h) if typ == "ref" else (r, hp)
+    dqm = xs.DetrendedQuantileMapping.train(a, b, kind="*", group=xs.Grouper("time", add_dims=["point"]), adapt_freq_thresh="1 kg m-2 d-1",
+                                            jitter_under_thresh_value="0.01 kg m-2 d-1", nquantiles=10)
+    assert "point" in dqm.ds.P0_ref.dims and dqm.ds.P0_ref.transpose("point", ...).values.shape[0] == P
+    # every member saw the same data: the same statistics, those of the plain training
+    plain = xs.DetrendedQuantileMapping.train(r, h, kind="*", group="time", adapt_freq_thresh="1 kg m-2 d-1", nquantiles=10)
+    for k in ("P0_ref", "P0_hist"):
+        v = dqm.ds[k].transpose("point", ...).values.reshape(P, -1)
+        np.testing.assert_allclose(v, np.tile(plain.ds[k].values.reshape(1, -1), (P, 1)), rtol=1e-6)
+    adj = dqm.adjust(b).values
+    assert np.isfinite(adj).all()

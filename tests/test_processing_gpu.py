@@ -8,6 +8,7 @@ import warnings
 import numpy as np
 import pytest
 
+import oracle
 import xsdba_amd as xs
 from xsdba_amd.labeled import DataArray
 from xsdba_amd.processing import adapt_freq, jitter, jitter_over_thresh, jitter_under_thresh
@@ -176,10 +177,11 @@ def test_adapt_freq_doy_window(cls):
 
 
 @pytest.mark.parametrize("gname,window", [("time.month", 1), ("time.dayofyear", 31)])
-def test_adapt_freq_add_dims_pools_the_members(gname, window):
-    """Grouper(add_dims=["member"]) (reference base.py:413: the extra dimension joins every group's sample; processing.py:46-122
-    run through it): dP0 and pth are ONE value per (cell, group) from the pooled sample, sim_ad keeps the members.  Expected dP0
-    from explicitly gathered pooled blocks (each member's windows, NaN past the ends of ITS series, never a neighbour's)."""
+def test_adapt_freq_add_dims_are_not_pooled(gname, window):
+    """Grouper(add_dims=["member"]) in adapt_freq (reference _processing.py:85-86: "ADD_DIMS are not pooled with other dims for
+    frequency adaptation"; tests/test_processing.py:166-182: the extra dimension stays on pth): every member is adapted on its own
+    — pth and dP0 equal those of the same call without `add_dims`, where the member is one more cell dimension — and a ref that
+    lacks the dimension is broadcast along it (_processing.py:104-106)."""
     rng = np.random.default_rng(3)
     T, L, M = 4 * 365, 2, 3
     pr = rng.integers(0, 100, size=(T, L, M)).astype(np.float64)
@@ -189,33 +191,27 @@ def test_adapt_freq_add_dims_pools_the_members(gname, window):
     ref = DataArray(ref_v, ("time", "lat", "member"), crd, {"units": "mm d-1"})
     gr = xs.Grouper(gname, window=window, add_dims=["member"])
     sim_ad, pth, dP0 = adapt_freq(ref, sim, thresh="1 mm d-1", group=gr)
-    assert sim_ad.dims == sim.dims and sim_ad.shape == sim.shape
-    assert pth.dims == ("lat", gr.prop) and dP0.dims == ("lat", gr.prop)
-    month = np.asarray(gr.group_index(sim)[0])
-    h = window // 2
-
-    def pooled_block(x, lat, g):  # every member's windows of the group's days
-        vals = []
-        for m in range(M):
-            for t in np.nonzero(month == g)[0]:
-                for j in range(window):
-                    tt = t + j - h
-                    if 0 <= tt < T:
-                        vals.append(x[tt, lat, m])
-        return np.asarray(vals)
-
+    assert set(sim_ad.dims) == set(sim.dims) and sim_ad.transpose(*sim.dims).shape == sim.shape
+    assert "member" in pth.dims and "member" in dP0.dims
+    plain = xs.Grouper(gname, window=window)
+    _, pth0, dP00 = adapt_freq(ref, sim, thresh="1 mm d-1", group=plain)
+    order = ("lat", "member", gr.prop)
+    np.testing.assert_array_equal(dP0.transpose(*order).values, dP00.transpose(*order).values)
+    np.testing.assert_allclose(pth.transpose(*order).values, pth0.transpose(*order).values, rtol=1e-12, equal_nan=True)
+    # against the oracle member by member: P0 from that member's windows alone
+    gidx, G = plain.group_index(sim)
     for lat in range(L):
-        for g in (0, 5, int(month.max())):
-            bs, br = pooled_block(sim_v, lat, g), pooled_block(ref_v, lat, g)
-            p0s, p0r = (bs < 1.0).mean(), (br < 1.0).mean()
-            np.testing.assert_allclose(dP0.values[lat, g], (p0s - p0r) / p0s, rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(pth.values, 20, rtol=0.12 if window == 1 else 0.3)
-    keep = sim_v > 20.5 if window == 1 else sim_v > 27
-    np.testing.assert_array_equal(sim_ad.values[keep], sim_v[keep])
-    changed = (sim_ad.values != sim_v)
-    assert changed.any() and (sim_v[changed] <= 1).all() and ((sim_ad.values[changed] > 1) & (sim_ad.values[changed] < (20.1 if window == 1 else 27))).all()
-    # every member takes part: about half of each member's dry days are filled
-    frac = [changed[:, :, m].sum() / (sim_v[:, :, m] <= 1).sum() for m in range(M)]
-    assert min(frac) > 0.3 and max(frac) < 0.7, frac
-    with pytest.raises(NotImplementedError):
-        adapt_freq(ref.isel(member=0), sim, thresh="1 mm d-1", group=gr)
+        for m in range(M):
+            _, epth, edp0, _, _ = oracle.adapt_freq(sim_v[:, lat, m][None], ref_v[:, lat, m][None], np.asarray(gidx, np.int32), G, window, 1.0, seed=0)
+            np.testing.assert_allclose(dP0.transpose(*order).values[lat, m], edp0.ravel(), rtol=1e-12, equal_nan=True)
+            np.testing.assert_allclose(pth.transpose(*order).values[lat, m], epth.ravel(), rtol=1e-12, equal_nan=True)
+    v = sim_ad.transpose(*sim.dims).values
+    changed = v != sim_v
+    assert changed.any() and (sim_v[changed] <= 1).all() and (v[changed] > 1).all()
+    # a ref without the extra dimension: broadcast along it (every member against the same ref)
+    r0 = ref.isel(member=0)
+    sim_b, pth_b, dP0_b = adapt_freq(r0, sim, thresh="1 mm d-1", group=gr)
+    assert "member" in pth_b.dims and set(sim_b.dims) == set(sim.dims)
+    for m in range(M):
+        _, _, edp0, _, _ = oracle.adapt_freq(sim_v[:, 0, m][None], ref_v[:, 0, 0][None], np.asarray(gidx, np.int32), G, window, 1.0, seed=0)
+        np.testing.assert_allclose(dP0_b.transpose(*order).values[0, m], edp0.ravel(), rtol=1e-12, equal_nan=True)

@@ -113,7 +113,14 @@ def _train_dataset(ref: DataArray, group: Grouper, quantiles, cell_dims, cell_sh
     coords[prop] = Coordinate(prop, crd.values)
     coords["quantiles"] = Coordinate("quantiles", np.asarray(quantiles))
     out = {}
+    members = tables.pop("_members", None)  # (dims, shape, coords) of the `add_dims` that P0_ref / P0_hist / pth keep
     for name, tab in tables.items():
+        if members is not None and name in ("P0_ref", "P0_hist", "pth"):
+            mdims, mshape, mcoords = members
+            c2 = {k: c for k, c in coords.items() if k != "quantiles"}
+            c2.update(mcoords)
+            out[name] = DataArray(np.asarray(tab).reshape(cell_shape + tuple(mshape) + (G,)), cell_dims + tuple(mdims) + (prop,), c2)
+            continue
         if getattr(tab, "strides", None) is not None and tab.size and not any(tab.strides):  # a zero-stride placeholder stays one
             tab = _Placeholder(tab)
         if isinstance(tab, _Placeholder):
@@ -152,6 +159,9 @@ class _TrainBlock:
     gidx_r: object = None    # group of every step of ref's (folded) time axis
     gidx_h: object = None    # ... of hist's
     same: bool = True        # ref and hist share the time axis: one fused training call
+    mr: object = None        # add_dims: the [cell, member, time] views of ref and hist (_Members), the plain group index
+    mh: object = None
+    gidx_plain: object = None
 
 
 def _prep_train(ds, group):
@@ -174,6 +184,7 @@ def _prep_train(ds, group):
     tb.r2, tb.gidx_r = mr.folded(gidx, group.window)
     tb.h2, tb.gidx_h = mh.folded(gidx, group.window)
     tb.same = mr.P == mh.P  # one fused training call needs ref and hist on the same (folded) time axis
+    tb.mr, tb.mh, tb.gidx_plain = mr, mh, gidx
     return mr.da, tb, tb.gidx_h, G, mr.cell_dims, mr.cell_shape, dt
 
 
@@ -199,12 +210,31 @@ def _preprocess_hist(ref, tb, G, group, adapt_freq_thresh, jitter_under_thresh_v
                         maximum=quantity_to_float(jitter_over_thresh_upper_bnd, ref, "jitter_over_thresh_upper_bnd"), seed=_draw_seed())
     extra = None
     if adapt_freq_thresh:
-        if not tb.same:
-            raise NotImplementedError("adapt_freq_thresh with `add_dims` present in only one of ref / hist is not implemented "
-                                      "on the HIP path (the kernel walks ref and hist on one time axis)")
         th = quantity_to_float(adapt_freq_thresh, ref, "adapt_freq_thresh")
-        h2, pth, _, P0_ref, P0_hist = hip.adapt_freq(h2, tb.r2, tb.gidx_h, G, group.window, th, seed=_draw_seed())
-        extra = {"P0_ref": P0_ref.astype(h2.dtype), "P0_hist": P0_hist.astype(h2.dtype), "pth": pth}
+        if tb.mh is None:
+            h2, pth, _, P0_ref, P0_hist = hip.adapt_freq(h2, tb.r2, tb.gidx_h, G, group.window, th, seed=_draw_seed())
+            extra = {"P0_ref": P0_ref.astype(h2.dtype), "P0_hist": P0_hist.astype(h2.dtype), "pth": pth}
+        else:
+            # `add_dims`: the members are NOT pooled for the frequency adaptation (_processing.py:85-86; P0_ref / P0_hist / pth
+            # keep the extra dimensions, _adjustment.py:86-95) — every member of hist is adapted on its own against its member
+            # of ref, a dataset without the dimension broadcast along it (_processing.py:104-106) — and the adapted members are
+            # pooled afterwards for the quantiles.
+            mr, mh = tb.mr, tb.mh
+            P = max(mr.P, mh.P)
+            if mr.P not in (1, P) or mh.P not in (1, P) or (mr.P == mh.P and mr.pool_shape != mh.pool_shape):
+                raise NotImplementedError("adapt_freq_thresh with differently shaped `add_dims` dimensions in ref and hist is not implemented on the HIP path")
+            C, T = mh.x3.shape[0], mh.T
+            dt = mh.x3.dtype
+            hx = np.asarray(_unfold(np.asarray(h2), mh.P, T)).reshape(C, mh.P, T)  # (hist after the jitter steps, member by member)
+            hb = np.ascontiguousarray(np.broadcast_to(hx, (C, P, T))).reshape(C * P, T)
+            rb = np.ascontiguousarray(np.broadcast_to(mr.x3, (C, P, T))).reshape(C * P, T)
+            h_ad, pth, _, P0_ref, P0_hist = hip.adapt_freq(hb, rb, tb.gidx_plain, G, group.window, th, seed=_draw_seed())
+            h2, tb.gidx_h = _fold(np.asarray(h_ad).reshape(C, P, T), tb.gidx_plain, group.window)
+            if mh.P != P:
+                tb.same = False  # (hist gained members: it no longer shares ref's folded axis, nor the group index the caller holds)
+            src = mh if mh.P == P else mr
+            members = (src.pooled, src.pool_shape, {d: src.da.coords[d] for d in src.pooled if d in src.da.coords})
+            extra = {"P0_ref": np.asarray(P0_ref).astype(dt), "P0_hist": np.asarray(P0_hist).astype(dt), "pth": np.asarray(pth), "_members": members}
     return h2, extra
 
 
@@ -307,6 +337,12 @@ def _prep_adjust(ds, group: Grouper, interp: str, grouped_linear: bool = False):
     if interp != "nearest" and group.prop != "group" and not grouped_linear:
         raise NotImplementedError(f"interp={interp!r} with group={group.name!r} is not implemented on the HIP path")
     sim = as_dataarray(ds["sim"])
+    if group.add_dims and "P0_ref" in ds.data_vars:
+        # the trained frequency tables keep the `add_dims` (reference _adjustment.py:86-95): a sim without them is broadcast
+        # along them, as xarray does when the reference combines the two (_processing.py:92-96)
+        from .processing import _broadcast_along
+
+        sim = _broadcast_along(sim, as_dataarray(ds["P0_ref"]), list(group.add_dims))
     dt = _common_dtype(sim, as_dataarray(ds["af"]))
     pooled = [d for d in group.add_dims if d in sim.dims]
     if pooled:  # the pooled members become cells of their own, next to each other (the tables are broadcast over them)

@@ -587,7 +587,9 @@ def map_blocks(reduces=None, **out_vars):
                 def _ordered(v):
                     # the template order of the reference (base.py:696-700), for device-resident results too: their transpose is a
                     # relabelling (labeled.DataArray.transpose), the buffer stays as the kernels wrote it
-                    return v.transpose(*[d for d in all_dims if d in v.dims])
+                    # (a variable may keep dimensions the template reduces: P0_ref / P0_hist / pth keep the `add_dims`, _adjustment.py:86-95
+                    #  of the reference — [PROP, ADD_DIMS]: they follow the template's)
+                    return v.transpose(*[d for d in all_dims if d in v.dims], *[d for d in v.dims if d not in all_dims])
 
                 out = Dataset({k: _ordered(v) for k, v in out.data_vars.items()}, attrs=out.attrs)
             except Exception as err:

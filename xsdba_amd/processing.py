@@ -63,6 +63,18 @@ def _series(da: DataArray, vals, cell_dims, cell_shape, dim, attrs=None):
     return out.transpose(*da.dims)
 
 
+def _broadcast_along(a: DataArray, other: DataArray, dims):
+    """`a` with the dimensions of `dims` it lacks taken from `other` (size, coordinate), in front — xr.broadcast for those"""
+    add = [d for d in dims if d not in a.dims and d in other.dims]
+    if not add:
+        return a
+    shape = tuple(other.shape[other.dims.index(d)] for d in add)
+    v = np.broadcast_to(np.asarray(a.values), shape + tuple(a.shape))
+    coords = dict(a.coords)
+    coords.update({d: other.coords[d] for d in add if d in other.coords})
+    return DataArray(np.ascontiguousarray(v), tuple(add) + tuple(a.dims), coords, dict(a.attrs), a.name)
+
+
 def jitter(x, lower=None, upper=None, minimum=None, maximum=None) -> DataArray:
     """Replace values under a threshold and values above another by a uniform random noise (processing.py:178-257):
     values < lower -> U(minimum, lower) (minimum excluded, default 0); values >= upper -> U(upper, maximum)."""
@@ -97,41 +109,22 @@ def adapt_freq(ref, sim, *, group: Grouper | str, thresh="0 mm d-1"):
     th = quantity_to_float(thresh, ref, "thresh")
     dt = np.result_type(ref.dtype, sim.dtype, np.float32)
     gidx, G = group.group_index(sim)
-    pooled = None
     if group.add_dims:
-        # base.py:413: the extra dimensions are pooled into every group's sample.  Pure layout (like the training path,
-        # _adjustment._prep_train): the P pooled members of a cell are laid end to end as ONE series, the gaps NaN and in no
-        # group, so that a window never reaches from one member into the next; sim_ad is cut back into members afterwards,
-        # pth and dP0 have no pooled dimension (the reference reduces them with the grouping dimension).
-        from ._adjustment import _Members, _unfold
-
-        ms = _Members(sim.astype(dt) if sim.dtype != dt else sim, group, dt)
-        if not ms.pooled:
+        # _processing.py:85-86: "ADD_DIMS are not pooled with other dims for frequency adaptation" — the probabilities, pth and
+        # the ranks are taken along time (and the window) for every member on its own; pth / dP0 keep the extra dimensions
+        # (_processing.py:20-26, tests/test_processing.py:166-182: "lat" in pth.dims).  A dataset that lacks one of them is
+        # broadcast along it (:104-106).  Members are therefore cells here.
+        extra = [d for d in group.add_dims if d in sim.dims or d in ref.dims]
+        if not extra:
             raise ValueError("`add_dims` argument needs to be a dimension in one of the input datasets.")
-        r_ = ref.astype(dt) if ref.dtype != dt else ref
-        if set(r_.dims) != set(ms.da.dims):
-            raise NotImplementedError("adapt_freq with `add_dims` present in only one of ref / sim is not implemented on the HIP "
-                                      "path (the kernel walks sim and ref on one time axis)")
-        mr = _Members(r_.transpose(*ms.da.dims), group, dt)
-        if mr.x3.shape != ms.x3.shape:
-            raise ValueError("ref and sim must have the same sizes along the pooled and the cell dimensions")
-        s2, g2 = ms.folded(gidx, group.window)
-        r2, _ = mr.folded(gidx, group.window)
-        sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, g2, G, group.window, th, seed=_draw_seed())
-        cell_dims, cell_shape = ms.cell_dims, ms.cell_shape
-        pooled = ms
-    else:
-        s2, r2, cell_dims, cell_shape = cell_time_pair(sim.astype(dt) if sim.dtype != dt else sim,
-                                                       ref.astype(dt) if ref.dtype != dt else ref, group.dim)
-        sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
+        sim, ref = _broadcast_along(sim, ref, extra), _broadcast_along(ref, sim, extra)
+    s2, r2, cell_dims, cell_shape = cell_time_pair(sim.astype(dt) if sim.dtype != dt else sim,
+                                                   ref.astype(dt) if ref.dtype != dt else ref, group.dim)
+    sim_ad, pth, dP0, _, _ = hip.adapt_freq(s2, r2, gidx, G, group.window, th, seed=_draw_seed())
     attrs = dict(sim.attrs)
     attrs["references"] = ("Themeßl et al. (2012), Empirical-statistical downscaling and error correction of regional climate "
                            "models and its impact on the climate change signal, Climatic Change, DOI 10.1007/s10584-011-0224-4.")
-    if pooled is not None:
-        full = np.asarray(_unfold(np.asarray(sim_ad), pooled.P, pooled.T)).reshape(pooled.cell_shape + pooled.pool_shape + (pooled.T,))
-        out = DataArray(full, pooled.da.dims, pooled.da.coords, attrs, sim.name).transpose(*sim.dims)
-    else:
-        out = _series(sim, sim_ad, cell_dims, cell_shape, group.dim, attrs)
+    out = _series(sim, sim_ad, cell_dims, cell_shape, group.dim, attrs)
     prop = group.prop
     crd = group.get_coordinate(sim)
     coords = {k: c for k, c in sim.coords.items() if k in cell_dims}
