@@ -1,0 +1,95 @@
+"""Random configurations of the hot path against the oracle (bit-exact EQM / QDM, DQM within 2e-6): series length, grouping,
+window, quantile count, kind, NaNs, ties (rounded values, zero-inflation, constant stretches), rank_window, extrapolation.
+    python scripts/diag/fuzz_vs_oracle.py [n_cases] [seed]
+Prints the failing configurations (none expected) and a count."""
+import sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import oracle
+from xsdba_amd import hip
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+
+
+def doy_month(T, start):
+    d0 = (np.arange(T) + start) % 365
+    cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
+    return d0.astype(np.int32), (np.searchsorted(cum, d0, side="right") - 1).astype(np.int32)
+
+
+def series(C, T, kind):
+    if kind == "+":
+        x = 280 + 10 * rng.standard_normal((C, T))
+    else:
+        x = rng.gamma(2.0, 4.0, (C, T))
+    mode = rng.integers(0, 6)
+    if mode == 1:
+        x = np.round(x, int(rng.integers(0, 3)))
+    elif mode == 2 and kind == "*":
+        x[rng.random((C, T)) < rng.uniform(0.2, 0.8)] = 0.0
+    elif mode == 3:
+        x[:, : T // 3] = x[:, :1]
+    elif mode == 4:
+        x = np.minimum(x, np.quantile(x, 0.7))
+    x = x.astype(np.float32)
+    if rng.random() < 0.5:
+        x[rng.random((C, T)) < rng.uniform(0.0, 0.1)] = np.nan
+    if rng.random() < 0.2:
+        x[0] = np.nan
+    return x
+
+
+bad = 0
+for case in range(n_cases):
+    T = int(rng.choice([400, 730, 1500, 3650, 4500, 7300, 9000, 10950, 12000]))
+    C = 3
+    doy, mon = doy_month(T, int(rng.integers(0, 365)))
+    gname = rng.choice(["time", "month", "season", "doy"])
+    if gname == "time":
+        gidx, G, W = np.zeros(T, np.int32), 1, 1
+    elif gname == "month":
+        gidx, G, W = mon, 12, int(rng.choice([1, 1, 3]))
+    elif gname == "season":
+        gidx, G, W = ((mon + 1) % 12 // 3).astype(np.int32), 4, 1
+    else:
+        gidx, G, W = doy, 365, int(rng.choice([1, 5, 15, 31]))
+    if rng.random() < 0.15 and G > 1:
+        gidx = gidx.copy(); gidx[rng.random(T) < 0.03] = -1
+    Q = int(rng.choice([5, 15, 20, 20, 33, 50]))
+    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    kind = str(rng.choice(["+", "*"]))
+    extrap = str(rng.choice(["constant", "nan"]))
+    ref, hist, sim = series(C, T, kind), series(C, T, kind), series(C, T, kind)
+    tag = f"case {case}: T={T} group={gname} W={W} Q={Q} kind={kind} extrap={extrap}"
+    try:
+        af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
+        eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
+        np.testing.assert_array_equal(np.asarray(hq), ehq, err_msg="hist_q")
+        np.testing.assert_array_equal(np.asarray(af), eaf, err_msg="af")
+        scen = hip.qm_adjust(sim, eaf, ehq, gidx, "nearest", extrap, kind)
+        escen = oracle.qm_adjust(sim, eaf, ehq, gidx, "nearest", extrap, kind)
+        ok = np.isclose(np.asarray(scen), escen, rtol=1e-6, atol=0, equal_nan=True)
+        if not ok.all():  # exact distance ties between rows are implementation-defined: count, do not fail, unless many
+            assert (~ok).mean() < 1e-3, f"qm_adjust {(~ok).sum()} mismatches"
+        for rw in ((False, True) if W > 1 else (False,)):
+            s2, sq = hip.qdm_adjust(sim, eaf, q, gidx, W, rw, "nearest", extrap, kind)
+            es2, esq = oracle.qdm_adjust(sim, eaf, q, gidx, W, rw, "nearest", extrap, kind)
+            np.testing.assert_array_equal(np.asarray(sq), esq, err_msg=f"sim_q rw={rw}")
+            np.testing.assert_array_equal(np.asarray(s2), es2, err_msg=f"qdm scen rw={rw}")
+            s3, _ = hip.qdm_adjust(sim, eaf, q, gidx, W, rw, "nearest", extrap, kind, want_sim_q=False)
+            np.testing.assert_array_equal(np.asarray(s3), es2, err_msg=f"qdm scen (no sim_q) rw={rw}")
+        if kind == "+" or (np.nanmin(ref) > 0 and np.nanmin(hist) > 0):
+            a2, h2, s2_ = hip.dqm_train(ref, hist, gidx, G, W, q, kind)
+            ea2, eh2, es2_ = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+            np.testing.assert_allclose(np.asarray(s2_), es2_, rtol=2e-6, equal_nan=True, err_msg="dqm scaling")
+            np.testing.assert_allclose(np.asarray(h2), eh2, rtol=4e-6, atol=1e-6, equal_nan=True, err_msg="dqm hist_q")
+    except AssertionError as e:
+        bad += 1
+        print("FAIL", tag, "|", str(e).strip().splitlines()[:4])
+    except Exception as e:  # noqa: BLE001
+        bad += 1
+        print("ERROR", tag, "|", type(e).__name__, str(e)[:200])
+    if case % 20 == 19:
+        print(f"... {case + 1} cases, {bad} bad", flush=True)
+print(f"done: {n_cases} cases, {bad} bad")
