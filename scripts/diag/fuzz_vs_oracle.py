@@ -9,6 +9,8 @@ import oracle
 from xsdba_amd import hip
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+long_series = len(sys.argv) > 3 and sys.argv[3] == "long"   # also series beyond 22 528 steps (the chunk-merge kernel)
+f64_share = 0.25
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 
 
@@ -18,7 +20,7 @@ def doy_month(T, start):
     return d0.astype(np.int32), (np.searchsorted(cum, d0, side="right") - 1).astype(np.int32)
 
 
-def series(C, T, kind):
+def series(C, T, kind, dtype):
     if kind == "+":
         x = 280 + 10 * rng.standard_normal((C, T))
     else:
@@ -32,7 +34,7 @@ def series(C, T, kind):
         x[:, : T // 3] = x[:, :1]
     elif mode == 4:
         x = np.minimum(x, np.quantile(x, 0.7))
-    x = x.astype(np.float32)
+    x = x.astype(dtype)
     if rng.random() < 0.5:
         x[rng.random((C, T)) < rng.uniform(0.0, 0.1)] = np.nan
     if rng.random() < 0.2:
@@ -42,7 +44,7 @@ def series(C, T, kind):
 
 bad = 0
 for case in range(n_cases):
-    T = int(rng.choice([400, 730, 1500, 3650, 4500, 7300, 9000, 10950, 12000]))
+    T = int(rng.choice([400, 730, 1500, 3650, 4500, 7300, 9000, 10950, 12000, 16000, 21900] + ([26000] if long_series else [])))
     C = 3
     doy, mon = doy_month(T, int(rng.integers(0, 365)))
     gname = rng.choice(["time", "month", "season", "doy"])
@@ -57,11 +59,12 @@ for case in range(n_cases):
     if rng.random() < 0.15 and G > 1:
         gidx = gidx.copy(); gidx[rng.random(T) < 0.03] = -1
     Q = int(rng.choice([5, 15, 20, 20, 33, 50]))
-    q = ((np.arange(Q) + 0.5) / Q).astype(np.float32)
+    dtype = np.float64 if rng.random() < f64_share else np.float32
+    q = ((np.arange(Q) + 0.5) / Q).astype(dtype)
     kind = str(rng.choice(["+", "*"]))
     extrap = str(rng.choice(["constant", "nan"]))
-    ref, hist, sim = series(C, T, kind), series(C, T, kind), series(C, T, kind)
-    tag = f"case {case}: T={T} group={gname} W={W} Q={Q} kind={kind} extrap={extrap}"
+    ref, hist, sim = series(C, T, kind, dtype), series(C, T, kind, dtype), series(C, T, kind, dtype)
+    tag = f"case {case}: T={T} group={gname} W={W} Q={Q} kind={kind} extrap={extrap} {np.dtype(dtype).name}"
     try:
         af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
         eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)

@@ -125,3 +125,25 @@ def test_xlong_matches_generic_kernel(hip, monkeypatch):
     af2, hq2 = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
     assert_close(hq, hq2, rtol=0.0, what="hist_q")
     assert_close(af, af2, rtol=0.0, what="af")
+
+
+@pytest.mark.parametrize("T,gname", [(22529, "doy31"), (26000, "month"), (30001, "week40")])
+def test_xlong_series_float64(hip, T, gname):
+    """float64 series of these lengths take the generic row kernel (k_train_long / k_train_xlong are float32 kernels): a copy of
+    the float32 dispatch once handed them doubles — EQM / DQM tables and group quantiles against the oracle"""
+    rng = np.random.default_rng(T)
+    C = 2
+    gidx, G, W = GROUPINGS[gname](T)
+    q = ((np.arange(20) + 0.5) / 20).astype(np.float64)
+    ref, hist = (x.astype(np.float64) * (1 + 1e-9 * rng.random(x.shape)) for x in _synth(rng, C, T, "+"))
+    af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, "+")
+    assert np.asarray(hq).dtype == np.float64
+    assert_close(hq, ehq, rtol=0.0, what="hist_q")
+    assert_close(af, eaf, rtol=0.0, what="af")
+    got = hip.quantile_groups(hist, gidx, G, W, q)
+    assert_close(got, oracle.quantile_groups(hist, gidx, G, W, q), rtol=0.0, what="quantile_groups")
+    af, hq, sc = hip.dqm_train(ref, hist, gidx, G, W, q, "+")
+    eaf, ehq, esc = oracle.dqm_train(ref, hist, gidx, G, W, q, "+")
+    assert_close(sc, esc, rtol=1e-12, atol=1e-10, what="scaling")   # (float64 block-reduction order of the group means)
+    assert_close(hq, ehq, rtol=1e-12, atol=1e-10, what="hist_q (dqm)")

@@ -974,49 +974,9 @@ int train_impl(xsdba_hip_ctx *ctx, int mode, const void *x0, const void *x1, int
             if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
             fast = true;
         }
-        // 22 529 .. 65 535 time steps: chunk sorts merged in global scratch, train_xlong.hpp
-        const bool fast_xlong = !fast && mode != 3 && pl->simple && pl->d_xl_pos && T > xs::LongCfg<11>::TPAD && T <= 65535 && G > 1 &&
-                                !(force && !strcmp(force, "rows")) && ctx->lane_ordered_atomics;
-        if (fast_xlong) {
-            void *flags, *scratch;
-            if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * ((size_t)C + 1), &flags))) return rc;
-            int *flag_count = (int *)flags, *flag_list = flag_count + 1;
-            HIP_TRY(hipMemsetAsync(flag_count, 0, sizeof(int), ctx->stream));
-            const unsigned nblk = (unsigned)std::min<int64_t>(C, ctx->n_cu);  // one block per CU (155 KB of LDS), cells walked grid-stride
-            auto go = [&](auto dqm, auto togp, auto wpl, auto ce) -> int {
-                constexpr bool DQM = decltype(dqm)::value, TOGP = decltype(togp)::value;
-                constexpr int WPL = decltype(wpl)::value, CE = decltype(ce)::value;
-                using X = xs::XLongGeo<WPL>;
-                int rc2;
-                if ((rc2 = ensure(ctx, S_SCR, X::scratch_bytes * nblk, &scratch))) return rc2;
-                if ((rc2 = set_lds(xs::k_train_xlong<DQM, TOGP, WPL, CE>, X::lds_bytes, ctx, "the per-cell sort"))) return rc2;
-                LaunchScope ls(ctx, "k_train_xlong");
-                hipLaunchKernelGGL((xs::k_train_xlong<DQM, TOGP, WPL, CE>), dim3(nblk), dim3(1024), X::lds_bytes, ctx->stream, (const float *)s0.dev,
-                                   (const float *)s1.dev, T, s0.sc, pl->d_row_ptr, pl->d_xl_rows, pl->d_tog_ptr, pl->d_xl_tog, G,
-                                   (const float *)dq, Q, (int)kind, mode, (float *)oaf.dev, (float *)ohq.dev, (float *)osc.dev,
-                                   flag_count, flag_list, C, pl->d_tog256, pl->d_xl_pos, pl->d_xl_time, (unsigned char *)scratch,
-#ifdef XSDBA_DIAG
-                                   getenv("XSDBA_HIP_DEBUG_PHASE") ? atoi(getenv("XSDBA_HIP_DEBUG_PHASE")) : 0);
-#else
-                                   0);
-#endif
-                return check_launch("k_train_xlong");
-            };
-            using std::false_type;
-            using std::true_type;
-            using std::integral_constant;
-            auto pick_w = [&](auto dqm, auto togp) -> int {
-                // (up to 32 768 steps: two chunks of at most 16 384, sorted with sixteen keys per thread instead of twenty-two)
-                if (T <= 2 * xs::LongCfg<8>::TPAD) return go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 8>{});
-                return T <= xs::XLongGeo<22>::TPAD ? go(dqm, togp, integral_constant<int, 22>{}, integral_constant<int, 11>{})
-                                                   : go(dqm, togp, integral_constant<int, 32>{}, integral_constant<int, 11>{});
-            };
-            rc = mode == 2 ? (pl->d_tog256 ? pick_w(true_type{}, true_type{}) : pick_w(true_type{}, false_type{}))
-                           : (pl->d_tog256 ? pick_w(false_type{}, true_type{}) : pick_w(false_type{}, false_type{}));
-            if (rc) return rc;
-            if ((rc = launch_rows(flag_list, flag_count, std::min<int64_t>((int64_t)C * G, 2048)))) return rc;
-            fast = true;
-        }
+        // (float64 series beyond 11 264 steps take the generic row kernel below: k_train_long / k_train_xlong are float32 kernels —
+        //  a copy of the float32 branch's xlong launch stood here since round 3 and handed them doubles: found by
+        //  scripts/diag/fuzz_vs_oracle.py in round 5, tests/test_xlong_series_gpu.py now runs float64 too)
     }
     if (!fast && (rc = launch_rows(nullptr, nullptr, C))) return rc;
     if ((rc = finish_out(ctx, &oaf)) || (rc = finish_out(ctx, &ohq)) || (rc = finish_out(ctx, &osc))) return rc;
