@@ -87,9 +87,45 @@ for case in range(n_cases):
             ea2, eh2, es2_ = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
             np.testing.assert_allclose(np.asarray(s2_), es2_, rtol=2e-6, equal_nan=True, err_msg="dqm scaling")
             np.testing.assert_allclose(np.asarray(h2), eh2, rtol=4e-6, atol=1e-6, equal_nan=True, err_msg="dqm hist_q")
+        # the adjust side of DQM (scaling, per-group polynomial trend, mapping, retrend), group means, LOCI, adapt_freq's tables
+        tnum = (np.arange(T, dtype=np.float64) * 86400e9 + 9.4e17)
+        if kind == "+" or (np.nanmin(sim) > 0 and np.nanmin(hist) > 0 and np.nanmin(ref) > 0):
+            ea2, eh2, es2_ = oracle.dqm_train(ref, hist, gidx, G, W, q, kind)
+            deg = int(rng.choice([0, 1, 1]))
+            scn = hip.dqm_adjust(sim, ea2, eh2, es2_, gidx, W, tnum, deg, "nearest", extrap, kind)
+            scn = scn[0] if isinstance(scn, tuple) else scn
+            escn = oracle.dqm_adjust(sim, ea2, eh2, es2_, gidx, W, tnum, deg, "nearest", extrap, kind)
+            escn = escn[0] if isinstance(escn, tuple) else escn
+            okd = np.isclose(np.asarray(scn), escn, rtol=2e-5 if dtype == np.float32 else 1e-9, atol=1e-4 if dtype == np.float32 else 1e-9, equal_nan=True)
+            assert (~okd).mean() < 2e-3, f"dqm_adjust {(~okd).sum()} of {okd.size} mismatches (degree {deg})"
+        gm = hip.group_means(sim, gidx, G, W)
+        np.testing.assert_allclose(np.asarray(gm), oracle.group_means(sim, gidx, G, W), rtol=1e-6 if dtype == np.float32 else 1e-12, equal_nan=True, err_msg="group_means")
+        if kind == "*":
+            th = float(np.nanquantile(hist, 0.3)) if np.isfinite(hist).any() else 1.0
+            laf, lth = hip.loci_train(ref, hist, gidx, G, W, th)
+            elaf, elth = oracle.loci_train(ref, hist, gidx, G, W, th)
+            np.testing.assert_allclose(np.asarray(lth), elth, rtol=1e-6, equal_nan=True, err_msg="loci hist_thresh")
+            # (hist values above the threshold all equal to it — capped data — make the factor a division by the rounding
+            #  residue of a mean, 1e14 or inf as the summation order has it: not compared)
+            sane = ~(np.abs(elaf) > 1e9) & ~(np.abs(np.asarray(laf)) > 1e9)
+            np.testing.assert_allclose(np.asarray(laf)[sane], elaf[sane], rtol=2e-5, equal_nan=True, err_msg="loci af")
+            if W == 1 or gname == "doy":  # (a coarse group with a window puts a step several times into one block: refused)
+                out = hip.adapt_freq(sim, ref, gidx, G, W, th, seed=3)
+                eout = oracle.adapt_freq(sim, ref, gidx, G, W, th, seed=3)
+                for nm, a_, b_ in zip(("pth", "dP0", "P0_ref", "P0_hist"), out[1:], eout[1:]):
+                    np.testing.assert_allclose(np.asarray(a_), b_, rtol=1e-6, equal_nan=True, err_msg=f"adapt_freq {nm}")
+        if G == 1:
+            for interp in ("linear",):
+                s1 = hip.qm_adjust(sim, eaf, ehq, gidx, interp, extrap, kind)
+                e1 = oracle.qm_adjust(sim, eaf, ehq, gidx, interp, extrap, kind)
+                ok1 = np.isclose(np.asarray(s1), e1, rtol=1e-5, atol=1e-5, equal_nan=True)
+                assert (~ok1).mean() < 1e-3, f"qm_adjust 1-D {interp}: {(~ok1).sum()} mismatches"
     except AssertionError as e:
         bad += 1
         print("FAIL", tag, "|", str(e).strip().splitlines()[:4])
+        import os
+        os.makedirs("gpurun_out", exist_ok=True)
+        np.savez_compressed(f"gpurun_out/fuzz_fail_{case}.npz", ref=ref, hist=hist, sim=sim, gidx=gidx, G=G, W=W, q=q, kind=kind, extrap=extrap)
     except Exception as e:  # noqa: BLE001
         bad += 1
         print("ERROR", tag, "|", type(e).__name__, str(e)[:200])
