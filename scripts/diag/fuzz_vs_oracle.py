@@ -64,7 +64,11 @@ for case in range(n_cases):
     kind = str(rng.choice(["+", "*"]))
     extrap = str(rng.choice(["constant", "nan"]))
     ref, hist, sim = series(C, T, kind, dtype), series(C, T, kind, dtype), series(C, T, kind, dtype)
-    tag = f"case {case}: T={T} group={gname} W={W} Q={Q} kind={kind} extrap={extrap} {np.dtype(dtype).name}"
+    layout = "cell-major"
+    if rng.random() < 0.3:  # the same cubes stored (time, cell): the wrappers hand element strides over
+        ref, hist, sim = (np.asfortranarray(x) for x in (ref, hist, sim))
+        layout = "time-major"
+    tag = f"case {case}: T={T} group={gname} W={W} Q={Q} kind={kind} extrap={extrap} {np.dtype(dtype).name} {layout}"
     try:
         af, hq = hip.eqm_train(ref, hist, gidx, G, W, q, kind)
         eaf, ehq = oracle.eqm_train(ref, hist, gidx, G, W, q, kind)
