@@ -127,3 +127,29 @@ def test_qdm_on_a_series_beyond_the_lds(hip, rank_window):
     np.testing.assert_array_equal(scen, escen)
     ranks = hip.rank_groups(sim, g, 365, W, rank_window)
     np.testing.assert_array_equal(ranks, esimq)
+
+
+@pytest.mark.parametrize("T,dtype", [(21900, np.float64), (40000, np.float64), (70001, np.float32)])
+def test_loci_rows_beyond_the_lds(T, dtype):
+    """LOCI under group="time": the hist row (every step of the series) goes through the global-memory row sort once it is
+    longer than the LDS takes (32 768 float32 / 16 384 float64 values) — thresholds and factors against the oracle
+    (reference _adjustment.py:889-919)"""
+    from xsdba_amd import hip
+
+    rng = np.random.default_rng(T)
+    C = 2
+    ref = rng.gamma(2.0, 4.0, (C, T)).astype(dtype)
+    hist = rng.gamma(2.5, 3.0, (C, T)).astype(dtype)
+    hist[1, rng.random(T) < 0.02] = np.nan
+    ref[1, rng.random(T) < 0.02] = np.nan
+    gidx = np.zeros(T, np.int32)
+    af, th = hip.loci_train(ref, hist, gidx, 1, 1, 3.0)
+    eaf, eth = oracle.loci_train(ref, hist, gidx, 1, 1, 3.0)
+    np.testing.assert_array_equal(np.asarray(th), eth)
+    np.testing.assert_allclose(np.asarray(af), eaf, rtol=1e-6 if dtype == np.float32 else 1e-12)
+    # two groups of which one is long
+    g2 = (np.arange(T) % 5 == 0).astype(np.int32)
+    af, th = hip.loci_train(ref, hist, g2, 2, 1, 3.0)
+    eaf, eth = oracle.loci_train(ref, hist, g2, 2, 1, 3.0)
+    np.testing.assert_array_equal(np.asarray(th), eth)
+    np.testing.assert_allclose(np.asarray(af), eaf, rtol=1e-6 if dtype == np.float32 else 1e-12)

@@ -1792,8 +1792,40 @@ int loci_train_impl(xsdba_hip_ctx *ctx, const void *ref, const void *hist, int64
     while (P < pl->max_row) P <<= 1;
     const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
     const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2), lds = red_b + (size_t)P * sizeof(U);
-    if ((rc = set_lds(xs::k_loci_thresh<R>, lds, ctx, "the LOCI row sort"))) return rc;
-    {
+    if (lds > (size_t)ctx->lds_limit && P >= 2 * xs::BIG_TILE) {
+        // a hist row beyond the LDS sort (60 years of daily float64 values under group="time"): sorted in global memory by the
+        // pipeline of train_bigrows.hpp, a batch of rows at a time
+        const size_t row_bytes = (size_t)P * sizeof(U);
+        const int tiles = P / xs::BIG_TILE;
+        int64_t batch = std::max<int64_t>(1, (int64_t)(((size_t)1 << 30) / row_bytes));
+        batch = std::min<int64_t>({batch, (int64_t)ng, (int64_t)((1ll << 30) / tiles)});
+        const size_t off_nv = ((size_t)batch * row_bytes + 255) & ~(size_t)255;
+        const size_t off_mu = (off_nv + (size_t)batch * sizeof(int) + 255) & ~(size_t)255;
+        void *scr;
+        if ((rc = ensure(ctx, S_SCR, off_mu + (size_t)batch * sizeof(R), &scr))) return rc;
+        U *keys = (U *)scr;
+        int *nvd = (int *)((unsigned char *)scr + off_nv);
+        R *mu = (R *)((unsigned char *)scr + off_mu);
+        const size_t lds_tile = (size_t)xs::BIG_TILE * sizeof(U);
+        if ((rc = set_lds(xs::k_big_local<U>, lds_tile, ctx, "a tile of the row sort"))) return rc;
+        LaunchScope ls(ctx, "k_loci_thresh(big rows)");
+        for (int64_t row0 = 0; row0 < (int64_t)ng; row0 += batch) {
+            const int64_t nb = std::min<int64_t>(batch, (int64_t)ng - row0);
+            hipLaunchKernelGGL(xs::k_big_fill<R>, dim3((unsigned)nb), dim3(1024), 0, ctx->stream, (const R *)h.dev, h.st, h.sc, pl->d_row_ptr,
+                               pl->d_row_idx, G, row0, P, (int)'+', 0, keys, nvd, mu);
+            hipLaunchKernelGGL(xs::k_big_local<U>, dim3((unsigned)(nb * tiles)), dim3(1024), lds_tile, ctx->stream, keys, P, 0);
+            const int64_t npairs = nb * (int64_t)(P / 2);
+            for (int k = 2 * xs::BIG_TILE; k <= P && k > 0; k <<= 1) {
+                for (int j = k >> 1; j >= xs::BIG_TILE; j >>= 1)
+                    hipLaunchKernelGGL(xs::k_big_step<U>, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, ctx->stream, keys, P, k, j, npairs);
+                hipLaunchKernelGGL(xs::k_big_local<U>, dim3((unsigned)(nb * tiles)), dim3(1024), lds_tile, ctx->stream, keys, P, k);
+            }
+            hipLaunchKernelGGL(xs::k_loci_thresh_big<R>, dim3((unsigned)nb), dim3(256), 0, ctx->stream, (const R *)r.dev, r.sc, pl->d_row_ptr,
+                               pl->d_row_idx, G, row0, P, thresh, (const U *)keys, (const int *)nvd, (R *)ot.dev);
+            if ((rc = check_launch("k_loci_thresh(big rows)"))) return rc;
+        }
+    } else {
+        if ((rc = set_lds(xs::k_loci_thresh<R>, lds, ctx, "the LOCI row sort"))) return rc;
         LaunchScope ls(ctx, "k_loci_thresh");
         hipLaunchKernelGGL(xs::k_loci_thresh<R>, dim3((unsigned)ng), dim3(NT), lds, ctx->stream, (const R *)r.dev, (const R *)h.dev,
                            r.sc, pl->d_row_ptr, pl->d_row_idx, G, thresh, (R *)ot.dev);

@@ -440,6 +440,45 @@ __global__ void k_loci_thresh(const R *__restrict__ ref, const R *__restrict__ h
     }
 }
 
+// k_loci_thresh for a row that does not fit the LDS (round 5): the hist row has been sorted in global memory by the pipeline of
+// train_bigrows.hpp (k_big_fill / k_big_local / k_big_step: `keys` [rows][P], `nvalid`); this kernel counts ref and reads the two
+// order statistics.  One block per (cell, group) row of the batch that starts at row0.
+template <typename R>
+__global__ __launch_bounds__(256) void k_loci_thresh_big(const R *__restrict__ ref, int64_t sc, const int *__restrict__ row_ptr,
+                                                         const int *__restrict__ row_idx, int G, int64_t row0, int P, double thresh,
+                                                         const typename KeyOf<R>::U *__restrict__ keys, const int *__restrict__ nvalid,
+                                                         R *__restrict__ hist_thresh)
+{
+    __shared__ double red[2 * 4 + 2];
+    const int64_t b = row0 + blockIdx.x;
+    const int64_t c = b / G;
+    const int g = (int)(b - c * G);
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    const R *xr = ref + c * sc;
+    double nle = 0;
+    int nr = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const R v = xr[row_idx[p0 + i]];
+        if (v == v) { nr++; if ((double)v <= thresh) nle += 1.0; }
+    }
+    block_sum_count(nle, nr, red);
+    if (threadIdx.x == 0) {
+        const double q = (nle + 1.0) / ((double)nr + 1.0);
+        const typename KeyOf<R>::U *kr = keys + (size_t)blockIdx.x * (size_t)P;
+        const int nh = nvalid[blockIdx.x];
+        R res = nan_of<R>();
+        if (nh > 0) {  // (the expressions of k_loci_thresh)
+            const double vi = (double)(nh - 1) * q;
+            int lo = (int)floor(vi);
+            lo = lo < 0 ? 0 : (lo > nh - 1 ? nh - 1 : lo);
+            const int hi = lo + 1 > nh - 1 ? nh - 1 : lo + 1;
+            const double a = (double)from_key(kr[lo]), bb = (double)from_key(kr[hi]), gam = vi - (double)lo;
+            res = (R)(a + (bb - a) * gam);
+        }
+        hist_thresh[(size_t)c * G + g] = res;
+    }
+}
+
 template <typename R>
 __global__ void k_loci_factor(const R *__restrict__ ref, const R *__restrict__ hist, int64_t sc, const int *__restrict__ row_ptr,
                               const int *__restrict__ row_idx, const int *__restrict__ gidx, int G, double thresh,
