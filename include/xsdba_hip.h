@@ -57,7 +57,7 @@ enum {
     XSDBA_E_UNSUPPORTED = -3,  /* an option this entry point does not serve, e.g. interp = LINEAR on a grouped table through
                                 * xsdba_hip_qm_adjust (the griddata interpolants have their own entries: _qm_adjust_linear2d / _cubic2d) */
     XSDBA_E_DEGREE = -4,       /* PolyDetrend degree outside 0..6 */
-    XSDBA_E_ROW_TOO_LONG = -5, /* a group row does not fit the LDS sort (see DESIGN.md limits) */
+    XSDBA_E_ROW_TOO_LONG = -5, /* a group row beyond 2^30 values, or a kernel whose LDS need exceeds the device */
     XSDBA_E_NO_DEVICE = -6     /* no usable gfx950 device / kernel image */
 };
 

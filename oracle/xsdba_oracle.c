@@ -390,7 +390,7 @@ API int xsdba_oracle_jitter(const void *x, int dtype, int64_t T, int64_t C, int6
     return 0;
 }
 
-typedef struct { double v; uint32_t tag; } af_item;
+typedef struct { double v; uint64_t tag; } af_item;  /* tag: 16 random bits << 32 | slot in the block (any block length) */
 static int af_cmp(const void *a, const void *b)
 {
     const af_item *x = (const af_item *)a, *y = (const af_item *)b;
@@ -467,13 +467,13 @@ API int xsdba_oracle_adapt_freq(const void *sim, const void *ref, int dtype, int
                 double v = LOADV(sim, c, tt);
                 if (isnan(v)) continue;
                 items[m].v = v;
-                items[m].tag = ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)i;
+                items[m].tag = ((uint64_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 32) | (uint64_t)(uint32_t)i;
                 m++;
             }
             qsort(items, (size_t)m, sizeof(af_item), af_cmp);
             double lowb = (p0r / p0h) * P0_sim;
             for (int64_t p = 0; p < m; p++) {
-                int64_t tt = pl.row_idx[p0 + (items[p].tag & 0xFFFFu)];
+                int64_t tt = pl.row_idx[p0 + (int64_t)(items[p].tag & 0xFFFFFFFFu)];
                 if (gidx[tt] != g) continue;
                 double rk = (double)(p + 1) / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
                 double rnk = mx * (rk - mn) / (mx - mn);

@@ -1,0 +1,36 @@
+"""adapt_freq: the LDS sorts against the selection (XSDBA_HIP_AF_SELECT=1) on rows where both apply, per-kernel times from the
+library's own profile; 8 192 cells x 10 950 days, sim drier than ref everywhere (every block adapts).
+    python scripts/experiments/exp_adapt_freq_select.py"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from xsdba_amd import hip  # noqa: E402
+
+C, T = 8192, 10950
+rng = np.random.default_rng(0)
+ref = rng.gamma(0.8, 4.0, (C, T)).astype(np.float32)
+sim = rng.gamma(0.8, 4.0, (C, T)).astype(np.float32)
+ref[rng.random((C, T)) < 0.3] = 0.0
+sim[rng.random((C, T)) < 0.5] = 0.0
+d0 = np.arange(T) % 365
+cum = np.concatenate([[0], np.cumsum([31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31])])
+mon = (np.searchsorted(cum, d0, side="right") - 1).astype(np.int32)
+ctx = hip.default_context()
+dsim, dref = ctx.to_device(sim), ctx.to_device(ref)
+for gname, gidx, G, W in (("time", np.zeros(T, np.int32), 1, 1), ("month", mon, 12, 1), ("doy31", d0.astype(np.int32), 365, 31)):
+    for sel in (False, True, False, True):
+        if sel:
+            os.environ["XSDBA_HIP_AF_SELECT"] = "1"
+        else:
+            os.environ.pop("XSDBA_HIP_AF_SELECT", None)
+        hip.adapt_freq(dsim, dref, gidx, G, W, 1.0, seed=1)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        hip.adapt_freq(dsim, dref, gidx, G, W, 1.0, seed=1)
+        ctx.synchronize()
+        print(f"{gname:6s} select={int(sel)}  {1e3 * (time.perf_counter() - t0):8.2f} ms per {C} cells", flush=True)
+os.environ.pop("XSDBA_HIP_AF_SELECT", None)

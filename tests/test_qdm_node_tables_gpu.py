@@ -103,3 +103,45 @@ def test_uneven_quantile_nodes_and_many_row_lengths():
     exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", "constant", "*")
     np.testing.assert_array_equal(a, exp)
     np.testing.assert_array_equal(b, exp)
+
+
+def _cells_one_group(T, rng, dtype):
+    C = 8
+    sim = rng.gamma(2.0, 2.0, (C, T)).astype(dtype)
+    sim[1, rng.random(T) < 0.5] = 0.0                        # ties at the minimum: the cell's own evaluation
+    sim[2] = np.minimum(sim[2], dtype(4.0))                  # ... at the maximum
+    sim[3, rng.random(T) < 0.03] = np.nan                    # NaNs: N differs from the launch's
+    sim[4] = np.round(sim[4], 1)                             # ties inside (the extremes untied, mostly): the launch's table
+    sim[5] = np.nan                                          # no value at all
+    sim[6, 5:] = np.nan                                      # five values
+    return sim                                               # (7: NaN among its factors, set by the caller)
+
+
+@pytest.mark.parametrize("T", [365, 1825, 2001, 4097, 7300, 10950, 11264])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_single_group_table_vs_elements_and_oracle(T, dtype):
+    """group="time", interp="nearest": pass D by the launch's one table (utils._interp_on_quantiles_1D's nearest: bounds halfway
+    between the nodes, a percent rank ON a bound goes down — T = 2001 with 20 even nodes puts 19 percent ranks exactly there)
+    against the element-by-element evaluation (XSDBA_HIP_QDM_TABLES=0) and the oracle, bit for bit"""
+    from xsdba_amd import hip
+
+    rng = np.random.default_rng(T)
+    gidx = np.zeros(T, np.int32)
+    sim = _cells_one_group(T, rng, dtype)
+    C = sim.shape[0]
+    for Q, kind, extrap, even in ((20, "*", "constant", True), (15, "+", "nan", True), (33, "*", "nan", False), (1, "+", "constant", True)):
+        q = ((np.arange(Q) + 0.5) / Q).astype(dtype) if even else (np.sort(rng.random(Q)) * 0.9 + 0.05).astype(dtype)
+        af = (1.0 + 0.3 * rng.standard_normal((C, 1, Q))).astype(dtype)
+        af[7, 0, Q // 2] = np.nan
+        a = _run(hip, True, sim, af, q, gidx, 1, False, "nearest", extrap, kind)
+        b = _run(hip, False, sim, af, q, gidx, 1, False, "nearest", extrap, kind)
+        exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "nearest", extrap, kind)
+        np.testing.assert_array_equal(a, exp)
+        np.testing.assert_array_equal(b, exp)
+        assert a.dtype == dtype
+    # the other interpolations of one group do not take the table
+    q = ((np.arange(20) + 0.5) / 20).astype(dtype)
+    af = (1.0 + 0.3 * rng.standard_normal((C, 1, 20))).astype(dtype)
+    a = _run(hip, True, sim, af, q, gidx, 1, False, "linear", "constant", "*")
+    exp, _ = oracle.qdm_adjust(sim, af, q, gidx, 1, False, "linear", "constant", "*")
+    np.testing.assert_allclose(a, exp, rtol=1e-6 if dtype == np.float32 else 1e-13, equal_nan=True)

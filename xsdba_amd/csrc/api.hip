@@ -1485,7 +1485,9 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
             const unsigned char *gtab = (const unsigned char *)flag_count;  // (a readable address when there are no tables)
             xs::QdmTabs gt;
             const char *tabenv = getenv("XSDBA_HIP_QDM_TABLES");
-            if (!ranks_only && !sim_q && G > 1 && Q <= 63 && !(tabenv && !strcmp(tabenv, "0"))) {
+            // (a single group holding every step: ONE table, of the 1-D nearest flavour — interp="nearest" only)
+            const bool one_d = G == 1 && pass && interp == XSDBA_INTERP_NEAREST && pl->row_ptr[1] - pl->row_ptr[0] == (int)T;
+            if (!ranks_only && !sim_q && (G > 1 || one_d) && Q <= 63 && !(tabenv && !strcmp(tabenv, "0"))) {
                 if ((rc = make_group_tabs(ctx, pl, (use_tog & 1) != 0))) return rc;
                 const Plan::GroupTabs &t = pl->gt[(use_tog & 1) ? 1 : 0];
                 if (t.K) {
@@ -1493,7 +1495,7 @@ int qdm_impl(xsdba_hip_ctx *ctx, const void *sim, int64_t T, int64_t C, int64_t 
                     if ((rc = ensure(ctx, S_TAB1, t.bytes, &tb))) return rc;
                     LaunchScope ls(ctx, "k_qdm_node_tables");
                     hipLaunchKernelGGL(xs::k_qdm_node_tables<R>, dim3((unsigned)std::min(8, (2 * t.max_n + 2 + 255) / 256), (unsigned)t.K), dim3(256), 0,
-                                       ctx->stream, (const R *)dqn, Q, t.d_cls_N, t.d_cls_off, (unsigned char *)tb);
+                                       ctx->stream, (const R *)dqn, Q, t.d_cls_N, t.d_cls_off, (unsigned char *)tb, one_d ? 1 : 0);
                     if ((rc = check_launch("k_qdm_node_tables"))) return rc;
                     gtab = (const unsigned char *)tb;
                     gt.K = t.K; gt.bytes = (int)t.bytes;
@@ -1620,7 +1622,6 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     Plan *pl;
     if ((rc = get_plan(ctx, gidx, T, G, W, &pl))) return rc;
     if (!pl->simple) return fail(XSDBA_E_UNSUPPORTED, "adapt_freq: a time step occurs twice in one group block (coarse group + window)");
-    if (pl->max_row > 65535) return fail(XSDBA_E_ROW_TOO_LONG, "adapt_freq: group block of %d values (max 65535)", pl->max_row);
     SeriesIn s, r;
     if ((rc = series_in<R>(ctx, S_IN0, S_CM0, sim, T, C, st, sc, &s))) return rc;
     if (ref && (rc = series_in<R>(ctx, S_IN1, S_CM1, ref, T, C, st, sc, &r))) return rc;
@@ -1644,12 +1645,18 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     while (P < pl->max_row) P <<= 1;
     const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
     const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2);
+    // What the LDS does not sort is decided by selection over the row in global memory (preproc.hpp; no row limit):
+    // bit 0: the ref row for pth; bit 1: the ranks whatever their number (always beyond 65 535 values: the slot of the LDS
+    // tags has 16 bits; XSDBA_HIP_AF_SELECT=1 sends everything that way — tests).
+    int sel = (red_b + (size_t)P * sizeof(U) > (size_t)ctx->lds_limit ? 1 : 0) | (pl->max_row > 65535 ? 2 : 0);
+    if (getenv("XSDBA_HIP_AF_SELECT")) sel = 3;
     // the (key, tag) pairs of the sub-threshold values: as many as the LDS takes, at most the row
-    int Ps = P;
+    int Ps = (sel & 2) ? 2 : P;
     while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;
-    const size_t lds = red_b + std::max((size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t)));
+    const size_t lds = red_b + std::max({(sel & 1) ? (size_t)0 : (size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t)),
+                                         (size_t)2560 /* the selection's histograms; the per-wave minima */});
     if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq row sort"))) return rc;
-    // [0] error flag of the pair sort, [1] length of the work list, [2...] the (cell, group) blocks with dP0 > 0
+    // [0] unused, [1] length of the work list, [2...] the (cell, group) blocks with dP0 > 0
     void *flag;
     if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (ng + 2), &flag))) return rc;
     HIP_TRY(hipMemsetAsync(flag, 0, 2 * sizeof(int), ctx->stream));
@@ -1675,14 +1682,10 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
                            ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
                            pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
                            ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
-                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, (int *)flag, screened ? work_list : (const int *)nullptr,
+                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, sel, screened ? work_list : (const int *)nullptr,
                            screened ? n_work : (const int *)nullptr, (int64_t)ng);
         if ((rc = check_launch("k_adapt_freq"))) return rc;
     }
-    int too_many = 0;
-    HIP_TRY(hipMemcpyAsync(&too_many, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    if (too_many) return fail(XSDBA_E_ROW_TOO_LONG, "adapt_freq: a group block holds %d values under the threshold, the LDS sort takes %d", too_many, Ps);
     if (ref && ((rc = finish_out(ctx, &o0)) || (rc = finish_out(ctx, &o1)) || (rc = finish_out(ctx, &o2)))) return rc;
     if ((rc = finish_out(ctx, &o3))) return rc;
     if ((rc = series_out_end<R>(ctx, &o, T, C))) return rc;

@@ -74,17 +74,90 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 //   values with  rnk in [P0_ref / P0_hist * P0_sim, P0_sim]  become  (pth - thresh) * U[0,1) + thresh  (in the data dtype);
 //   the time series keeps the window-centre element of each block (base.py:438-439), i.e. time step t is corrected by the
 //   block of ITS group.
-// Ties are broken by sorting (key, tag) pairs, tag = 16 random bits (stream 3, mixed with the group) | slot in the row.
+// Ties are broken by the order of (key, tag) pairs, tag = 16 random bits (stream 3, mixed with the group) | slot in the row.
 // dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: max(P_max, Ps) * sizeof(U)] with [tags: Ps * 4] behind the first Ps keys,
-// Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values; a block with more of them raises *err_flag
+// Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values (sorted in LDS).
+// No row limit (round 5): what the LDS does not take is decided by SELECTION instead of sorting — the replaced values are
+// those whose rank k lies in a band [k_lo, k_hi] (the percent rank is monotone in k), i.e. whose (key, tag) lies between the
+// k_lo-th and the k_hi-th smallest: two order statistics, found together by a radix select over the row in global memory
+// (block_select2: a byte per pass, 256-bin histograms in LDS), then one pass that compares.  The same routine reads the two
+// order statistics of the ref row that pth interpolates when that row does not fit the LDS sort (sel bit 0).  sel bit 1: ranks by
+// selection whatever their number (rows beyond 65 535 values, whose slots do not fit the 16 bits of the LDS tags — the selection
+// carries the tag as 16 random bits << 32 | slot, the same order; XSDBA_HIP_AF_SELECT=1: tests).
 // sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
 // ---------------------------------------------------------------------------------------------
+// The kA-th and the kB-th smallest (0-based; both below the count of elements gen accepts) of the composites (key, 48-bit tag)
+// that gen(i, key, tag, need_tag) yields for i in [0, L), most significant byte first: sizeof(U) passes over the keys, six
+// over the tags of the elements whose key is a selected one (with_tag; the tag is only asked for then).
+// hist: 516 ints of LDS.  Whole block; ends on a barrier.
+template <typename U, typename Gen>
+__device__ __forceinline__ void block_select2(Gen gen, int L, bool with_tag, int kA, int kB, int *hist, U &keyA, uint64_t &tagA,
+                                              U &keyB, uint64_t &tagB)
+{
+    constexpr int KBY = (int)sizeof(U);
+    const int npass = KBY + (with_tag ? 6 : 0);
+    const int lane = threadIdx.x & 63;
+    int *res = hist + 512;
+    keyA = keyB = 0;
+    tagA = tagB = 0;
+    for (int p = 0; p < npass; p++) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        const bool kp = p < KBY;
+        const int t = p - KBY;
+        const int sh = kp ? 8 * (KBY - 1 - p) : 8 * (5 - t);
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            U k;
+            uint64_t tg = 0;
+            if (!gen(i, k, tg, false)) continue;
+            if (kp) {
+                const int d = (int)((k >> sh) & 0xFF);
+                if (p == 0 || ((k ^ keyA) >> (sh + 8)) == 0) atomicAdd(&hist[d], 1);
+                if (p == 0 || ((k ^ keyB) >> (sh + 8)) == 0) atomicAdd(&hist[256 + d], 1);
+            } else {
+                const bool mA = k == keyA, mB = k == keyB;
+                if (mA || mB) {
+                    (void)gen(i, k, tg, true);
+                    const int d = (int)((tg >> sh) & 0xFF);
+                    if (mA && (t == 0 || ((tg ^ tagA) >> (sh + 8)) == 0)) atomicAdd(&hist[d], 1);
+                    if (mB && (t == 0 || ((tg ^ tagB) >> (sh + 8)) == 0)) atomicAdd(&hist[256 + d], 1);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // wave 0: the bin that holds the k-th candidate, and k among that bin's
+            for (int s_ = 0; s_ < 2; s_++) {
+                const int k = s_ ? kB : kA;
+                const int *h = hist + 256 * s_ + 4 * lane;
+                const int c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+                const int tot = c0 + c1 + c2 + c3;
+                int incl = tot;
+                for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+                const int excl = incl - tot;
+                if (k >= excl && k < incl) {
+                    int r = k - excl, j = 0;
+                    if (r >= c0) { r -= c0; j = 1; if (r >= c1) { r -= c1; j = 2; if (r >= c2) { r -= c2; j = 3; } } }
+                    res[2 * s_] = 4 * lane + j;
+                    res[2 * s_ + 1] = r;
+                }
+            }
+        }
+        __syncthreads();
+        const int dA = res[0], dB = res[2];
+        kA = res[1];
+        kB = res[3];
+        if (kp) { keyA |= (U)dA << sh; keyB |= (U)dB << sh; }
+        else { tagA |= (uint64_t)dA << sh; tagB |= (uint64_t)dB << sh; }
+        __syncthreads();  // (res is read before the next pass clears the histograms)
+    }
+}
+
 template <typename R>
 __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag, int64_t block_id)
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int sel, int64_t block_id)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -123,17 +196,41 @@ __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, cons
                 k = to_key(v);
                 if (v == v) { nr++; if ((double)v <= thresh) c0r += 1.0; }
             }
-            keys[i] = k;
+            if (!(sel & 1)) keys[i] = k;
         }
         block_sum_count(c0r, nr, red);
         p0r = nr ? c0r / (double)nr : __builtin_nan("");
         p0h = P0_sim;
         const double d = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
         pthv = nan_of<R>();
-        if (d > 0.0) {  // block-uniform
+        if (d > 0.0 && !(sel & 1)) {  // block-uniform
             block_bitonic_sort<U>(keys, P);
             auto load = [&](int i) { return (double)from_key(keys[i]); };
             // np.nanquantile on the float64 copy of the row (the gufunc's float64 loop), rounded once
+            pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
+        } else if (d > 0.0) {
+            // the row stays in global memory: the (at most) two order statistics vecquantile_sorted reads, by selection
+            // (d > 0: nr >= 1 and p0h is a number)
+            int ia = 0, ib = 0;
+            if (nr > 1) {
+                const double pp = p0h * 100.0;
+                if (pp == 100.0) ia = ib = nr - 1;
+                else if (pp != 0.0) {
+                    const double rank = 1.0 + (double)(nr - 1) * (pp / 100.0);
+                    int lo = (int)floor(rank) - 1;
+                    lo = lo < 0 ? 0 : (lo > nr - 2 ? nr - 2 : lo);
+                    ia = lo; ib = lo + 1;
+                }
+            }
+            auto gen_ref = [&](int i, U &k, uint64_t &, bool) {
+                const R v = xr[row_idx[p0 + i]];
+                k = to_key(v);
+                return v == v;
+            };
+            U ka, kb;
+            uint64_t ta_, tb_;
+            block_select2<U>(gen_ref, L, false, ia, ib, reinterpret_cast<int *>(keys), ka, ta_, kb, tb_);
+            auto load = [&](int i) { return (double)from_key(i == ia ? ka : kb); };
             pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
         }
         __syncthreads();
@@ -164,39 +261,81 @@ __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, cons
     };
     const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
     auto tag_of = [&](int tt, int slot) { return ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)slot; };
+    // (the same order with room for any slot: rows beyond 65 535 values, the selection)
+    auto tag48_of = [&](int tt, int slot) { return ((uint64_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 32) | (uint64_t)(uint32_t)slot; };
     if (n0 == 0) {
         // nothing under the threshold although the training asks for adaptation: P0_sim = 0 and the smallest value has
         // rnk = 0 = P0_sim, inside the band, so the reference replaces it.  Lexicographic (key, tag) minimum of the row.
         U bk = KeyOf<R>::MAXK;
-        uint32_t bt = 0xFFFFFFFFu;
+        uint64_t bt = ~0ull;
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
             const int tt = row_idx[p0 + i];
             const R v = xs[tt];
             if (v == v) {
                 const U k = to_key(v + (R)0);
-                const uint32_t tg = tag_of(tt, i);
-                if (k < bk || (k == bk && tg < bt)) { bk = k; bt = tg; }
+                if (k <= bk) {
+                    const uint64_t tg = tag48_of(tt, i);
+                    if (k < bk || tg < bt) { bk = k; bt = tg; }
+                }
             }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const U ok = __shfl_down(bk, o, 64);
-            const uint32_t ot = __shfl_down(bt, o, 64);
+            const uint64_t ot = __shfl_down(bt, o, 64);
             if (ok < bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
         }
+        uint64_t *wt = reinterpret_cast<uint64_t *>(keys + 64);  // (per wave: key in keys[w], tag in wt[w])
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { keys[threadIdx.x >> 6] = bk; tags[threadIdx.x >> 6] = bt; }
+        if ((threadIdx.x & 63) == 0) { keys[threadIdx.x >> 6] = bk; wt[threadIdx.x >> 6] = bt; }
         __syncthreads();
         if (threadIdx.x == 0 && N > 0) {
-            for (int w = 1; w < nw; w++) if (keys[w] < bk || (keys[w] == bk && tags[w] < bt)) { bk = keys[w]; bt = tags[w]; }
-            const int tt = row_idx[p0 + (int)(bt & 0xFFFFu)];
+            for (int w = 1; w < nw; w++) if (keys[w] < bk || (keys[w] == bk && wt[w] < bt)) { bk = keys[w]; bt = wt[w]; }
+            const int tt = row_idx[p0 + (int)(uint32_t)bt];
             if (gidx[tt] == g) replace_if_in_band(1, tt);
         }
         return;
     }
     int Ps = 2;
     while (Ps < n0) Ps <<= 1;
-    if (Ps > P_sub_cap) {  // block-uniform: does not fit the LDS, reported through the error flag
-        if (threadIdx.x == 0) atomicMax(err_flag, n0);
+    if (Ps > P_sub_cap || (sel & 2)) {  // block-uniform: more pairs than the LDS sorts (or rows with slots beyond 16 bits)
+        // the band of ranks that are replaced: rnk(k) is non-decreasing in k (every operation of replace_if_in_band's expression
+        // is monotone under rounding; 0 / 0 = NaN for N = 1 fails both tests: replaced), so "rnk < lowb" holds on a prefix of
+        // k = 1 .. n0 and "rnk > P0_sim" on a suffix
+        auto rnk_of = [&](int k) {
+            const double rk = (double)k / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
+            return mx * (rk - mn) / (mx - mn);
+        };
+        int lo = 1, hi = n0 + 1;
+        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rnk_of(mid) < lowb) lo = mid + 1; else hi = mid; }
+        const int k_lo = lo;
+        lo = 1; hi = n0 + 1;
+        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rnk_of(mid) > P0_sim) hi = mid; else lo = mid + 1; }
+        const int k_hi = lo - 1;
+        if (k_lo > k_hi) return;
+        auto gen_sub = [&](int i, U &k, uint64_t &tg, bool need_tag) {
+            const int tt = row_idx[p0 + i];
+            const R v = xs[tt];
+            if (!(v == v && (double)v <= thresh)) return false;
+            k = to_key(v + (R)0);
+            if (need_tag) tg = tag48_of(tt, i);
+            return true;
+        };
+        U ka, kb;
+        uint64_t ta_, tb_;
+        block_select2<U>(gen_sub, L, true, k_lo - 1, k_hi - 1, reinterpret_cast<int *>(keys), ka, ta_, kb, tb_);
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            const int tt = row_idx[p0 + i];
+            const R v = xs[tt];
+            if (!(v == v && (double)v <= thresh) || gidx[tt] != g) continue;  // (only the block's centre elements reach the time series)
+            const U k = to_key(v + (R)0);
+            if (k < ka || k > kb) continue;
+            if (k == ka || k == kb) {
+                const uint64_t tg = tag48_of(tt, i);
+                if ((k == ka && tg < ta_) || (k == kb && tg > tb_)) continue;
+            }
+            const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
+            sim_ad[c * osc + tt] = (pthv - th) * u + th;
+        }
         return;
     }
     int *fill = reinterpret_cast<int *>(red);
@@ -298,14 +437,14 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int *__restrict__ err_flag,
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int sel,
                              const int *__restrict__ work_list, const int *__restrict__ n_work, int64_t n_all)
 {
     // work_list (from k_af_screen: the (cell, group) blocks with dP0 > 0, count read on the device) or every block
     const int64_t n_items = work_list ? (int64_t)*n_work : n_all;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         adapt_freq_block<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
-                            sim_ad, osc, P_max, P_sub_cap, err_flag, work_list ? (int64_t)work_list[item] : item);
+                            sim_ad, osc, P_max, P_sub_cap, sel, work_list ? (int64_t)work_list[item] : item);
         __syncthreads();  // the LDS is reused by the next block of work
     }
 }

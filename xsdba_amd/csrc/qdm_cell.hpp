@@ -102,16 +102,35 @@ __device__ __forceinline__ int qdm_node_code(double sq, const R *qn, int Q)
     return w;
 }
 
+// The same byte for the ONE row of a single group (utils._interp_on_quantiles_1D with interp1d 'nearest', as interp1d_eval
+// decides it: bounds halfway between the nodes, summed in the table's type, a percent rank ON a bound goes DOWN): complete rows
+// only (no NaN among the nodes or the cell's factors — the compacted row of pass D is then the row itself).
+template <typename R>
+__device__ __forceinline__ int qdm_node_code_1d(double sq, const R *qn, int Q)
+{
+    if (sq != sq) return 255;
+    if (sq < (double)qn[0]) return 0x40;
+    if (sq > (double)qn[Q - 1]) return (Q - 1) | 0x80;
+    int lo = 0, hi = Q - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const R b = qn[mid] / (R)2.0 + qn[mid + 1] / (R)2.0;
+        if ((double)b < sq) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 // The map 2 * rank -> node code of a group depends on the group's (N, ties at the minimum, ties at the maximum) only — not on
 // the cell.  For the triples (N, 1, 1) — a ranking row of N valid values with untied extremes: every row of a cell without NaNs
 // and without ties at its extremes — it is tabulated ONCE per launch, one table per distinct row length of the plan, with the
 // very expressions pass D evaluates per element (utils.rank :631-635 rescaling, two float64 divisions, a bisection).  A cell
 // whose groups all match reads these tables and builds none of its own (k_qdm_cell spent 1.9 K such evaluations per cell on
 // the middle group's table and ~150 instructions per element of every group with another triple: 5 of 12 months).
+// one_d: the row of a single group (1-D nearest: qdm_node_code_1d) instead of the rows of a grouped table.
 // grid: (blocks, classes).
 template <typename R>
 __global__ __launch_bounds__(256) void k_qdm_node_tables(const R *__restrict__ quantiles, int Q, const int *__restrict__ cls_N,
-                                                         const int *__restrict__ cls_off, unsigned char *__restrict__ out)
+                                                         const int *__restrict__ cls_off, unsigned char *__restrict__ out, int one_d)
 {
     __shared__ R qn[64];
     if ((int)threadIdx.x < Q) qn[threadIdx.x] = quantiles[threadIdx.x];
@@ -123,7 +142,8 @@ __global__ __launch_bounds__(256) void k_qdm_node_tables(const R *__restrict__ q
     for (int r2 = blockIdx.x * blockDim.x + threadIdx.x; r2 < 2 * n + 2; r2 += gridDim.x * blockDim.x) {
         const double r = (double)r2 / 2.0;
         const double pr = r / N0;
-        tab[r2] = (unsigned char)(r2 ? qdm_node_code<R>(pmax0 * (pr - pmin0) / (pmax0 - pmin0), qn, Q) : 255);
+        const double sq = pmax0 * (pr - pmin0) / (pmax0 - pmin0);
+        tab[r2] = (unsigned char)(r2 ? (one_d ? qdm_node_code_1d<R>(sq, qn, Q) : qdm_node_code<R>(sq, qn, Q)) : 255);
     }
 }
 
@@ -826,6 +846,24 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
         // (mode 0).  Modes, table offsets and the cell's table live in the unused tail of gstat (groups beyond G).
         const int tidd = (wid << 6) | lane;  // (the thread index from the per-cell opaque lane: what derives from it is formed here, not kept — spilled — across the cell loop)
         const bool bad_nodes = af && G > 1 && tmeta[3];
+        // A single group holding every step (group="time"), interp="nearest", no sim_q wanted: the launch's ONE table (2 * rank ->
+        // node of the row of T values with untied extremes, 1-D flavour) is copied where the elements-by-place of the ranks pass
+        // lay (dead since the barrier above) — the element loop below spent two float64 divisions and a bisection on every step
+        // (4.3 of 9.9 ms per 64 800 cells).  A cell with NaNs (another N), ties at an extreme or NaN factors goes element by element.
+        // (Loaded and stored at once: held across the conversion below, the pieces spilled in the instantiation that serves the months.)
+        const bool one1 = PASS && af && G == 1 && !sim_q && interp == 0 && gt.K == 1;
+        unsigned char *tab1 = smem + Cfg::off_rank;
+        if (one1) {
+            constexpr int T1V = (2 * TPAD + 2 + 16 * NT - 1) / (16 * NT);
+            const int t1_n16 = (2 * gt.N[0] + 2 + 15) >> 4;
+            const uint4 *src = reinterpret_cast<const uint4 *>(gtab + (size_t)gt.off[0] * 16);
+            uint4 t1v[T1V];
+#pragma unroll
+            for (int i = 0; i < T1V; i++) t1v[i] = tidd + i * NT < t1_n16 ? src[tidd + i * NT] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int i = 0; i < T1V; i++)
+                if (tidd + i * NT < t1_n16) reinterpret_cast<uint4 *>(tab1)[tidd + i * NT] = t1v[i];
+        }
         const int Gp = (G + 15) & ~15;
         unsigned char *gmode = reinterpret_cast<unsigned char *>(gstat + 3 * G);   // bits 0-1: 0 / 1 (table in LDS) / 2 (in gtab); bit 2: the launch's
         uint16_t *goff = reinterpret_cast<uint16_t *>(gmode + Gp);                  // where the group's table starts, in units of 16 bytes
@@ -868,6 +906,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 goff[g] = (uint16_t)max(cls_off, 0);
                 kinds |= ni > 0 ? (cls_off >= 0 ? 2 : 1) : 0;
             }
+            if (one1) gmode[0] = (unsigned char)(ni == gt.N[0] && nmini == 1 && nmaxi == 1);
             // (the float64 triple only where something reads it: element by element, or the cell's own table)
             const double N = (double)ni, nmin = (double)nmini, nmax = (double)nmaxi;
             gstat[3 * g] = N;
@@ -910,6 +949,7 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
             __syncthreads();
         }
         XS_CLK(4);
+        const bool use1 = one1 && gmode[0] == 1 && tab_n == Q;
         if (af && use_tab) {
             // All of a thread's (at most RND) elements at once, stage by stage, every load of a stage in flight together: element by
             // element the pass is a chain of dependent round trips (group index -> mode -> table byte -> factor -> store) that all
@@ -966,6 +1006,28 @@ __global__ __launch_bounds__(1024) void k_qdm_cell(
                 if (have && (code[u] & 0xC0) && extrap != 0) a = nan_of<R>();
                 // (streaming store: the result must not push this CU's series out of the L2 before pass D has read it again —
                 //  the keys have left the LDS in the two-stream walk)
+                if (tidd + u * NT < (int)T) __builtin_nontemporal_store(apply_corr<R>(vv[u], a, kind), &scen_c[(unsigned)(tidd + u * NT)]);
+            }
+        } else if (use1) {
+            // (stage by stage, every load of a stage in flight together, as above)
+            R *const scen_c = scen + (size_t)c * T;
+            int rr[RND], code[RND];
+            R vv[RND], aa[RND];
+#pragma unroll
+            for (int u = 0; u < RND; u++) {
+                const int tc = min(tidd + u * NT, (int)T - 1);
+                rr[u] = r2buf[tc];
+                vv[u] = ser.at_time(tc);
+            }
+#pragma unroll
+            for (int u = 0; u < RND; u++) code[u] = tab1[rr[u]];
+#pragma unroll
+            for (int u = 0; u < RND; u++) aa[u] = ty[code[u] & 0x3F];
+#pragma unroll
+            for (int u = 0; u < RND; u++) {
+                const bool have = code[u] != 255;
+                R a = have ? aa[u] : nan_of<R>();
+                if (have && (code[u] & 0xC0) && extrap != 0) a = nan_of<R>();
                 if (tidd + u * NT < (int)T) __builtin_nontemporal_store(apply_corr<R>(vv[u], a, kind), &scen_c[(unsigned)(tidd + u * NT)]);
             }
         } else  // (sim_q wanted, a single group, or no room for the table: element by element)
