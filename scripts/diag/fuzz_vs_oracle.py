@@ -114,8 +114,16 @@ for case in range(n_cases):
             sane = ~(np.abs(elaf) > 1e9) & ~(np.abs(np.asarray(laf)) > 1e9)
             np.testing.assert_allclose(np.asarray(laf)[sane], elaf[sane], rtol=2e-5, equal_nan=True, err_msg="loci af")
             if W == 1 or gname == "doy":  # (a coarse group with a window puts a step several times into one block: refused)
-                out = hip.adapt_freq(sim, ref, gidx, G, W, th, seed=3)
+                import os
+                sel = rng.random() < 0.4   # every block by selection over the row in global memory (the path of rows beyond the LDS sorts)
+                if sel:
+                    os.environ["XSDBA_HIP_AF_SELECT"] = "1"
+                try:
+                    out = hip.adapt_freq(sim, ref, gidx, G, W, th, seed=3)
+                finally:
+                    os.environ.pop("XSDBA_HIP_AF_SELECT", None)
                 eout = oracle.adapt_freq(sim, ref, gidx, G, W, th, seed=3)
+                np.testing.assert_array_equal(np.asarray(out[0]), eout[0], err_msg=f"adapt_freq sim_ad (select={sel})")
                 for nm, a_, b_ in zip(("pth", "dP0", "P0_ref", "P0_hist"), out[1:], eout[1:]):
                     np.testing.assert_allclose(np.asarray(a_), b_, rtol=1e-6, equal_nan=True, err_msg=f"adapt_freq {nm}")
         if G == 1:
