@@ -1,4 +1,4 @@
-"""adapt_freq: the LDS sorts against the selection (XSDBA_HIP_AF_SELECT=1) on rows where both apply, per-kernel times from the
+"""adapt_freq: the LDS sorts (XSDBA_HIP_AF_SELECT=0) against the selection (the default) on rows where both apply, per-kernel times from the
 library's own profile; 8 192 cells x 10 950 days, sim drier than ref everywhere (every block adapts).
     python scripts/experiments/exp_adapt_freq_select.py"""
 import os
@@ -24,9 +24,9 @@ dsim, dref = ctx.to_device(sim), ctx.to_device(ref)
 for gname, gidx, G, W in (("time", np.zeros(T, np.int32), 1, 1), ("month", mon, 12, 1), ("doy31", d0.astype(np.int32), 365, 31)):
     for sel in (False, True, False, True):
         if sel:
-            os.environ["XSDBA_HIP_AF_SELECT"] = "1"
-        else:
             os.environ.pop("XSDBA_HIP_AF_SELECT", None)
+        else:
+            os.environ["XSDBA_HIP_AF_SELECT"] = "0"
         hip.adapt_freq(dsim, dref, gidx, G, W, 1.0, seed=1)
         ctx.synchronize()
         t0 = time.perf_counter()

@@ -1,7 +1,7 @@
 """adapt_freq without a row limit (reference _processing.py:75-142; oracle: xsdba_oracle_adapt_freq): what the LDS does not sort —
 the ref row of pth, the sub-threshold (key, tag) pairs of the ranks — is decided by selection over the row in global memory
-(preproc.hpp block_select2).  Against the oracle bit for bit, and against the LDS sorts where both apply
-(XSDBA_HIP_AF_SELECT=1 sends every block through the selection): windows, months, one group, NaNs, heavy ties (dry days are all
+(preproc.hpp block_select2; the default everywhere since it is no slower).  Against the oracle bit for bit, and against the LDS
+sorts where both apply (XSDBA_HIP_AF_SELECT=0: the LDS sorts wherever they fit): windows, months, one group, NaNs, heavy ties (dry days are all
 0.0: the tags decide), nothing under the threshold, a single valid value, rows beyond the LDS sort (21 900 float64 steps; more
 than 16 384 values under the threshold) and beyond 65 535 values (slots beyond the 16 bits of the LDS tags)."""
 import os
@@ -41,8 +41,8 @@ def _pair(C, T, rng, dtype, dry_sim, dry_ref):
 
 
 def _check(hip, sim, ref, gidx, G, W, select, seed=5):
-    if select:
-        os.environ["XSDBA_HIP_AF_SELECT"] = "1"
+    if not select:
+        os.environ["XSDBA_HIP_AF_SELECT"] = "0"
     try:
         h = hip.adapt_freq(sim, ref, gidx, G, W, 1.0, seed=seed, first_cell=3)
         e = oracle.adapt_freq(sim, ref, gidx, G, W, 1.0, seed=seed, first_cell=3)
@@ -86,7 +86,9 @@ def test_rows_beyond_the_lds(T, dtype, dry):
 
     rng = np.random.default_rng(T)
     sim, ref = _pair(4, T, rng, dtype, dry, 0.3)
-    a = _check(hip, sim, ref, np.zeros(T, np.int32), 1, 1, select=False)
+    a = _check(hip, sim, ref, np.zeros(T, np.int32), 1, 1, select=False)   # (the LDS sorts for whatever part fits them)
+    b = _check(hip, sim, ref, np.zeros(T, np.int32), 1, 1, select=True)
+    np.testing.assert_array_equal(a, b)
     assert (a != sim)[~np.isnan(sim)].any()
 
 
@@ -103,3 +105,4 @@ def test_months_of_a_long_hourly_series():
     m = np.isin(gidx, (0, 1, 2))
     sim[0, m & (rng.random(T) < 0.5)] = 0.0   # winter months of one cell: > 8 192 values under the threshold
     _check(hip, sim, ref, gidx, 12, 1, select=False)
+    _check(hip, sim, ref, gidx, 12, 1, select=True)

@@ -1645,11 +1645,13 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     while (P < pl->max_row) P <<= 1;
     const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
     const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2);
-    // What the LDS does not sort is decided by selection over the row in global memory (preproc.hpp; no row limit):
-    // bit 0: the ref row for pth; bit 1: the ranks whatever their number (always beyond 65 535 values: the slot of the LDS
-    // tags has 16 bits; XSDBA_HIP_AF_SELECT=1 sends everything that way — tests).
-    int sel = (red_b + (size_t)P * sizeof(U) > (size_t)ctx->lds_limit ? 1 : 0) | (pl->max_row > 65535 ? 2 : 0);
-    if (getenv("XSDBA_HIP_AF_SELECT")) sel = 3;
+    // The order statistics of the ref row (bit 0) and the band of the random tie-break (bit 1) by selection over the row in
+    // global memory (preproc.hpp; no row limit, and no slower than the LDS sorts where those apply: 125 against 135 ms per
+    // 8 192 day-of-year cells with every block adapting).  XSDBA_HIP_AF_SELECT=0 (A/B runs, tests): the LDS sorts wherever
+    // they fit — a ref row within the LDS, at most 65 535 values in a block (the slot of the LDS tags has 16 bits).
+    int sel = 3;
+    const char *selenv = getenv("XSDBA_HIP_AF_SELECT");
+    if (selenv && !strcmp(selenv, "0")) sel = (red_b + (size_t)P * sizeof(U) > (size_t)ctx->lds_limit ? 1 : 0) | (pl->max_row > 65535 ? 2 : 0);
     // the (key, tag) pairs of the sub-threshold values: as many as the LDS takes, at most the row
     int Ps = (sel & 2) ? 2 : P;
     while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;

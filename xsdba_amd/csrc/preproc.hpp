@@ -81,9 +81,10 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 // those whose rank k lies in a band [k_lo, k_hi] (the percent rank is monotone in k), i.e. whose (key, tag) lies between the
 // k_lo-th and the k_hi-th smallest: two order statistics, found together by a radix select over the row in global memory
 // (block_select2: a byte per pass, 256-bin histograms in LDS), then one pass that compares.  The same routine reads the two
-// order statistics of the ref row that pth interpolates when that row does not fit the LDS sort (sel bit 0).  sel bit 1: ranks by
-// selection whatever their number (rows beyond 65 535 values, whose slots do not fit the 16 bits of the LDS tags — the selection
-// carries the tag as 16 random bits << 32 | slot, the same order; XSDBA_HIP_AF_SELECT=1: tests).
+// order statistics of the ref row that pth interpolates (sel bit 0).  sel bit 1: ranks by selection whatever their number (the
+// selection carries the tag as 16 random bits << 32 | slot — the order of the LDS tags, with room for the slots of rows beyond
+// 65 535 values).  The host sets both bits (the selection is no slower than the sorts where those apply); XSDBA_HIP_AF_SELECT=0
+// clears them wherever the LDS sorts fit (A/B runs, tests).
 // sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
 // ---------------------------------------------------------------------------------------------
 // The kA-th and the kB-th smallest (0-based; both below the count of elements gen accepts) of the composites (key, 48-bit tag)
