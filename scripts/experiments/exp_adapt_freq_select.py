@@ -29,8 +29,12 @@ for gname, gidx, G, W in (("time", np.zeros(T, np.int32), 1, 1), ("month", mon, 
             os.environ["XSDBA_HIP_AF_SELECT"] = "0"
         hip.adapt_freq(dsim, dref, gidx, G, W, 1.0, seed=1)
         ctx.synchronize()
+        ctx.profile_enable(True); ctx.profile_read(reset=True)
         t0 = time.perf_counter()
         hip.adapt_freq(dsim, dref, gidx, G, W, 1.0, seed=1)
         ctx.synchronize()
-        print(f"{gname:6s} select={int(sel)}  {1e3 * (time.perf_counter() - t0):8.2f} ms per {C} cells", flush=True)
+        wall = 1e3 * (time.perf_counter() - t0)
+        kern = {k: round(v["total_ms"], 2) for k, v in ctx.profile_read(reset=True).items() if v["count"] and v["total_ms"] > 0.02}
+        ctx.profile_enable(False)
+        print(f"{gname:6s} select={int(sel)}  {wall:8.2f} ms per {C} cells  {kern}", flush=True)
 os.environ.pop("XSDBA_HIP_AF_SELECT", None)

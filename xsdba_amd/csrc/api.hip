@@ -1643,21 +1643,27 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     else if ((rc = launch_transpose<R>(ctx, (const R *)s.dev, C, T, s.sc, 1, (R *)o.kernel_dst, T, 1))) return rc;
     int P = 2;
     while (P < pl->max_row) P <<= 1;
-    const int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+    int NT = P >= 8192 ? 1024 : (P >= 2048 ? 512 : (P >= 512 ? 256 : (P >= 128 ? 128 : 64)));
+    if (const char *e = getenv("XSDBA_HIP_AF_THREADS")) { const int v = atoi(e); if (v >= 64 && v <= 1024) NT = (v / 64) * 64; }  // (tuning runs)
     const size_t red_b = sizeof(double) * (2 * (size_t)(NT / 64) + 2);
-    // The order statistics of the ref row (bit 0) and the band of the random tie-break (bit 1) by selection over the row in
-    // global memory (preproc.hpp; no row limit, and no slower than the LDS sorts where those apply: 125 against 135 ms per
-    // 8 192 day-of-year cells with every block adapting).  XSDBA_HIP_AF_SELECT=0 (A/B runs, tests): the LDS sorts wherever
-    // they fit — a ref row within the LDS, at most 65 535 values in a block (the slot of the LDS tags has 16 bits).
-    int sel = 3;
+    // By selection (preproc.hpp adapt_freq_block_sel; no row limit, and no slower than the LDS sorts where those apply), the rows
+    // staged in LDS when they fit.  XSDBA_HIP_AF_SELECT=0 (A/B runs, tests): the bitonic sorts in LDS wherever they apply — a
+    // ref row within the LDS, at most 65 535 values in a block (the slot of the LDS tags has 16 bits).
     const char *selenv = getenv("XSDBA_HIP_AF_SELECT");
-    if (selenv && !strcmp(selenv, "0")) sel = (red_b + (size_t)P * sizeof(U) > (size_t)ctx->lds_limit ? 1 : 0) | (pl->max_row > 65535 ? 2 : 0);
-    // the (key, tag) pairs of the sub-threshold values: as many as the LDS takes, at most the row
-    int Ps = (sel & 2) ? 2 : P;
-    while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;
-    const size_t lds = red_b + std::max({(sel & 1) ? (size_t)0 : (size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t)),
-                                         (size_t)2560 /* the selection's histograms; the per-wave minima */});
-    if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq row sort"))) return rc;
+    const bool sorts = selenv && !strcmp(selenv, "0") && red_b + (size_t)P * sizeof(U) <= (size_t)ctx->lds_limit && pl->max_row <= 65535;
+    const size_t sel_b = (size_t)(32 + 2048) * sizeof(int);  // counters, results, four histograms (the last two double-buffered)
+    int Lcap = -1, Ps = P;
+    size_t lds;
+    if (sorts) {
+        // the (key, tag) pairs of the sub-threshold values: as many as the LDS takes, at most the row
+        while (Ps > 2 && red_b + (size_t)Ps * (sizeof(U) + sizeof(uint32_t)) > (size_t)ctx->lds_limit) Ps >>= 1;
+        lds = std::max(red_b + std::max((size_t)P * sizeof(U), (size_t)Ps * (sizeof(U) + sizeof(uint32_t))), sel_b);
+    } else {
+        const size_t per = (ref ? 2 : 1) * sizeof(R) + sizeof(int);  // a staged element: the sim value, the ref value (training), the time step
+        Lcap = sel_b + (size_t)pl->max_row * per <= (size_t)ctx->lds_limit ? pl->max_row : 0;
+        lds = sel_b + (size_t)Lcap * per;
+    }
+    if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq rows"))) return rc;
     // [0] unused, [1] length of the work list, [2...] the (cell, group) blocks with dP0 > 0
     void *flag;
     if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (ng + 2), &flag))) return rc;
@@ -1666,7 +1672,9 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     // cheap screening pass per cell (prefix sums over time) when the four prefix arrays fit the LDS
     const int snt = 512;
     const size_t slds = (((size_t)8 * (size_t)(T + 1) + 15) & ~(size_t)15) + sizeof(int) * 2 * snt;
-    const bool screened = T < 65535 && slds <= (size_t)ctx->lds_limit;
+    // (a thread per group there: with few groups — one group: ONE thread walks the whole series, 77 ms per 8 192 cells against 2.8 for
+    //  everything k_adapt_freq does — the blocks count for themselves, in parallel)
+    const bool screened = T < 65535 && slds <= (size_t)ctx->lds_limit && G >= 64;
     if (screened) {
         if ((rc = set_lds(xs::k_af_screen<R>, slds, ctx, "the adapt_freq prefix sums"))) return rc;
         LaunchScope ls(ctx, "k_af_screen");
@@ -1684,7 +1692,7 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
                            ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
                            pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
                            ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),
-                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, sel, screened ? work_list : (const int *)nullptr,
+                           (double *)o3.dev, (R *)o.kernel_dst, T, P, Ps, Lcap, screened ? work_list : (const int *)nullptr,
                            screened ? n_work : (const int *)nullptr, (int64_t)ng);
         if ((rc = check_launch("k_adapt_freq"))) return rc;
     }

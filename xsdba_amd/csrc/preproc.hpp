@@ -75,81 +75,305 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 //   the time series keeps the window-centre element of each block (base.py:438-439), i.e. time step t is corrected by the
 //   block of ITS group.
 // Ties are broken by the order of (key, tag) pairs, tag = 16 random bits (stream 3, mixed with the group) | slot in the row.
-// dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: max(P_max, Ps) * sizeof(U)] with [tags: Ps * 4] behind the first Ps keys,
-// Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values (sorted in LDS).
-// No row limit (round 5): what the LDS does not take is decided by SELECTION instead of sorting — the replaced values are
-// those whose rank k lies in a band [k_lo, k_hi] (the percent rank is monotone in k), i.e. whose (key, tag) lies between the
-// k_lo-th and the k_hi-th smallest: two order statistics, found together by a radix select over the row in global memory
-// (block_select2: a byte per pass, 256-bin histograms in LDS), then one pass that compares.  The same routine reads the two
-// order statistics of the ref row that pth interpolates (sel bit 0).  sel bit 1: ranks by selection whatever their number (the
-// selection carries the tag as 16 random bits << 32 | slot — the order of the LDS tags, with room for the slots of rows beyond
-// 65 535 values).  The host sets both bits (the selection is no slower than the sorts where those apply); XSDBA_HIP_AF_SELECT=0
-// clears them wherever the LDS sorts fit (A/B runs, tests).
 // sim_ad must hold a copy of sim on entry (time steps in no group and untouched values keep it).
+//
+// adapt_freq_block_sel (the default): by SELECTION, no row limit.  The replaced values are those whose rank k lies in a band
+// [k_lo, k_hi] (the percent rank is monotone in k: the band's ends by bisection on the very expression), i.e. whose (key, tag)
+// lies between the k_lo-th and the k_hi-th smallest of the sub-threshold values; pth interpolates two order statistics of the
+// ref row.  The four order statistics are found TOGETHER by one radix select, a byte per pass, most significant first
+// (sizeof(key) passes over the keys of both rows, then 4 — rows beyond 65 536 values: 6 — over the tags of the sim elements on
+// a selected key; four 256-bin histograms in LDS, a wave per histogram finds the bin), then one pass compares.  The rows are
+// read from global memory once and staged in LDS (values, time steps) when they fit (Lcap > 0), else gathered in every pass.
+// Two barriers per pass: histograms and results are double-buffered (a pass clears the next pass's bins while it counts).
+// dynamic LDS: [4 counters, 2 x 8 results: 32 ints][2 x 4 x 256 bins][Lcap sim values][Lcap ref values (training)][Lcap time steps]
+//
+// adapt_freq_block (XSDBA_HIP_AF_SELECT=0: A/B runs, tests; rows within the LDS, at most 65 535 values): bitonic sorts in LDS of
+// the ref row and of the sub-threshold (key, tag) pairs; a block with more pairs than the LDS takes goes through
+// adapt_freq_block_sel.
+// dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: max(P_max, Ps) * sizeof(U)] with [tags: Ps * 4] behind the first Ps keys,
+// Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values
 // ---------------------------------------------------------------------------------------------
-// The kA-th and the kB-th smallest (0-based; both below the count of elements gen accepts) of the composites (key, 48-bit tag)
-// that gen(i, key, tag, need_tag) yields for i in [0, L), most significant byte first: sizeof(U) passes over the keys, six
-// over the tags of the elements whose key is a selected one (with_tag; the tag is only asked for then).
-// hist: 516 ints of LDS.  Whole block; ends on a barrier.
-template <typename U, typename Gen>
-__device__ __forceinline__ void block_select2(Gen gen, int L, bool with_tag, int kA, int kB, int *hist, U &keyA, uint64_t &tagA,
-                                              U &keyB, uint64_t &tagB)
+// inclusive wave64 prefix sum on the DPP path (train_cell.hpp's wave_incl_scan; this header does not see it)
+__device__ __forceinline__ int af_wave_incl_scan(int v)
 {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
+template <typename R>
+__device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
+                             const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
+                             double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
+                             double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
+                             R *__restrict__ sim_ad, int64_t osc, int Lcap, int64_t block_id)
+{
+    using U = typename KeyOf<R>::U;
     constexpr int KBY = (int)sizeof(U);
-    const int npass = KBY + (with_tag ? 6 : 0);
-    const int lane = threadIdx.x & 63;
-    int *res = hist + 512;
-    keyA = keyB = 0;
-    tagA = tagB = 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *cnt = reinterpret_cast<int *>(smem);  // [0..3] #valid / #(<= thresh) of sim, of ref
+    int *res2 = cnt + 8;                       // [pass & 1][2 s], [2 s + 1]: the digit of target s, its rank among that bin's
+    int *hist2 = cnt + 32;                     // [pass & 1][4][256]
+    R *sv = reinterpret_cast<R *>(hist2 + 2048);
+    R *srv = sv + Lcap;
+    int *stt = reinterpret_cast<int *>(sv + (train ? 2 : 1) * (size_t)Lcap);
+    const bool stage = Lcap > 0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    const int64_t c = block_id / G;
+    const int g = (int)(block_id % G);
+    const int p0 = row_ptr[g], L = row_ptr[g + 1] - p0;
+    const R *xs = sim + c * sc;
+    const R *xr = train ? ref + c * rsc : nullptr;
+    const size_t og = (size_t)c * G + g;
+
+    // ---- the rows, once: counts (utils.ecdf :87-105), staged copies
+    if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+    int c_n = 0, c_0 = 0, r_n = 0, r_0 = 0;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const int tt = row_idx[p0 + i];
+        const R v = xs[tt];
+        if (stage) { sv[i] = v; stt[i] = tt; }
+        if (v == v) { c_n++; if ((double)v <= thresh) c_0++; }
+        if (train) {
+            const R rv = xr[tt];
+            if (stage) srv[i] = rv;
+            if (rv == rv) { r_n++; if ((double)rv <= thresh) r_0++; }
+        }
+    }
+    // (the loads of four elements of a thread issued together — indexes, then values — measured: slower, 89.5 against 81 ms per
+    //  8 192 day-of-year cells; the phase is 4.4 ms of the kernel — -DXS_AF_STOP=1 — the rest is the passes: 14 ms per key pass,
+    //  7 per tag pass)
+#if defined(XS_AF_STOP) && XS_AF_STOP == 1
+    if (c_n == -12345) sim_ad[0] = (R)0;
+    return;
+#endif
+    c_n = wave_sum(c_n); c_0 = wave_sum(c_0); r_n = wave_sum(r_n); r_0 = wave_sum(r_0);
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&cnt[0], c_n); atomicAdd(&cnt[1], c_0); atomicAdd(&cnt[2], r_n); atomicAdd(&cnt[3], r_0); }
+    __syncthreads();
+    const int N = cnt[0], n0 = cnt[1], nr = cnt[2];
+    const double P0_sim = N ? (double)n0 / (double)N : __builtin_nan("");
+    double p0r, p0h;
+    if (train) { p0r = nr ? (double)cnt[3] / (double)nr : __builtin_nan(""); p0h = P0_sim; }
+    else { p0r = P0_ref[og]; p0h = P0_hist[og]; }
+    const double dP0 = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
+    if (threadIdx.x == 0) {
+        if (train) { P0_ref[og] = p0r; P0_hist[og] = p0h; }
+        if (dP0_out) dP0_out[og] = dP0;
+    }
+    if (!(dP0 > 0.0)) {  // no adaptation needed (or undefined): sim_ad keeps sim
+        if (train && threadIdx.x == 0) pth[og] = nan_of<R>();
+        return;
+    }
+
+    // ---- the band of ranks that are replaced.  With n0 > 0 values <= thresh only those can be replaced: a value above it has
+    // rnk >= n0 / (N - 1) > n0 / N = P0_sim ("too big"); they come first in the full order, hence their ranks are k = 1 .. n0.
+    // rnk(k) — xarray's k/N rescaled as utils.rank does, mx * (rnk - mn) / (mx - mn) with mx = N/N, mn = 1/N — is
+    // non-decreasing in k (every operation is monotone under rounding; 0 / 0 = NaN for N = 1 fails both tests: replaced), so
+    // "rnk < lowb" holds on a prefix of k = 1 .. n0 and "rnk > P0_sim" on a suffix.
+    const double lowb = (p0r / p0h) * P0_sim;
+    const R th = (R)thresh;
+    auto rnk_of = [&](int k) {
+        const double rk = (double)k / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
+        return mx * (rk - mn) / (mx - mn);
+    };
+    // (Found by wave 0, thirty-two probes of each search per round: the expression holds four float64 divisions, a bisection by
+    //  every thread of the block was ~20 evaluations per thread — a fifth of the kernel on day-of-year rows.)
+    if (wid == 0 && n0 > 0) {
+        const int half = lane >> 5, l5 = lane & 31;
+        int lo = 1, hi = n0 + 1;  // the first k with "not (rnk < lowb)" (lanes 0-31) / with "rnk > P0_sim" (lanes 32-63); n0 + 1: none
+        while (__any(hi > lo)) {
+            const int step = (hi - lo + 31) >> 5;
+            const int kq = lo + l5 * step;  // ascending probes; at or beyond hi: true
+            const bool pr = kq >= hi ? true : (half == 0 ? !(rnk_of(kq) < lowb) : (rnk_of(kq) > P0_sim));
+            const unsigned long long bal = __ballot(pr);
+            const uint32_t m = half == 0 ? (uint32_t)bal : (uint32_t)(bal >> 32);
+            const int ft = m ? __ffs((int)m) - 1 : 32;  // the first true probe: the answer lies behind the probe before it, up to it
+            const int nhi = ft < 32 ? min(lo + ft * step, hi) : hi;
+            const int nlo = ft > 0 ? lo + (ft - 1) * step + 1 : lo;
+            lo = nlo; hi = nhi;
+        }
+        if (l5 == 0) cnt[4 + half] = lo;
+    }
+    __syncthreads();
+    const int k_lo = n0 > 0 ? cnt[4] : 1, k_hi = n0 > 0 ? cnt[5] - 1 : 0;
+    const bool do_s = k_lo <= k_hi, do_r = train != 0;
+    // the (at most) two order statistics of the ref row that vecquantile_sorted reads (dP0 > 0: nr >= 1, p0h is a number)
+    int ia = 0, ib = 0;
+    if (do_r && nr > 1) {
+        const double pp = p0h * 100.0;
+        if (pp == 100.0) ia = ib = nr - 1;
+        else if (pp != 0.0) {
+            const double rank = 1.0 + (double)(nr - 1) * (pp / 100.0);
+            int lo = (int)floor(rank) - 1;
+            lo = lo < 0 ? 0 : (lo > nr - 2 ? nr - 2 : lo);
+            ia = lo; ib = lo + 1;
+        }
+    }
+    const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
+    const int TB = L > 65536 ? 48 : 32;  // bits of a tag: 16 random ones above the slot (the same order either way)
+    auto tag_of = [&](int tt, int slot) { return ((uint64_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << (TB - 16)) | (uint64_t)(uint32_t)slot; };
+    auto sim_at = [&](int i) { return stage ? sv[i] : xs[row_idx[p0 + i]]; };
+    auto ref_at = [&](int i) { return stage ? srv[i] : xr[row_idx[p0 + i]]; };
+    auto tt_at = [&](int i) { return stage ? stt[i] : row_idx[p0 + i]; };
+
+    // ---- the radix select.  Targets 0, 1: the (k_lo - 1)-th and (k_hi - 1)-th smallest (key, tag) of the sub-threshold sim
+    // values (-0.0 ranks as +0.0, a tie, like the float comparison of the reference); 2, 3: the ia-th and ib-th smallest valid
+    // ref key.
+    U keyA = 0, keyB = 0, keyC = 0, keyD = 0;
+    uint64_t tagA = 0, tagB = 0;
+    int kA = k_lo - 1, kB = k_hi - 1, kC = ia, kD = ib;
+#if defined(XS_AF_STOP) && XS_AF_STOP == 2
+    const int npass = KBY;
+#else
+    const int npass = do_s ? KBY + TB / 8 : (do_r ? KBY : 0);
+#endif
+    // (two targets of a row share a histogram as long as the digits chosen for them are the same: the exponent bytes of a row's
+    //  keys nearly always, every byte when both statistics fall on one value — half the adds of those passes)
+    bool sameAB = true, sameCD = true;
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist2[i] = 0;
+    __syncthreads();
     for (int p = 0; p < npass; p++) {
-        for (int i = threadIdx.x; i < 512; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
+        int *hist = hist2 + 1024 * (p & 1), *res = res2 + 8 * (p & 1);
+        {   // the bins of the next pass (last read before the second barrier of the previous pass)
+            int *hn = hist2 + 1024 * ((p + 1) & 1);
+            for (int i = threadIdx.x; i < 1024; i += blockDim.x) hn[i] = 0;
+        }
         const bool kp = p < KBY;
-        const int t = p - KBY;
-        const int sh = kp ? 8 * (KBY - 1 - p) : 8 * (5 - t);
+        const int sh = kp ? 8 * (KBY - 1 - p) : TB - 8 - 8 * (p - KBY);
+        const bool first = p == 0 || p == KBY;  // (no digits of the key / of the tag chosen yet)
+        for (int i0 = 0; i0 < L; i0 += blockDim.x) {
+            const int i = i0 + (int)threadIdx.x;
+            if (do_s) {
+                bool onA = false, onB = false;
+                int d = 0;
+                if (i < L) {
+                    const R v = sim_at(i);
+                    if (v == v && (double)v <= thresh) {
+                        const U k = to_key(v + (R)0);
+                        if (kp) {
+                            d = (int)((k >> sh) & 0xFF);
+                            onA = first || ((k ^ keyA) >> (sh + 8)) == 0;
+                            onB = first || ((k ^ keyB) >> (sh + 8)) == 0;
+                        } else {
+                            const bool mA = k == keyA, mB = k == keyB;
+                            if (mA || mB) {
+                                const uint64_t tg = tag_of(tt_at(i), i);
+                                d = (int)((tg >> sh) & 0xFF);
+                                onA = mA && (first || ((tg ^ tagA) >> (sh + 8)) == 0);
+                                onB = mB && (first || ((tg ^ tagB) >> (sh + 8)) == 0);
+                            }
+                        }
+                    }
+                }
+                if (onA) atomicAdd(&hist[d], 1);
+                if (onB && !sameAB) atomicAdd(&hist[256 + d], 1);
+            }
+            if (do_r && kp) {
+                bool onC = false, onD = false;
+                int d = 0;
+                if (i < L) {
+                    const R rv = ref_at(i);
+                    if (rv == rv) {
+                        const U k = to_key(rv);
+                        d = (int)((k >> sh) & 0xFF);
+                        onC = first || ((k ^ keyC) >> (sh + 8)) == 0;
+                        onD = first || ((k ^ keyD) >> (sh + 8)) == 0;
+                    }
+                }
+                if (onC) atomicAdd(&hist[512 + d], 1);
+                if (onD && !sameCD) atomicAdd(&hist[768 + d], 1);
+            }
+        }
+        __syncthreads();
+        // a wave per target: the bin that holds its k-th candidate, and k among that bin's
+        for (int s_ = wid; s_ < 4; s_ += nw) {
+            if (s_ < 2 ? !do_s : !(do_r && kp)) continue;
+            const int k = s_ == 0 ? kA : (s_ == 1 ? kB : (s_ == 2 ? kC : kD));
+            const int *h = hist + 256 * ((s_ == 1 && sameAB) ? 0 : ((s_ == 3 && sameCD) ? 2 : s_)) + 4 * lane;
+            const int c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
+            const int tot = c0 + c1 + c2 + c3;
+            const int incl = af_wave_incl_scan(tot);
+            const int excl = incl - tot;
+            if (k >= excl && k < incl) {
+                int r = k - excl, j = 0;
+                if (r >= c0) { r -= c0; j = 1; if (r >= c1) { r -= c1; j = 2; if (r >= c2) { r -= c2; j = 3; } } }
+                res[2 * s_] = 4 * lane + j;
+                res[2 * s_ + 1] = r;
+            }
+        }
+        __syncthreads();
+        if (do_s) {
+            if (kp) { keyA |= (U)res[0] << sh; keyB |= (U)res[2] << sh; }
+            else { tagA |= (uint64_t)res[0] << sh; tagB |= (uint64_t)res[2] << sh; }
+            kA = res[1]; kB = res[3];
+            sameAB = sameAB && res[0] == res[2];
+        }
+        if (do_r && kp) { keyC |= (U)res[4] << sh; keyD |= (U)res[6] << sh; kC = res[5]; kD = res[7]; sameCD = sameCD && res[4] == res[6]; }
+    }
+
+    // ---- pth = np.nanquantile on the float64 copy of the ref row (the gufunc's float64 loop), rounded once
+    R pthv;
+    if (train) {
+        auto load = [&](int i) { return (double)from_key(i == ia ? keyC : keyD); };
+        pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
+        if (threadIdx.x == 0) pth[og] = pthv;
+    } else pthv = pth[og];
+
+    if (n0 == 0) {
+        // nothing under the threshold although the training asks for adaptation: P0_sim = 0 and the smallest value has
+        // rnk = 0 = P0_sim, inside the band, so the reference replaces it.  Lexicographic (key, tag) minimum of the row.
+        U bk = KeyOf<R>::MAXK;
+        uint64_t bt = ~0ull;
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            U k;
-            uint64_t tg = 0;
-            if (!gen(i, k, tg, false)) continue;
-            if (kp) {
-                const int d = (int)((k >> sh) & 0xFF);
-                if (p == 0 || ((k ^ keyA) >> (sh + 8)) == 0) atomicAdd(&hist[d], 1);
-                if (p == 0 || ((k ^ keyB) >> (sh + 8)) == 0) atomicAdd(&hist[256 + d], 1);
-            } else {
-                const bool mA = k == keyA, mB = k == keyB;
-                if (mA || mB) {
-                    (void)gen(i, k, tg, true);
-                    const int d = (int)((tg >> sh) & 0xFF);
-                    if (mA && (t == 0 || ((tg ^ tagA) >> (sh + 8)) == 0)) atomicAdd(&hist[d], 1);
-                    if (mB && (t == 0 || ((tg ^ tagB) >> (sh + 8)) == 0)) atomicAdd(&hist[256 + d], 1);
+            const R v = sim_at(i);
+            if (v == v) {
+                const U k = to_key(v + (R)0);
+                if (k <= bk) {
+                    const uint64_t tg = tag_of(tt_at(i), i);
+                    if (k < bk || tg < bt) { bk = k; bt = tg; }
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x < 64) {  // wave 0: the bin that holds the k-th candidate, and k among that bin's
-            for (int s_ = 0; s_ < 2; s_++) {
-                const int k = s_ ? kB : kA;
-                const int *h = hist + 256 * s_ + 4 * lane;
-                const int c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
-                const int tot = c0 + c1 + c2 + c3;
-                int incl = tot;
-                for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
-                const int excl = incl - tot;
-                if (k >= excl && k < incl) {
-                    int r = k - excl, j = 0;
-                    if (r >= c0) { r -= c0; j = 1; if (r >= c1) { r -= c1; j = 2; if (r >= c2) { r -= c2; j = 3; } } }
-                    res[2 * s_] = 4 * lane + j;
-                    res[2 * s_ + 1] = r;
-                }
-            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const U ok = __shfl_down(bk, o, 64);
+            const uint64_t ot = __shfl_down(bt, o, 64);
+            if (ok < bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
         }
         __syncthreads();
-        const int dA = res[0], dB = res[2];
-        kA = res[1];
-        kB = res[3];
-        if (kp) { keyA |= (U)dA << sh; keyB |= (U)dB << sh; }
-        else { tagA |= (uint64_t)dA << sh; tagB |= (uint64_t)dB << sh; }
-        __syncthreads();  // (res is read before the next pass clears the histograms)
+        U *wk = reinterpret_cast<U *>(hist2);                // per wave: key, tag
+        uint64_t *wt = reinterpret_cast<uint64_t *>(hist2 + 256);
+        if (lane == 0) { wk[wid] = bk; wt[wid] = bt; }
+        __syncthreads();
+        if (threadIdx.x == 0 && N > 0) {
+            for (int w = 1; w < nw; w++) if (wk[w] < bk || (wk[w] == bk && wt[w] < bt)) { bk = wk[w]; bt = wt[w]; }
+            const int tt = tt_at((int)(bt & (TB == 48 ? 0xFFFFFFFFull : 0xFFFFull)));
+            const double rnk = rnk_of(1);
+            if (gidx[tt] == g && !((rnk < lowb) || (rnk > P0_sim))) {
+                const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
+                sim_ad[c * osc + tt] = (pthv - th) * u + th;
+            }
+        }
+        return;
+    }
+    if (!do_s) return;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const R v = sim_at(i);
+        if (!(v == v && (double)v <= thresh)) continue;
+        const U k = to_key(v + (R)0);
+        if (k < keyA || k > keyB) continue;
+        const int tt = tt_at(i);
+        if (gidx[tt] != g) continue;  // (only the block's centre elements reach the time series)
+        if (k == keyA || k == keyB) {
+            const uint64_t tg = tag_of(tt, i);
+            if ((k == keyA && tg < tagA) || (k == keyB && tg > tagB)) continue;
+        }
+        const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
+        sim_ad[c * osc + tt] = (pthv - th) * u + th;
     }
 }
 
@@ -158,7 +382,7 @@ __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, cons
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int sel, int64_t block_id)
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int64_t block_id)
 {
     using U = typename KeyOf<R>::U;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -197,41 +421,17 @@ __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, cons
                 k = to_key(v);
                 if (v == v) { nr++; if ((double)v <= thresh) c0r += 1.0; }
             }
-            if (!(sel & 1)) keys[i] = k;
+            keys[i] = k;
         }
         block_sum_count(c0r, nr, red);
         p0r = nr ? c0r / (double)nr : __builtin_nan("");
         p0h = P0_sim;
         const double d = p0h == 0.0 ? __builtin_nan("") : (p0h - p0r) / p0h;
         pthv = nan_of<R>();
-        if (d > 0.0 && !(sel & 1)) {  // block-uniform
+        if (d > 0.0) {  // block-uniform
             block_bitonic_sort<U>(keys, P);
             auto load = [&](int i) { return (double)from_key(keys[i]); };
             // np.nanquantile on the float64 copy of the row (the gufunc's float64 loop), rounded once
-            pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
-        } else if (d > 0.0) {
-            // the row stays in global memory: the (at most) two order statistics vecquantile_sorted reads, by selection
-            // (d > 0: nr >= 1 and p0h is a number)
-            int ia = 0, ib = 0;
-            if (nr > 1) {
-                const double pp = p0h * 100.0;
-                if (pp == 100.0) ia = ib = nr - 1;
-                else if (pp != 0.0) {
-                    const double rank = 1.0 + (double)(nr - 1) * (pp / 100.0);
-                    int lo = (int)floor(rank) - 1;
-                    lo = lo < 0 ? 0 : (lo > nr - 2 ? nr - 2 : lo);
-                    ia = lo; ib = lo + 1;
-                }
-            }
-            auto gen_ref = [&](int i, U &k, uint64_t &, bool) {
-                const R v = xr[row_idx[p0 + i]];
-                k = to_key(v);
-                return v == v;
-            };
-            U ka, kb;
-            uint64_t ta_, tb_;
-            block_select2<U>(gen_ref, L, false, ia, ib, reinterpret_cast<int *>(keys), ka, ta_, kb, tb_);
-            auto load = [&](int i) { return (double)from_key(i == ia ? ka : kb); };
             pthv = (R)vecquantile_sorted<double>(load, nr, p0h);
         }
         __syncthreads();
@@ -262,81 +462,41 @@ __device__ __forceinline__ void adapt_freq_block(const R *__restrict__ sim, cons
     };
     const uint64_t gm = mix64((uint64_t)(g + 1) * 0xD1B54A32D192ED03ull);
     auto tag_of = [&](int tt, int slot) { return ((uint32_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 16) | (uint32_t)slot; };
-    // (the same order with room for any slot: rows beyond 65 535 values, the selection)
-    auto tag48_of = [&](int tt, int slot) { return ((uint64_t)(mix64(rng_hash(seed, cell0 + c, tt, 3) ^ gm) >> 48) << 32) | (uint64_t)(uint32_t)slot; };
     if (n0 == 0) {
         // nothing under the threshold although the training asks for adaptation: P0_sim = 0 and the smallest value has
         // rnk = 0 = P0_sim, inside the band, so the reference replaces it.  Lexicographic (key, tag) minimum of the row.
         U bk = KeyOf<R>::MAXK;
-        uint64_t bt = ~0ull;
+        uint32_t bt = 0xFFFFFFFFu;
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
             const int tt = row_idx[p0 + i];
             const R v = xs[tt];
             if (v == v) {
                 const U k = to_key(v + (R)0);
-                if (k <= bk) {
-                    const uint64_t tg = tag48_of(tt, i);
-                    if (k < bk || tg < bt) { bk = k; bt = tg; }
-                }
+                const uint32_t tg = tag_of(tt, i);
+                if (k < bk || (k == bk && tg < bt)) { bk = k; bt = tg; }
             }
         }
         for (int o = 32; o > 0; o >>= 1) {
             const U ok = __shfl_down(bk, o, 64);
-            const uint64_t ot = __shfl_down(bt, o, 64);
+            const uint32_t ot = __shfl_down(bt, o, 64);
             if (ok < bk || (ok == bk && ot < bt)) { bk = ok; bt = ot; }
         }
-        uint64_t *wt = reinterpret_cast<uint64_t *>(keys + 64);  // (per wave: key in keys[w], tag in wt[w])
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) { keys[threadIdx.x >> 6] = bk; wt[threadIdx.x >> 6] = bt; }
+        if ((threadIdx.x & 63) == 0) { keys[threadIdx.x >> 6] = bk; tags[threadIdx.x >> 6] = bt; }
         __syncthreads();
         if (threadIdx.x == 0 && N > 0) {
-            for (int w = 1; w < nw; w++) if (keys[w] < bk || (keys[w] == bk && wt[w] < bt)) { bk = keys[w]; bt = wt[w]; }
-            const int tt = row_idx[p0 + (int)(uint32_t)bt];
+            for (int w = 1; w < nw; w++) if (keys[w] < bk || (keys[w] == bk && tags[w] < bt)) { bk = keys[w]; bt = tags[w]; }
+            const int tt = row_idx[p0 + (int)(bt & 0xFFFFu)];
             if (gidx[tt] == g) replace_if_in_band(1, tt);
         }
         return;
     }
     int Ps = 2;
     while (Ps < n0) Ps <<= 1;
-    if (Ps > P_sub_cap || (sel & 2)) {  // block-uniform: more pairs than the LDS sorts (or rows with slots beyond 16 bits)
-        // the band of ranks that are replaced: rnk(k) is non-decreasing in k (every operation of replace_if_in_band's expression
-        // is monotone under rounding; 0 / 0 = NaN for N = 1 fails both tests: replaced), so "rnk < lowb" holds on a prefix of
-        // k = 1 .. n0 and "rnk > P0_sim" on a suffix
-        auto rnk_of = [&](int k) {
-            const double rk = (double)k / (double)N, mn = 1.0 / (double)N, mx = (double)N / (double)N;
-            return mx * (rk - mn) / (mx - mn);
-        };
-        int lo = 1, hi = n0 + 1;
-        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rnk_of(mid) < lowb) lo = mid + 1; else hi = mid; }
-        const int k_lo = lo;
-        lo = 1; hi = n0 + 1;
-        while (lo < hi) { const int mid = lo + ((hi - lo) >> 1); if (rnk_of(mid) > P0_sim) hi = mid; else lo = mid + 1; }
-        const int k_hi = lo - 1;
-        if (k_lo > k_hi) return;
-        auto gen_sub = [&](int i, U &k, uint64_t &tg, bool need_tag) {
-            const int tt = row_idx[p0 + i];
-            const R v = xs[tt];
-            if (!(v == v && (double)v <= thresh)) return false;
-            k = to_key(v + (R)0);
-            if (need_tag) tg = tag48_of(tt, i);
-            return true;
-        };
-        U ka, kb;
-        uint64_t ta_, tb_;
-        block_select2<U>(gen_sub, L, true, k_lo - 1, k_hi - 1, reinterpret_cast<int *>(keys), ka, ta_, kb, tb_);
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            const int tt = row_idx[p0 + i];
-            const R v = xs[tt];
-            if (!(v == v && (double)v <= thresh) || gidx[tt] != g) continue;  // (only the block's centre elements reach the time series)
-            const U k = to_key(v + (R)0);
-            if (k < ka || k > kb) continue;
-            if (k == ka || k == kb) {
-                const uint64_t tg = tag48_of(tt, i);
-                if ((k == ka && tg < ta_) || (k == kb && tg > tb_)) continue;
-            }
-            const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
-            sim_ad[c * osc + tt] = (pthv - th) * u + th;
-        }
+    if (Ps > P_sub_cap) {  // block-uniform: more pairs than the LDS sorts — the whole block again, by selection (rows in global memory)
+        __syncthreads();
+        adapt_freq_block_sel<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
+                                sim_ad, osc, 0, block_id);
         return;
     }
     int *fill = reinterpret_cast<int *>(red);
@@ -438,14 +598,20 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
-                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap, int sel,
+                             R *__restrict__ sim_ad, int64_t osc, int P_max, int P_sub_cap,
+                             int Lcap /* >= 0: by selection, rows of up to Lcap values staged in LDS (0: none); -1: the LDS sorts */,
                              const int *__restrict__ work_list, const int *__restrict__ n_work, int64_t n_all)
 {
     // work_list (from k_af_screen: the (cell, group) blocks with dP0 > 0, count read on the device) or every block
     const int64_t n_items = work_list ? (int64_t)*n_work : n_all;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        adapt_freq_block<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
-                            sim_ad, osc, P_max, P_sub_cap, sel, work_list ? (int64_t)work_list[item] : item);
+        const int64_t id = work_list ? (int64_t)work_list[item] : item;
+        if (Lcap >= 0)
+            adapt_freq_block_sel<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
+                                    sim_ad, osc, Lcap, id);
+        else
+            adapt_freq_block<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
+                                sim_ad, osc, P_max, P_sub_cap, id);
         __syncthreads();  // the LDS is reused by the next block of work
     }
 }
