@@ -93,6 +93,14 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 // dynamic LDS: [red: 2*(NT/64)+2 doubles][keys: max(P_max, Ps) * sizeof(U)] with [tags: Ps * 4] behind the first Ps keys,
 // Ps = min(P_max, P_sub_cap) pairs for the sub-threshold values
 // ---------------------------------------------------------------------------------------------
+#ifndef XS_AF_CLK
+#define XS_AF_CLK 0
+#endif
+#if XS_AF_CLK  // shader-clock shares of adapt_freq_block_sel's phases, printed by the first work item of block 0 (tuning builds)
+#define AF_CLK(i) do { const long long now_ = clock64(); clk_[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define AF_CLK(i) do { } while (0)
+#endif
 // inclusive wave64 prefix sum on the DPP path (train_cell.hpp's wave_incl_scan; this header does not see it)
 __device__ __forceinline__ int af_wave_incl_scan(int v)
 {
@@ -130,6 +138,9 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
     const R *xr = train ? ref + c * rsc : nullptr;
     const size_t og = (size_t)c * G + g;
 
+#if XS_AF_CLK
+    long long clk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
     // ---- the rows, once: counts (utils.ecdf :87-105), staged copies
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     int c_n = 0, c_0 = 0, r_n = 0, r_0 = 0;
@@ -155,6 +166,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
     __syncthreads();
     if (lane == 0) { atomicAdd(&cnt[0], c_n); atomicAdd(&cnt[1], c_0); atomicAdd(&cnt[2], r_n); atomicAdd(&cnt[3], r_0); }
     __syncthreads();
+    AF_CLK(0);
     const int N = cnt[0], n0 = cnt[1], nr = cnt[2];
     const double P0_sim = N ? (double)n0 / (double)N : __builtin_nan("");
     double p0r, p0h;
@@ -201,6 +213,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
     }
     __syncthreads();
     const int k_lo = n0 > 0 ? cnt[4] : 1, k_hi = n0 > 0 ? cnt[5] - 1 : 0;
+    AF_CLK(1);
     const bool do_s = k_lo <= k_hi, do_r = train != 0;
     // the (at most) two order statistics of the ref row that vecquantile_sorted reads (dP0 > 0: nr >= 1, p0h is a number)
     int ia = 0, ib = 0;
@@ -289,7 +302,9 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
                 if (onD && !sameCD) atomicAdd(&hist[768 + d], 1);
             }
         }
+        AF_CLK(2);
         __syncthreads();
+        AF_CLK(3);
         // a wave per target: the bin that holds its k-th candidate, and k among that bin's
         for (int s_ = wid; s_ < 4; s_ += nw) {
             if (s_ < 2 ? !do_s : !(do_r && kp)) continue;
@@ -306,7 +321,9 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
                 res[2 * s_ + 1] = r;
             }
         }
+        AF_CLK(4);
         __syncthreads();
+        AF_CLK(5);
         if (do_s) {
             if (kp) { keyA |= (U)res[0] << sh; keyB |= (U)res[2] << sh; }
             else { tagA |= (uint64_t)res[0] << sh; tagB |= (uint64_t)res[2] << sh; }
@@ -361,6 +378,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
         return;
     }
     if (!do_s) return;
+    AF_CLK(6);
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
         const R v = sim_at(i);
         if (!(v == v && (double)v <= thresh)) continue;
@@ -375,6 +393,12 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
         const R u = (R)u53(rng_hash(seed, cell0 + c, tt, 4));
         sim_ad[c * osc + tt] = (pthv - th) * u + th;
     }
+    AF_CLK(7);
+#if XS_AF_CLK
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("adapt_freq_block_sel clocks: stage+count %lld  band %lld  count %lld  bar1 %lld  scan %lld  bar2 %lld  update+pth %lld  final %lld  (L %d n0 %d passes %d)\n",
+               clk_[0], clk_[1], clk_[2], clk_[3], clk_[4], clk_[5], clk_[6], clk_[7], L, n0, npass);
+#endif
 }
 
 template <typename R>
