@@ -215,3 +215,26 @@ def test_adapt_freq_add_dims_are_not_pooled(gname, window):
     for m in range(M):
         _, _, edp0, _, _ = oracle.adapt_freq(sim_v[:, 0, m][None], ref_v[:, 0, 0][None], np.asarray(gidx, np.int32), G, window, 1.0, seed=0)
         np.testing.assert_allclose(dP0_b.transpose(*order).values[0, m], edp0.ravel(), rtol=1e-12, equal_nan=True)
+
+
+def test_adapt_freq_sixty_years_one_group():
+    """the size the fuzzer met round 4's row limits at (60 years of daily float64 data under group="time": a block of 21 900
+    values, beyond the LDS sorts): through the public functions, inside a training and outside"""
+    rng = np.random.default_rng(21)
+    n = 60 * 365
+    ref = _da(np.where(rng.random(n) < 0.3, 0.0, rng.gamma(0.8, 6.0, n)), "mm d-1", start="1950-01-01")
+    hist = _da(np.where(rng.random(n) < 0.6, 0.0, rng.gamma(0.8, 6.0, n)), "mm d-1", start="1950-01-01")
+    hist_ad, pth, dP0 = adapt_freq(ref, hist, group="time", thresh="1 mm d-1")
+    d = float(dP0.values.ravel()[0])
+    assert 0.2 < d < 0.6
+    changed = hist_ad.values != hist.values
+    # the share of the sub-threshold values that were lifted is dP0 (the band of ranks between P0_ref / P0_hist * P0_sim and P0_sim)
+    sub = hist.values <= 1.0
+    assert not changed[~sub].any()
+    np.testing.assert_allclose(changed[sub].mean(), d, atol=2e-3)
+    lifted = hist_ad.values[changed]
+    assert (lifted > 1.0).all() and (lifted <= float(pth.values.ravel()[0]) + 1e-12).all()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ADJ = xs.EmpiricalQuantileMapping.train(ref, hist, kind="*", group="time", adapt_freq_thresh="1 mm d-1")
+    np.testing.assert_allclose(ADJ.ds.pth.values.ravel(), pth.values.ravel())
