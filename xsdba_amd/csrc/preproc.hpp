@@ -124,7 +124,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
     constexpr int KBY = (int)sizeof(U);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *cnt = reinterpret_cast<int *>(smem);  // [0..3] #valid / #(<= thresh) of sim, of ref
-    int *res2 = cnt + 8;                       // [pass & 1][2 s], [2 s + 1]: the digit of target s, its rank among that bin's
+    int *res2 = cnt + 8;                       // [pass & 1][12]: [2 s], [2 s + 1]: the digit of target s, its rank among that bin's; [8 + s]: the bin's count
     int *hist2 = cnt + 32;                     // [pass & 1][4][256]
     R *sv = reinterpret_cast<R *>(hist2 + 2048);
     R *srv = sv + Lcap;
@@ -247,11 +247,16 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
 #endif
     // (two targets of a row share a histogram as long as the digits chosen for them are the same: the exponent bytes of a row's
     //  keys nearly always, every byte when both statistics fall on one value — half the adds of those passes)
-    bool sameAB = true, sameCD = true;
+    // An end of the band whose bin holds ONE candidate is known without its remaining digits (nothing else shares its prefix:
+    // every other element compares by the prefix alone) — they are filled with zeros (the lower end) / ones (the upper end) and
+    // the target leaves the passes.  Distinct values settle after two or three key passes; a tie group (the zeros of a dry
+    // season) after two tag passes as a rule (16 random bits among a few hundred candidates).
+    bool sameAB = true, sameCD = true, doneA = false, doneB = false, act_s = do_s;
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) hist2[i] = 0;
     __syncthreads();
     for (int p = 0; p < npass; p++) {
-        int *hist = hist2 + 1024 * (p & 1), *res = res2 + 8 * (p & 1);
+        if (!act_s && !(do_r && p < KBY)) break;  // (both ends of the band known, the ref row's statistics complete)
+        int *hist = hist2 + 1024 * (p & 1), *res = res2 + 12 * (p & 1);
         {   // the bins of the next pass (last read before the second barrier of the previous pass)
             int *hn = hist2 + 1024 * ((p + 1) & 1);
             for (int i = threadIdx.x; i < 1024; i += blockDim.x) hn[i] = 0;
@@ -261,7 +266,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
         const bool first = p == 0 || p == KBY;  // (no digits of the key / of the tag chosen yet)
         for (int i0 = 0; i0 < L; i0 += blockDim.x) {
             const int i = i0 + (int)threadIdx.x;
-            if (do_s) {
+            if (act_s) {
                 bool onA = false, onB = false;
                 int d = 0;
                 if (i < L) {
@@ -270,10 +275,10 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
                         const U k = to_key(v + (R)0);
                         if (kp) {
                             d = (int)((k >> sh) & 0xFF);
-                            onA = first || ((k ^ keyA) >> (sh + 8)) == 0;
-                            onB = first || ((k ^ keyB) >> (sh + 8)) == 0;
+                            onA = !doneA && (first || ((k ^ keyA) >> (sh + 8)) == 0);
+                            onB = !doneB && (first || ((k ^ keyB) >> (sh + 8)) == 0);
                         } else {
-                            const bool mA = k == keyA, mB = k == keyB;
+                            const bool mA = !doneA && k == keyA, mB = !doneB && k == keyB;
                             if (mA || mB) {
                                 const uint64_t tg = tag_of(tt_at(i), i);
                                 d = (int)((tg >> sh) & 0xFF);
@@ -307,7 +312,7 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
         AF_CLK(3);
         // a wave per target: the bin that holds its k-th candidate, and k among that bin's
         for (int s_ = wid; s_ < 4; s_ += nw) {
-            if (s_ < 2 ? !do_s : !(do_r && kp)) continue;
+            if (s_ < 2 ? (!act_s || (s_ == 0 ? doneA : doneB)) : !(do_r && kp)) continue;
             const int k = s_ == 0 ? kA : (s_ == 1 ? kB : (s_ == 2 ? kC : kD));
             const int *h = hist + 256 * ((s_ == 1 && sameAB) ? 0 : ((s_ == 3 && sameCD) ? 2 : s_)) + 4 * lane;
             const int c0 = h[0], c1 = h[1], c2 = h[2], c3 = h[3];
@@ -319,16 +324,30 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
                 if (r >= c0) { r -= c0; j = 1; if (r >= c1) { r -= c1; j = 2; if (r >= c2) { r -= c2; j = 3; } } }
                 res[2 * s_] = 4 * lane + j;
                 res[2 * s_ + 1] = r;
+                res[8 + s_] = j == 0 ? c0 : (j == 1 ? c1 : (j == 2 ? c2 : c3));
             }
         }
         AF_CLK(4);
         __syncthreads();
         AF_CLK(5);
-        if (do_s) {
-            if (kp) { keyA |= (U)res[0] << sh; keyB |= (U)res[2] << sh; }
-            else { tagA |= (uint64_t)res[0] << sh; tagB |= (uint64_t)res[2] << sh; }
-            kA = res[1]; kB = res[3];
-            sameAB = sameAB && res[0] == res[2];
+        if (act_s) {
+            const bool sab = sameAB && !doneA && !doneB && res[0] == res[2];
+            if (!doneA) {
+                if (kp) keyA |= (U)res[0] << sh; else tagA |= (uint64_t)res[0] << sh;
+                kA = res[1];
+                doneA = res[8] == 1;  // (the digits below stay zero)
+            }
+            if (!doneB) {
+                if (kp) keyB |= (U)res[2] << sh; else tagB |= (uint64_t)res[2] << sh;
+                kB = res[3];
+                if (res[9] == 1) {
+                    doneB = true;  // the digits below: ones
+                    if (kp) { keyB |= ((U)1 << sh) - (U)1; tagB = ~0ull; }
+                    else tagB |= (1ull << sh) - 1ull;
+                }
+            }
+            sameAB = sab;
+            act_s = !(doneA && doneB);
         }
         if (do_r && kp) { keyC |= (U)res[4] << sh; keyD |= (U)res[6] << sh; kC = res[5]; kD = res[7]; sameCD = sameCD && res[4] == res[6]; }
     }
