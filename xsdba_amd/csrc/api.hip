@@ -1663,7 +1663,7 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
         Lcap = sel_b + (size_t)pl->max_row * per <= (size_t)ctx->lds_limit ? pl->max_row : 0;
         lds = sel_b + (size_t)Lcap * per;
     }
-    if ((rc = set_lds(xs::k_adapt_freq<R>, lds, ctx, "the adapt_freq rows"))) return rc;
+    if ((rc = sorts ? set_lds(xs::k_adapt_freq<R, true>, lds, ctx, "the adapt_freq rows") : set_lds(xs::k_adapt_freq<R, false>, lds, ctx, "the adapt_freq rows"))) return rc;
     // [0] unused, [1] length of the work list, [2...] the (cell, group) blocks with dP0 > 0
     void *flag;
     if ((rc = ensure(ctx, S_FLAGS, sizeof(int) * (ng + 2), &flag))) return rc;
@@ -1688,7 +1688,8 @@ int adapt_freq_impl(xsdba_hip_ctx *ctx, const void *sim, const void *ref, int64_
     {
         LaunchScope ls(ctx, "k_adapt_freq");
         const unsigned grid = screened ? (unsigned)std::min<size_t>(ng, (size_t)32 * ctx->n_cu) : (unsigned)ng;
-        hipLaunchKernelGGL(xs::k_adapt_freq<R>, dim3(grid), dim3(NT), lds, ctx->stream, (const R *)s.dev,
+        auto *kern = sorts ? xs::k_adapt_freq<R, true> : xs::k_adapt_freq<R, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, ctx->stream, (const R *)s.dev,
                            ref ? (const R *)r.dev : (const R *)nullptr, s.sc, ref ? r.sc : (int64_t)0, pl->d_row_ptr, pl->d_row_idx,
                            pl->d_gidx, G, thresh, seed, cell0, ref ? 1 : 0, ref ? (double *)o0.dev : (double *)const_cast<void *>(i0),
                            ref ? (double *)o1.dev : (double *)const_cast<void *>(i1), ref ? (R *)o2.dev : (R *)const_cast<void *>(i2),

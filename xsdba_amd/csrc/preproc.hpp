@@ -636,8 +636,10 @@ __global__ void k_af_screen(const R *__restrict__ sim, const R *__restrict__ ref
     }
 }
 
-template <typename R>
-__global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
+// SORTS: the LDS-sort block function (XSDBA_HIP_AF_SELECT=0) — its own instantiation, so that the selection keeps its registers
+// (the two in one kernel: 88 VGPRs, five waves per SIMD)
+template <typename R, bool SORTS = false>
+__global__ __attribute__((amdgpu_waves_per_eu(SORTS ? 4 : 8))) void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ ref, int64_t sc, int64_t rsc,
                              const int *__restrict__ row_ptr, const int *__restrict__ row_idx, const int *__restrict__ gidx, int G,
                              double thresh, uint64_t seed, int64_t cell0, int train, double *__restrict__ P0_ref,
                              double *__restrict__ P0_hist, R *__restrict__ pth, double *__restrict__ dP0_out,
@@ -649,7 +651,7 @@ __global__ void k_adapt_freq(const R *__restrict__ sim, const R *__restrict__ re
     const int64_t n_items = work_list ? (int64_t)*n_work : n_all;
     for (int64_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const int64_t id = work_list ? (int64_t)work_list[item] : item;
-        if (Lcap >= 0)
+        if constexpr (!SORTS)
             adapt_freq_block_sel<R>(sim, ref, sc, rsc, row_ptr, row_idx, gidx, G, thresh, seed, cell0, train, P0_ref, P0_hist, pth, dP0_out,
                                     sim_ad, osc, Lcap, id);
         else
