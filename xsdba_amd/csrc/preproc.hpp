@@ -96,6 +96,9 @@ template <typename U> __device__ __forceinline__ void block_bitonic_sort_pairs(U
 #ifndef XS_AF_CLK
 #define XS_AF_CLK 0
 #endif
+#ifndef XS_AF_BATCH  // elements of a thread whose index loads, then value loads, are issued together when the rows are read (0: one by one)
+#define XS_AF_BATCH 2
+#endif
 #if XS_AF_CLK  // shader-clock shares of adapt_freq_block_sel's phases, printed by the first work item of block 0 (tuning builds)
 #define AF_CLK(i) do { const long long now_ = clock64(); clk_[i] += now_ - last_; last_ = now_; } while (0)
 #else
@@ -144,6 +147,28 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
     // ---- the rows, once: counts (utils.ecdf :87-105), staged copies
     if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
     int c_n = 0, c_0 = 0, r_n = 0, r_0 = 0;
+#if XS_AF_BATCH
+    for (int i0 = threadIdx.x; i0 < L; i0 += XS_AF_BATCH * blockDim.x) {
+        int tt[XS_AF_BATCH];
+        R v[XS_AF_BATCH], rv[XS_AF_BATCH];
+#pragma unroll
+        for (int u = 0; u < XS_AF_BATCH; u++) tt[u] = row_idx[p0 + min(i0 + u * (int)blockDim.x, L - 1)];
+#pragma unroll
+        for (int u = 0; u < XS_AF_BATCH; u++) { v[u] = xs[tt[u]]; rv[u] = train ? xr[tt[u]] : (R)0; }
+#pragma unroll
+        for (int u = 0; u < XS_AF_BATCH; u++) {
+            const int i = i0 + u * (int)blockDim.x;
+            if (i < L) {
+                if (stage) { sv[i] = v[u]; stt[i] = tt[u]; }
+                if (v[u] == v[u]) { c_n++; if ((double)v[u] <= thresh) c_0++; }
+                if (train) {
+                    if (stage) srv[i] = rv[u];
+                    if (rv[u] == rv[u]) { r_n++; if ((double)rv[u] <= thresh) r_0++; }
+                }
+            }
+        }
+    }
+#else
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
         const int tt = row_idx[p0 + i];
         const R v = xs[tt];
@@ -155,9 +180,9 @@ __device__ __forceinline__ void adapt_freq_block_sel(const R *__restrict__ sim, 
             if (rv == rv) { r_n++; if ((double)rv <= thresh) r_0++; }
         }
     }
-    // (the loads of four elements of a thread issued together — indexes, then values — measured: slower, 89.5 against 81 ms per
-    //  8 192 day-of-year cells; the phase is 4.4 ms of the kernel — -DXS_AF_STOP=1 — the rest is the passes: 14 ms per key pass,
-    //  7 per tag pass)
+#endif
+    // (two elements of a thread at a time: -DXS_AF_BATCH=0 / 2 / 4: 1.94 / 1.76 / 1.68 ms per 8 192 one-group cells, 46.7 / 46.6 /
+    //  46.3 per 8 192 day-of-year cells; four spill under the 64-VGPR cap)
 #if defined(XS_AF_STOP) && XS_AF_STOP == 1
     if (c_n == -12345) sim_ad[0] = (R)0;
     return;
